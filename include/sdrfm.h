@@ -1,0 +1,125 @@
+/*
+ * sdrfm.h — C-ABI of the MI355X-native IQ -> FM-audio path ("sdrfm").
+ *
+ * This is the drop-in boundary for the consumer hook that the reference firmware leaves empty:
+ *   - the bulk-IN FSM fills `CommItf.buff` / `CommItf.buffSize` with interleaved uint8 I/Q
+ *     (Middlewares/ST/STM32_USB_Host_Library/Class/RTLSDR/Inc/usbh_rtlsdr.h:165-173) and then does
+ *     nothing in RTLSDR_XFER_COMPLETE (.../RTLSDR/Src/usbh_rtlsdr.c:1094-1097); the application-side
+ *     poll of `xferState` is commented out (src/main.c:76-79).
+ *   - sdrfm_process() is what either hook calls with (buff, USBH_LL_GetLastXferSize()) — see INTEGRATION.md.
+ *
+ * Conventions follow the reference's class-driver layer:
+ *   - return value 0 == OK, same numeric values as USBH_StatusTypeDef for the first five codes
+ *     (Middlewares/ST/STM32_USB_Host_Library/Core/Inc/usbh_def.h:303-311);
+ *   - errors are returned, never thrown/aborted; a handle is not thread-safe (single superloop model,
+ *     src/main.c:72-80); independent handles may be used concurrently;
+ *   - the callee is finished with `iq` when the call returns (the reference re-arms the same buffer
+ *     immediately, usbh_rtlsdr.c:1068-1077), except in SDRFM_F_DEVICE_PTRS mode (see below).
+ *
+ * Arithmetic (build-defined; the reference holds no DSP code — see DESIGN.md "Frozen spec"):
+ *   x[n]  = ((float)I_n - 127.5f) + j((float)Q_n - 127.5f)
+ *   y[m]  = sum_{k} h[k] * x[(m+1)*D - 1 - k]        x[n<0] = 0, fp32 FMA chain, oldest sample first
+ *   d[m]  = atan2f(Im(y[m]*conj(y[m-1])), Re(...))   y[-1] = 0, d = 0 when both parts are exactly 0
+ *   a[j]  = sum_{k} g[k] * d[(j+1)*Da - 1 - k]       d[m<0] = 0, fp32 FMA chain, oldest sample first
+ * All state (FIR history, y[m-1], d history, decimator phases) persists across calls; chunk lengths need
+ * not be multiples of D.
+ *
+ * There is NO CPU fallback in this library: every entry point that computes runs hand-written HIP kernels
+ * on a gfx950 device and fails with SDRFM_NO_DEVICE when none is usable.
+ */
+#ifndef SDRFM_H
+#define SDRFM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDRFM_ABI_VERSION 1u
+
+/* status codes: first five numerically equal USBH_OK..USBH_UNRECOVERED_ERROR (usbh_def.h:303-311) */
+enum {
+  SDRFM_OK = 0,
+  SDRFM_BUSY = 1,
+  SDRFM_FAIL = 2,
+  SDRFM_NOT_SUPPORTED = 3,
+  SDRFM_UNRECOVERED_ERROR = 4,
+  /* extensions */
+  SDRFM_EINVAL = 16,      /* NULL pointer, zero sizes, bad struct_size, non-finite taps            */
+  SDRFM_EODD = 17,        /* nbytes not a multiple of 2 (half an I/Q pair)                          */
+  SDRFM_ECAPACITY = 18,   /* audio buffer / stride too small, or nbytes > max_bytes_per_call        */
+  SDRFM_NO_DEVICE = 19,   /* no usable gfx950 HIP device, or HIP runtime error at create            */
+  SDRFM_ENOMEM = 20
+};
+
+#define SDRFM_MAX_TAPS 256u       /* limit for fir_taps and audio_taps */
+#define SDRFM_MAX_DECIM 64u
+
+/* flags for sdrfm_process_batch */
+#define SDRFM_F_DEVICE_PTRS 1u    /* iq and audio are device pointers on cfg.device; call is enqueued on the
+                                     handle's stream and returns without synchronising */
+
+typedef struct sdrfm_config {
+  uint32_t struct_size;           /* = sizeof(sdrfm_config) */
+  uint32_t n_streams;             /* independent IQ streams processed per call (>= 1) */
+  uint32_t fir_taps;              /* T  : channel low-pass taps, 1..SDRFM_MAX_TAPS */
+  uint32_t fir_decim;             /* D  : 1..SDRFM_MAX_DECIM (2.4 MS/s / 10 = 240 kS/s, the rate the firmware
+                                          programs: usbh_rtlsdr.c:898) */
+  const float* fir_coeffs;        /* h[0..T), copied at create */
+  uint32_t audio_taps;            /* Ta : audio low-pass taps, 1..SDRFM_MAX_TAPS */
+  uint32_t audio_decim;           /* Da : 1..SDRFM_MAX_DECIM (240 kS/s / 5 = 48 kHz) */
+  const float* audio_coeffs;      /* g[0..Ta), copied at create */
+  uint32_t max_bytes_per_call;    /* per-stream upper bound for nbytes (sizes device staging); 0 = 1 MiB */
+  int32_t  device;                /* HIP device ordinal */
+  uint32_t flags;                 /* reserved, must be 0 */
+} sdrfm_config;
+
+typedef struct sdrfm sdrfm_t;
+
+/* Create / destroy. The handle owns its device buffers, streaming state and output staging — it plays the role
+ * of the class handle malloc'd in InterfaceInit and freed in InterfaceDeInit (usbh_rtlsdr.c:182-183,635-638). */
+int  sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out);
+void sdrfm_destroy(sdrfm_t* h);
+
+/* Zero all streaming state (as after create). */
+int  sdrfm_reset(sdrfm_t* h);
+
+/* Number of audio samples per stream that the NEXT process call with `nbytes` will produce (depends on the
+ * decimator phases carried in the handle). */
+int  sdrfm_audio_count(const sdrfm_t* h, uint32_t nbytes, uint32_t* n_audio);
+
+/* Single-stream hand-off (handle must have n_streams == 1): host buffer in, host audio out, synchronous.
+ *   iq      : interleaved uint8 I0 Q0 I1 Q1 ... exactly as the RTL2832 bulk pipe delivers it
+ *             (RTLSDR_CommItfTypedef.buff, usbh_rtlsdr.h:165-173)
+ *   nbytes  : valid bytes (USBH_LL_GetLastXferSize, usbh_conf.c:350-353); must be even; 0 is a no-op
+ *   audio   : receives *n_audio floats (radians per 240 kS/s sample, low-passed, at 48 kHz)            */
+int  sdrfm_process(sdrfm_t* h, const uint8_t* iq, uint32_t nbytes,
+                   float* audio, uint32_t audio_cap, uint32_t* n_audio);
+
+/* Batched hand-off: n_streams buffers of nbytes_per_stream bytes, stream s at iq + s*iq_stride (bytes);
+ * audio for stream s at audio + s*audio_stride (floats). All streams advance by the same amount, so
+ * *n_audio (per stream) is one number. With SDRFM_F_DEVICE_PTRS the buffers are device memory and the work is
+ * only enqueued (use sdrfm_synchronize or the stream). */
+int  sdrfm_process_batch(sdrfm_t* h, const uint8_t* iq, size_t iq_stride, uint32_t nbytes_per_stream,
+                         float* audio, size_t audio_stride, uint32_t* n_audio, uint32_t flags);
+
+/* Run on a caller-owned HIP stream (hipStream_t passed as void*; NULL = the handle's own stream). */
+int  sdrfm_set_stream(sdrfm_t* h, void* hip_stream);
+int  sdrfm_synchronize(sdrfm_t* h);
+
+/* Introspection used by bench/tests: which kernel variant serves this configuration ("spec T64 D10 R4", "generic"). */
+const char* sdrfm_kernel_name(const sdrfm_t* h);
+uint32_t    sdrfm_abi_version(void);
+const char* sdrfm_strerror(int status);
+
+/* Test hooks: HOST evaluation of the exact arithmetic the device uses for stage K3 (same source, same rounding), so
+ * that its accuracy against libm can be checked without a GPU.  No compute path calls these. */
+float sdrfm_host_atan2f(float y, float x);
+float sdrfm_host_discriminate(float yr, float yi, float pr, float pi);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDRFM_H */

@@ -1,0 +1,93 @@
+"""ctypes wrapper of oracle/libsdrfm_oracle.so — TEST INFRASTRUCTURE (tests/, smoke(), bench.py's cpu_baseline only)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "libsdrfm_oracle.so")
+        if not os.path.exists(path):
+            raise ImportError("%s missing: run `make -C oracle` or __graft_entry__.build()" % path)
+        lib = C.CDLL(path)
+        vp, f32p = C.c_void_p, C.c_void_p
+        lib.sdrfm_oracle_create.argtypes = [C.c_uint32, C.c_uint32, f32p, C.c_uint32, C.c_uint32, f32p]
+        lib.sdrfm_oracle_create.restype = vp
+        lib.sdrfm_oracle_destroy.argtypes = [vp]
+        lib.sdrfm_oracle_destroy.restype = None
+        lib.sdrfm_oracle_reset.argtypes = [vp]
+        lib.sdrfm_oracle_reset.restype = None
+        lib.sdrfm_oracle_process.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t]
+        lib.sdrfm_oracle_process.restype = C.c_long
+        lib.sdrfm_oracle_process_f64.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t]
+        lib.sdrfm_oracle_process_f64.restype = C.c_long
+        lib.sdrfm_oracle_last_stage.argtypes = [vp, vp, vp, C.c_size_t]
+        lib.sdrfm_oracle_last_stage.restype = C.c_size_t
+        _lib = lib
+    return _lib
+
+
+class Oracle:
+    """One stream of the scalar-C oracle."""
+
+    def __init__(self, h, g, D=10, Da=5):
+        self._lib = _load()
+        self.h = np.ascontiguousarray(h, dtype=np.float32)
+        self.g = np.ascontiguousarray(g, dtype=np.float32)
+        self.D, self.Da = int(D), int(Da)
+        self._o = self._lib.sdrfm_oracle_create(self.h.size, self.D, self.h.ctypes.data, self.g.size, self.Da,
+                                                self.g.ctypes.data)
+        if not self._o:
+            raise ValueError("sdrfm_oracle_create failed")
+
+    def close(self):
+        if self._o:
+            self._lib.sdrfm_oracle_destroy(self._o)
+            self._o = None
+
+    def __del__(self):
+        self.close()
+
+    def reset(self):
+        self._lib.sdrfm_oracle_reset(self._o)
+
+    def _cap(self, nbytes):
+        return nbytes // 2 // self.D // self.Da + 2
+
+    def process(self, iq):
+        iq = np.ascontiguousarray(iq, dtype=np.uint8).reshape(-1)
+        out = np.empty(self._cap(iq.size), dtype=np.float32)
+        n = self._lib.sdrfm_oracle_process(self._o, iq.ctypes.data, iq.size, out.ctypes.data, out.size)
+        if n < 0:
+            raise ValueError("sdrfm_oracle_process rejected its arguments")
+        return out[:n].copy()
+
+    def process_f64(self, iq):
+        iq = np.ascontiguousarray(iq, dtype=np.uint8).reshape(-1)
+        out = np.empty(self._cap(iq.size), dtype=np.float64)
+        n = self._lib.sdrfm_oracle_process_f64(self._o, iq.ctypes.data, iq.size, out.ctypes.data, out.size)
+        if n < 0:
+            raise ValueError("sdrfm_oracle_process_f64 rejected its arguments")
+        return out[:n].copy()
+
+    def last_stage(self):
+        n = self._lib.sdrfm_oracle_last_stage(self._o, None, None, 0)
+        y = np.empty(2 * n, dtype=np.float32)
+        d = np.empty(n, dtype=np.float32)
+        self._lib.sdrfm_oracle_last_stage(self._o, y.ctypes.data, d.ctypes.data, n)
+        return y.reshape(-1, 2), d
+
+
+def process_batch(h, g, iq2d, D=10, Da=5):
+    """[n_streams, nbytes] -> [n_streams, n_audio] with a fresh oracle per stream."""
+    outs = []
+    for s in range(iq2d.shape[0]):
+        o = Oracle(h, g, D, Da)
+        outs.append(o.process(iq2d[s]))
+        o.close()
+    return np.stack(outs)

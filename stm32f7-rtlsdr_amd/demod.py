@@ -1,0 +1,128 @@
+"""FmDemod — Python mirror of the sdrfm_* C entry points (include/sdrfm.h).
+
+Host-buffer calls take/return numpy arrays; device-buffer calls take torch CUDA(HIP) tensors and only enqueue work on a
+HIP stream (torch is used for device memory and streams only).
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import lib as _l
+
+
+@dataclass
+class FmConfig:
+    fir_coeffs: np.ndarray          # h[0..T)
+    audio_coeffs: np.ndarray        # g[0..Ta)
+    fir_decim: int = 10             # 2.4 MS/s -> 240 kS/s, the rate the firmware programs (usbh_rtlsdr.c:898)
+    audio_decim: int = 5            # 240 kS/s -> 48 kHz
+    n_streams: int = 1
+    max_bytes_per_call: int = 1 << 20
+    device: int = 0
+
+
+class FmDemod:
+    """One sdrfm_t handle. Not thread-safe (same model as the reference's single superloop, src/main.c:72-80)."""
+
+    def __init__(self, cfg: FmConfig):
+        self._lib = _l.load_library()
+        self.cfg = cfg
+        h = np.ascontiguousarray(cfg.fir_coeffs, dtype=np.float32)
+        g = np.ascontiguousarray(cfg.audio_coeffs, dtype=np.float32)
+        c = _l.Config()
+        c.struct_size = C.sizeof(_l.Config)
+        c.n_streams = cfg.n_streams
+        c.fir_taps, c.fir_decim = h.size, cfg.fir_decim
+        c.fir_coeffs = h.ctypes.data_as(C.POINTER(C.c_float))
+        c.audio_taps, c.audio_decim = g.size, cfg.audio_decim
+        c.audio_coeffs = g.ctypes.data_as(C.POINTER(C.c_float))
+        c.max_bytes_per_call = cfg.max_bytes_per_call
+        c.device = cfg.device
+        c.flags = 0
+        self._h = C.c_void_p()
+        st = self._lib.sdrfm_create(C.byref(c), C.byref(self._h))
+        if st != _l.OK:
+            self._h = None
+            raise _l.SdrfmError(st, "sdrfm_create")
+
+    # -- lifecycle --------------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sdrfm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _ck(self, st, where):
+        if st != _l.OK:
+            raise _l.SdrfmError(st, where)
+
+    def reset(self):
+        self._ck(self._lib.sdrfm_reset(self._h), "sdrfm_reset")
+
+    @property
+    def kernel_name(self):
+        return self._lib.sdrfm_kernel_name(self._h).decode()
+
+    def audio_count(self, nbytes):
+        n = C.c_uint32()
+        self._ck(self._lib.sdrfm_audio_count(self._h, int(nbytes), C.byref(n)), "sdrfm_audio_count")
+        return n.value
+
+    def set_stream(self, hip_stream_ptr):
+        self._ck(self._lib.sdrfm_set_stream(self._h, C.c_void_p(int(hip_stream_ptr) if hip_stream_ptr else None)),
+                 "sdrfm_set_stream")
+
+    def synchronize(self):
+        self._ck(self._lib.sdrfm_synchronize(self._h), "sdrfm_synchronize")
+
+    # -- host buffers -----------------------------------------------------------------------------------------
+    def process(self, iq: np.ndarray) -> np.ndarray:
+        """sdrfm_process: single stream, uint8 interleaved I/Q in, float32 audio out."""
+        iq = np.ascontiguousarray(iq, dtype=np.uint8).reshape(-1)
+        # capacity from the handle itself; odd lengths are passed through so the C side reports SDRFM_EODD
+        cap = self.audio_count(iq.size & ~1) + 1
+        out = np.empty(cap, dtype=np.float32)
+        n = C.c_uint32()
+        self._ck(self._lib.sdrfm_process(self._h, iq.ctypes.data, iq.size, out.ctypes.data, cap, C.byref(n)),
+                 "sdrfm_process")
+        return out[: n.value]
+
+    def process_batch(self, iq: np.ndarray) -> np.ndarray:
+        """sdrfm_process_batch on host memory: iq [n_streams, nbytes] uint8 -> audio [n_streams, n_audio] float32."""
+        iq = np.ascontiguousarray(iq, dtype=np.uint8)
+        assert iq.ndim == 2 and iq.shape[0] == self.cfg.n_streams
+        nbytes = iq.shape[1]
+        cap = max(self.audio_count(nbytes & ~1), 1)
+        out = np.empty((iq.shape[0], cap), dtype=np.float32)
+        n = C.c_uint32()
+        self._ck(self._lib.sdrfm_process_batch(self._h, iq.ctypes.data, nbytes, nbytes, out.ctypes.data, cap,
+                                               C.byref(n), 0), "sdrfm_process_batch")
+        return out[:, : n.value]
+
+    # -- device buffers (torch tensors on cfg.device) -----------------------------------------------------------
+    def process_batch_device(self, iq, audio, nbytes=None):
+        """Enqueue one batch on device-resident buffers (SDRFM_F_DEVICE_PTRS); returns n_audio per stream.
+
+        iq: torch.uint8 [n_streams, >=nbytes] (row stride = iq.stride(0)); audio: torch.float32 [n_streams, cap].
+        Nothing is synchronised; the work runs on the stream given to set_stream() (or the handle's own).
+        """
+        assert iq.is_cuda and audio.is_cuda and iq.dim() == 2 and audio.dim() == 2
+        assert iq.stride(1) == 1 and audio.stride(1) == 1
+        nbytes = iq.shape[1] if nbytes is None else int(nbytes)
+        n = C.c_uint32()
+        self._ck(self._lib.sdrfm_process_batch(self._h, C.c_void_p(iq.data_ptr()), iq.stride(0), nbytes,
+                                               C.c_void_p(audio.data_ptr()), audio.stride(0), C.byref(n),
+                                               _l.F_DEVICE_PTRS), "sdrfm_process_batch(device)")
+        return n.value

@@ -1,0 +1,89 @@
+"""ctypes binding of csrc/libsdrfm.so — one Python function per C entry point of include/sdrfm.h."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+STATUS = {
+    0: "SDRFM_OK", 1: "SDRFM_BUSY", 2: "SDRFM_FAIL", 3: "SDRFM_NOT_SUPPORTED", 4: "SDRFM_UNRECOVERED_ERROR",
+    16: "SDRFM_EINVAL", 17: "SDRFM_EODD", 18: "SDRFM_ECAPACITY", 19: "SDRFM_NO_DEVICE", 20: "SDRFM_ENOMEM",
+}
+OK, EINVAL, EODD, ECAPACITY, NO_DEVICE = 0, 16, 17, 18, 19
+F_DEVICE_PTRS = 1
+
+# every symbol include/sdrfm.h declares
+ABI_SYMBOLS = [
+    "sdrfm_create", "sdrfm_destroy", "sdrfm_reset", "sdrfm_audio_count", "sdrfm_process", "sdrfm_process_batch",
+    "sdrfm_set_stream", "sdrfm_synchronize", "sdrfm_kernel_name", "sdrfm_abi_version", "sdrfm_strerror",
+    "sdrfm_host_atan2f", "sdrfm_host_discriminate",
+]
+
+
+class SdrfmError(RuntimeError):
+    def __init__(self, status, where=""):
+        self.status = int(status)
+        name = STATUS.get(self.status, "status %d" % self.status)
+        msg = ""
+        try:
+            msg = load_library().sdrfm_strerror(self.status).decode()
+        except Exception:  # pragma: no cover
+            pass
+        super().__init__("%s%s (%s)" % (where + ": " if where else "", name, msg))
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("n_streams", C.c_uint32), ("fir_taps", C.c_uint32), ("fir_decim", C.c_uint32),
+        ("fir_coeffs", C.POINTER(C.c_float)), ("audio_taps", C.c_uint32), ("audio_decim", C.c_uint32),
+        ("audio_coeffs", C.POINTER(C.c_float)), ("max_bytes_per_call", C.c_uint32), ("device", C.c_int32),
+        ("flags", C.c_uint32),
+    ]
+
+
+def library_path():
+    return os.path.join(_HERE, "csrc", "libsdrfm.so")
+
+
+_lib = None
+
+
+def load_library():
+    """Load libsdrfm.so or raise — never substitute anything else for it."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C stm32f7-rtlsdr_amd/csrc`). There is no fallback implementation." % path)
+    lib = C.CDLL(path)
+    vp, u32, u32p = C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)
+    lib.sdrfm_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    lib.sdrfm_create.restype = C.c_int
+    lib.sdrfm_destroy.argtypes = [vp]
+    lib.sdrfm_destroy.restype = None
+    lib.sdrfm_reset.argtypes = [vp]
+    lib.sdrfm_reset.restype = C.c_int
+    lib.sdrfm_audio_count.argtypes = [vp, u32, u32p]
+    lib.sdrfm_audio_count.restype = C.c_int
+    lib.sdrfm_process.argtypes = [vp, vp, u32, vp, u32, u32p]
+    lib.sdrfm_process.restype = C.c_int
+    lib.sdrfm_process_batch.argtypes = [vp, vp, C.c_size_t, u32, vp, C.c_size_t, u32p, u32]
+    lib.sdrfm_process_batch.restype = C.c_int
+    lib.sdrfm_set_stream.argtypes = [vp, vp]
+    lib.sdrfm_set_stream.restype = C.c_int
+    lib.sdrfm_synchronize.argtypes = [vp]
+    lib.sdrfm_synchronize.restype = C.c_int
+    lib.sdrfm_kernel_name.argtypes = [vp]
+    lib.sdrfm_kernel_name.restype = C.c_char_p
+    lib.sdrfm_abi_version.argtypes = []
+    lib.sdrfm_abi_version.restype = u32
+    lib.sdrfm_strerror.argtypes = [C.c_int]
+    lib.sdrfm_strerror.restype = C.c_char_p
+    lib.sdrfm_host_atan2f.argtypes = [C.c_float, C.c_float]
+    lib.sdrfm_host_atan2f.restype = C.c_float
+    lib.sdrfm_host_discriminate.argtypes = [C.c_float] * 4
+    lib.sdrfm_host_discriminate.restype = C.c_float
+    _lib = lib
+    return lib
