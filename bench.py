@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py — IQ MSamples/s through FIR + FM-demod + resample on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path (sdrfm_process_batch on device-resident buffers: one fused kernel launch) over one
+batch of synthetic IQ: by default BASELINE configs[2] — 256 concurrent 2.4 MS/s streams x 0.1 s (480 000 B each),
+64-tap FIR /10, FM discriminator, 32-tap /5 audio resampler.  With --gpus N (launched by torch.distributed.run) every
+rank owns its own 256 streams on its own GPU (streams are independent: no data-path collective, weak scaling).
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).  The GPU legs never touch oracle/; only the
+`cpu_baseline` leg (rank 0, N=1) times the scalar-C oracle on a bounded sample of the same workload.
+"""
+import argparse
+import glob
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--streams-per-gpu", type=int, default=256)
+    ap.add_argument("--seconds", type=float, default=0.1, help="capture length per stream per step")
+    ap.add_argument("--fir-taps", type=int, default=64)
+    ap.add_argument("--distinct", type=int, default=0, help="distinct synthetic streams (0 = all)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--check", action="store_true", help="also verify a few streams against the oracle (not timed)")
+    return ap.parse_args()
+
+
+def latest_traffic(kernel_name):
+    """HBM bytes per launch from the newest committed PMC summary (profiles/traffic_r*.json), if it is for this kernel."""
+    best = None
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json"))):
+        try:
+            with open(fn) as f:
+                t = json.load(f)
+            if t.get("kernel_name") == kernel_name:
+                best = t
+        except Exception:
+            pass
+    return best
+
+
+def cpu_baseline(pkg, h, g, iq_host, seconds, threads):
+    """Scalar-C oracle on the GPU box's host cores, bounded sample of the same workload."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle.oracle import Oracle
+    n_streams, nbytes = iq_host.shape
+    nsamp = nbytes // 2
+
+    def run(nthreads, budget):
+        orcs = [Oracle(h, g) for _ in range(nthreads)]
+        done, t0 = 0, time.perf_counter()
+
+        def work(i):
+            k = 0
+            while time.perf_counter() - t0 < budget:
+                orcs[i].reset()
+                orcs[i].process(iq_host[(i + k * nthreads) % n_streams])
+                k += 1
+            return k
+        if nthreads == 1:
+            done = work(0)
+        else:
+            with ThreadPoolExecutor(nthreads) as ex:
+                done = sum(ex.map(work, range(nthreads)))
+        dt = time.perf_counter() - t0
+        return done * nsamp / dt / 1e6, done
+
+    v1, n1 = run(1, seconds)
+    out = {"value": round(v1, 3), "unit": "MSamples/s", "cores": 1, "kind": "port",
+           "sample": "%d stream-chunks of the workload (%.1f s x 2.4 MS/s each), scalar-C oracle, 1 thread, %.0f s" % (n1, nsamp / 2.4e6, seconds)}
+    if threads > 1:
+        vn, nn = run(threads, max(3.0, seconds / 2))
+        out["all_cores"] = {"value": round(vn, 3), "cores": threads, "stream_chunks": nn}
+    return out
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = importlib.import_module("stm32f7-rtlsdr_amd")
+    fs = 2.4e6
+    ns = args.streams_per_gpu
+    nsamp = int(round(args.seconds * fs))
+    nbytes = 2 * nsamp
+    h, g = pkg.default_config(args.fir_taps, fs=fs)
+    D, Da = 10, 5
+
+    # synthetic input: FM test signal, distinct PRNG stream per (rank, stream)
+    distinct = args.distinct if args.distinct > 0 else ns
+    t_gen = time.perf_counter()
+    base = pkg.make_iq(distinct, nsamp, mode="fm", fs=fs, first_id=rank * ns)
+    iq_host = base if distinct == ns else np.tile(base, ((ns + distinct - 1) // distinct, 1))[:ns]
+    t_gen = time.perf_counter() - t_gen
+
+    dm = pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, fir_decim=D, audio_decim=Da, n_streams=ns, device=local_rank))
+    stream = torch.cuda.Stream()
+    dm.set_stream(stream.cuda_stream)
+    n_audio_max = nsamp // D // Da + 1
+    with torch.cuda.stream(stream):
+        iq = torch.from_numpy(iq_host).cuda()
+        audio = torch.zeros((ns, n_audio_max), dtype=torch.float32, device="cuda")
+    stream.synchronize()
+
+    def step():
+        return dm.process_batch_device(iq, audio)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    n_audio = 0
+    for a, b in evs:
+        a.record(stream)
+        n_audio = step()
+        b.record(stream)
+    fence()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = [a.elapsed_time(b) for a, b in evs]
+    kernel_ms_avg = float(np.mean(kernel_ms))
+
+    ok = None
+    if args.check and rank == 0:
+        from oracle.oracle import Oracle
+        dm.reset()
+        step()
+        dm.synchronize()
+        got = audio[:, :n_audio].cpu().numpy()
+        ok = True
+        for s in (0, ns // 2, ns - 1):
+            want = Oracle(h, g).process(iq_host[s])
+            err = np.max(np.abs(got[s] - want) / np.maximum(np.abs(want), 1.0))
+            ok = ok and bool(err <= 1e-5)
+
+    if rank == 0:
+        total_samples = float(world) * ns * nsamp * args.steps
+        value = total_samples / elapsed / 1e6
+        samples_per_launch = ns * nsamp
+        alg_bytes = samples_per_launch * 2.0 + ns * n_audio * 4.0        # 2 B in + 4/(D*Da) B out per IQ sample
+        achieved = alg_bytes / (kernel_ms_avg * 1e-3) / 1e9
+        traffic = latest_traffic(dm.kernel_name)
+        res = {
+            "metric": "IQ MSamples/s through FIR+FM-demod+resample",
+            "value": round(value, 1), "unit": "MSamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: %d concurrent 2.4 MS/s uint8 IQ streams per GPU x %.1f s (%d B each), "
+                                   "%d-tap FIR /%d + FM discriminator + %d-tap /%d -> 48 kHz; device-resident, streams sharded "
+                                   "across GPUs with no collective" % (ns, args.seconds, nbytes, args.fir_taps, D, len(g), Da),
+                       "streams_per_gpu": ns, "bytes_per_stream": nbytes, "fir_taps": args.fir_taps, "kernel": dm.kernel_name,
+                       "bytes_per_sample_algorithmic": round(alg_bytes / samples_per_launch, 4),
+                       "GB_per_s_input": round(value * 2e6 / 1e9, 1)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
+                         "kernel": dm.kernel_name, "kernel_ms_avg": round(kernel_ms_avg, 4),
+                         "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
+                         "algorithmic_bytes_per_launch": alg_bytes},
+            "gen_seconds": round(t_gen, 2),
+        }
+        if ok is not None:
+            res["parity_ok"] = ok
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(pkg, h, g, iq_host[: min(ns, 64)], args.cpu_seconds, os.cpu_count() or 1)
+        print(json.dumps(res), flush=True)
+    dm.set_stream(None)
+    dm.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

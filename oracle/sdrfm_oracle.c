@@ -16,7 +16,7 @@
  *                                                                vendors (CMSIS/core/arm_math.h:3291-3331).  Accumulation:
  *                                                                acc = fmaf(h[k], x, acc), OLDEST sample first (k = T-1 .. 0).
  *   K3  p     = y[m] * conj(y[m-1]),  y[-1] = 0
- *       re    = fmaf(yr, pr, yi*pi);  im = fmaf(yi, pr, -(yr*pi))
+ *       re    = fmaf(yr, pr, yi*pi);  im = yi*pr - yr*pi   (two rounded products, one subtraction)
  *       d[m]  = (re == 0 && im == 0) ? 0 : atan2f(im, re)
  *   K4  a[j]  = sum_k g[k] d[(j+1)Da-1-k],  d[m<0] = 0          same convention and accumulation order as K2.
  */
@@ -122,7 +122,7 @@ long sdrfm_oracle_process(sdrfm_oracle* o, const uint8_t* iq, size_t nbytes, flo
       ai = fmaf(c, xi[j], ai);
     }
     const float re = fmaf(ar, pr, ai * pi);
-    const float im = fmaf(ai, pr, -(ar * pi));
+    const float im = ai * pr - ar * pi;             /* two rounded products: exactly 0 for y[m] == y[m-1] */
     const float d = (re == 0.0f && im == 0.0f) ? 0.0f : atan2f(im, re);
     wd[Hd + m] = d;
     o->last_y[2 * m] = ar; o->last_y[2 * m + 1] = ai; o->last_d[m] = d;

@@ -43,7 +43,7 @@ SDRFM_HD float sdrfm_atan2f(float y, float x) {
 /* K3: FM discriminator of consecutive decimated samples y (re,im) and previous p (re,im). */
 SDRFM_HD float sdrfm_discriminate(float yr, float yi, float pr, float pi) {
   const float re = __builtin_fmaf(yr, pr, yi * pi);
-  const float im = __builtin_fmaf(yi, pr, -(yr * pi));
+  const float im = yi * pr - yr * pi; /* two rounded products (TU is built with -ffp-contract=off) */
   return (re == 0.0f && im == 0.0f) ? 0.0f : sdrfm_atan2f(im, re);
 }
 
