@@ -57,6 +57,9 @@ enum {
 #define SDRFM_MAX_TAPS 256u       /* limit for fir_taps and audio_taps */
 #define SDRFM_MAX_DECIM 64u
 
+/* flags for sdrfm_config.flags */
+#define SDRFM_CFG_FORCE_GENERIC 1u  /* never select a (T,D)-specialised kernel: run the generic kernel (tests) */
+
 /* flags for sdrfm_process_batch */
 #define SDRFM_F_DEVICE_PTRS 1u    /* iq and audio are device pointers on cfg.device; call is enqueued on the
                                      handle's stream and returns without synchronising */
@@ -73,7 +76,7 @@ typedef struct sdrfm_config {
   const float* audio_coeffs;      /* g[0..Ta), copied at create */
   uint32_t max_bytes_per_call;    /* per-stream upper bound for nbytes (sizes device staging); 0 = 1 MiB */
   int32_t  device;                /* HIP device ordinal */
-  uint32_t flags;                 /* reserved, must be 0 */
+  uint32_t flags;                 /* SDRFM_CFG_* */
 } sdrfm_config;
 
 typedef struct sdrfm sdrfm_t;
@@ -109,7 +112,8 @@ int  sdrfm_process_batch(sdrfm_t* h, const uint8_t* iq, size_t iq_stride, uint32
 int  sdrfm_set_stream(sdrfm_t* h, void* hip_stream);
 int  sdrfm_synchronize(sdrfm_t* h);
 
-/* Introspection used by bench/tests: which kernel variant serves this configuration ("spec T64 D10 R4", "generic"). */
+/* Introspection used by bench/tests: the kernel variant that served the LAST call (before any call: the one the
+ * configuration selects), e.g. "fast T64 D10 R4 Ta32 Da5" or "generic T7 D3 Ta5 Da4 NA64". */
 const char* sdrfm_kernel_name(const sdrfm_t* h);
 uint32_t    sdrfm_abi_version(void);
 const char* sdrfm_strerror(int status);

@@ -31,6 +31,12 @@
 #include "../../include/sdrfm.h"
 #include "sdrfm_math.h"
 
+typedef float f2_t __attribute__((ext_vector_type(2)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+typedef int i4_t __attribute__((ext_vector_type(4)));
+__device__ f4_t llvm_amdgcn_raw_buffer_load_format_v4f32(i4_t rsrc, int voffset, int soffset, int aux) __asm(
+    "llvm.amdgcn.raw.buffer.load.format.v4f32");
+
 namespace {
 
 struct CallParams {
@@ -52,9 +58,10 @@ struct CallParams {
   uint32_t A;   // audio outputs a[0..A) produced by this call
   int32_t e0;   // chunk index of the newest input of y[0]:  D-1-phase_x
   int32_t f0;   // call-relative index of the newest d of a[0]: Da-1-phase_d
-  uint32_t NA;  // audio outputs per tile
-  uint32_t tiles_per_stream;
+  uint32_t NA;  // audio outputs per tile (generic kernel) / per segment (fast kernel)
+  uint32_t tiles_per_stream;  // tiles (generic) / segments (fast) per stream
   uint32_t n_streams;
+  uint32_t phase_x;           // inputs already consumed towards y[0] (0..D-1)
 };
 
 // ---- virtual input: chunk index s in [-(T-1), N) ---------------------------------------------------------------
@@ -63,6 +70,63 @@ __device__ __forceinline__ float2 load_x(const CallParams& p, uint32_t stream, i
   const uint8_t* b = p.iq + (size_t)stream * p.iq_stride + 2 * (size_t)s;
   const uchar2 v = *reinterpret_cast<const uchar2*>(b);
   return make_float2((float)v.x - 127.5f, (float)v.y - 127.5f);
+}
+
+
+// ---- state hand-over of one stream: new FIR history, y[M-1], new discriminator history -------------------------
+// Runs in its own block(s) of the same launch as the audio tiles; reads only the call's inputs and the OLD state set,
+// writes only the NEW state set, so it is independent of every other block.
+// scratch: xs (capacity xs_cap samples) and ys (>= Ta+1 entries) in LDS; hs = FIR taps in LDS.
+__device__ __forceinline__ void state_handover(const CallParams& p, uint32_t stream, float2* xs, uint32_t xs_cap, float2* ys,
+                                               const float* hs) {
+  const uint32_t T = p.T, D = p.D, Ta = p.Ta;
+  const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+  const int N = (int)p.N, M = (int)p.M;
+  // new input history = last T-1 samples of [old history | chunk]
+  for (uint32_t k = tid; k + 1 < T; k += nthr)
+    p.hist_x_out[(size_t)stream * (T - 1) + k] = load_x(p, stream, N - (int)(T - 1) + (int)k);
+  // y[M-Ta .. M-1] (those that exist) -> ys[0..Ta)
+  const int ylo = M - (int)Ta;
+  const int yc0 = ylo > 0 ? ylo : 0;
+  const int xlo = p.e0 + yc0 * (int)D - (int)(T - 1);
+  const int xhi = p.e0 + (M - 1) * (int)D;
+  const bool staged = (M > 0) && ((uint32_t)(xhi - xlo + 1) <= xs_cap);
+  if (staged)
+    for (int s = xlo + (int)tid; s <= xhi; s += (int)nthr) xs[s - xlo] = load_x(p, stream, s);
+  __syncthreads();
+  for (int q = (int)tid; q < (int)Ta; q += (int)nthr) {
+    const int i = ylo + q;
+    float2 y = make_float2(0.f, 0.f);
+    if (i >= 0) {
+      const int s0 = p.e0 + i * (int)D - (int)(T - 1);
+      float ar = 0.0f, ai = 0.0f;
+      for (uint32_t j = 0; j < T; ++j) {
+        const float c = hs[T - 1 - j];
+        const float2 x = staged ? xs[s0 + (int)j - xlo] : load_x(p, stream, s0 + (int)j);
+        ar = __builtin_fmaf(c, x.x, ar);
+        ai = __builtin_fmaf(c, x.y, ai);
+      }
+      y = make_float2(ar, ai);
+    } else if (i == -1) {
+      y = p.yprev_in[stream];
+    }
+    ys[q] = y;
+  }
+  __syncthreads();
+  if (tid == 0) p.yprev_out[stream] = (M > 0) ? ys[Ta - 1] : p.yprev_in[stream];
+  // new d history = d[M-(Ta-1) .. M-1]
+  for (int q = (int)tid; q + 1 < (int)Ta; q += (int)nthr) {
+    const int i = M - (int)(Ta - 1) + q;
+    float d;
+    if (i < 0) {
+      d = p.hist_d_in[(size_t)stream * (Ta - 1) + (Ta - 1 + i)];
+    } else {
+      const float2 y = ys[i - ylo];
+      const float2 pr = ys[i - 1 - ylo];  // i-1-ylo >= 0 always; index -1 was filled from the old state above
+      d = sdrfm_discriminate(y.x, y.y, pr.x, pr.y);
+    }
+    p.hist_d_out[(size_t)stream * (Ta - 1) + q] = d;
+  }
 }
 
 // =================================================================================================================
@@ -139,50 +203,230 @@ __global__ void __launch_bounds__(256) k_generic(CallParams p) {
       p.audio[(size_t)stream * p.audio_stride + j] = acc;
     }
   } else {
-    // ------------------------------------------------------------------ state hand-over of one stream
-    const uint32_t stream = blockIdx.x - n_tile_blocks;
-    const int N = (int)p.N, M = (int)p.M;
-    // new input history = last T-1 samples of [old history | chunk]
-    for (uint32_t k = tid; k + 1 < T; k += nthr)
-      p.hist_x_out[(size_t)stream * (T - 1) + k] = load_x(p, stream, N - (int)(T - 1) + (int)k);
-    // y[M-Ta .. M-1] (those that exist) -> ys[0..Ta)
+    __syncthreads();  // taps are in LDS
+    state_handover(p, blockIdx.x - n_tile_blocks, xs, NX_MAX, ys, hs);
+  }
+}
+
+// =================================================================================================================
+//  Fast kernel: compile-time (T, D, R).  One WAVE per block, one contiguous segment of one stream per wave, processed
+//  as a sequence of sub-tiles of 64*R decimated outputs with everything carried in LDS/registers between sub-tiles:
+//
+//    HBM --typed buffer_load_format_xyzw (u8x4 -> 4 x f32 in the texture unit, 256 B per wave-instruction)--> VGPRs
+//        (prefetched one sub-tile ahead, in flight during the previous sub-tile's FIR)
+//    VGPR -0x1.fep+6 (= -127.5f)--> LDS x-tile, f32x2 per sample, rows of R*D samples (+16 B pad: conflict-free b128)
+//    LDS --ds_read_b128--> sliding window of lane t (its R consecutive outputs share (R-1)*D+T samples)
+//        v_pk_fma_f32 acc(I,Q) += tap * x(I,Q), tap broadcast from an SGPR pair: 64 taps live in 64 SGPRs
+//    y --DPP/bpermute neighbour--> conj product --> atan2 --> LDS d ring --> audio FIR --> HBM
+//
+//  Why this shape (measured on MI355X, tools/ubench): v_pk_fma_f32 with an SGPR tap runs at the full fp32 rate while
+//  a scalar v_fma_f32 with an SGPR operand runs at half rate; v_cvt_f32_ubyteN is a half-rate op but the typed buffer
+//  load converts for free at the full streaming rate (6.6 TB/s of u8 in); a single wave issues VALU at <= ~60 % of peak,
+//  so two resident waves per SIMD are needed, which bounds the LDS tile to ~23 KiB per wave.
+//
+//  Requirements (else the generic kernel runs): T even, T >= D, D even, Ta-1 <= 64*R, decimator phase even,
+//  iq 4-byte aligned with 4-byte-multiple stride.
+// =================================================================================================================
+// buffer resource word3: dst_sel = (R,G,B,A), num_format = USCALED (2), data_format = 8_8_8_8 (10)
+#define SDRFM_RSRC_U8X4_USCALED 0x52FAC
+
+// acc += tap * x, tap = low (HI=0) or high (HI=1) half of a wave-uniform SGPR pair, broadcast to both lanes of the pack
+template <int HI>
+__device__ __forceinline__ void pk_fma_bcast(f2_t& acc, f2_t tap_pair, f2_t x) {
+  if constexpr (HI == 0)
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(tap_pair), "v"(x));
+  else
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(tap_pair), "v"(x));
+}
+
+constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
+
+template <int T, int D, int R>
+__global__ void __launch_bounds__(64) k_fast(CallParams p) {
+  constexpr int RD = R * D, NYT = 64 * R, NST = 64 * RD, HP = T - D, NW = RD + HP;
+  constexpr int ROWPAD = ((RD / 2) % 2 == 0) ? 2 : 0, RS = (RD + ROWPAD) * 8;
+  constexpr int NROWS = (HP + NST + RD - 1) / RD, XBYTES = NROWS * RS;
+  constexpr int NLOAD = RD / 2;
+  constexpr int QSTEP = RD / cgcd(128, RD);          // loads q and q+QSTEP land a whole number of rows apart
+  constexpr int QROWS = 128 * QSTEP / RD;
+  static_assert(T % 2 == 0 && D % 2 == 0 && T >= D && NLOAD % QSTEP == 0 && NW % 2 == 0 && HP % 2 == 0, "geometry");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* xb = smem;                                   // x tile: position u <-> sub-tile sample s' = u - HP
+  const uint32_t Ta = p.Ta, Da = p.Da;
+  const uint32_t DOFF = (Ta - 1 + 3u) & ~3u;                  // d ring: [DOFF-(Ta-1), DOFF) history | [DOFF, DOFF+NYT) new
+  float* dbuf = reinterpret_cast<float*>(smem + XBYTES);
+  float* hs = dbuf + DOFF + NYT;                              // FIR taps (state blocks only)
+  const int lane = (int)threadIdx.x;
+
+  const uint32_t n_seg_blocks = p.n_streams * p.tiles_per_stream;
+  if (blockIdx.x >= n_seg_blocks) {
+    for (uint32_t k = lane; k < (uint32_t)T; k += 64) hs[k] = p.h[k];
     __syncthreads();
-    const int ylo = M - (int)Ta;
-    for (int q = (int)tid; q < (int)Ta; q += (int)nthr) {
-      const int i = ylo + q;
-      float2 y = make_float2(0.f, 0.f);
-      if (i >= 0) {
-        const int s0 = p.e0 + i * (int)D - (int)(T - 1);
-        float ar = 0.0f, ai = 0.0f;
-        for (uint32_t j = 0; j < T; ++j) {
-          const float c = hs[T - 1 - j];
-          const float2 x = load_x(p, stream, s0 + (int)j);
-          ar = __builtin_fmaf(c, x.x, ar);
-          ai = __builtin_fmaf(c, x.y, ai);
-        }
-        y = make_float2(ar, ai);
-      } else if (i == -1) {
-        y = p.yprev_in[stream];
-      }
-      ys[q] = y;
+    float2* ys = reinterpret_cast<float2*>(dbuf);             // Ta+1 float2 fit: DOFF+NYT >= 2*(Ta+1) checked on host
+    state_handover(p, blockIdx.x - n_seg_blocks, reinterpret_cast<float2*>(xb), XBYTES / 8, ys, hs);
+    return;
+  }
+  const uint32_t stream = blockIdx.x / p.tiles_per_stream;
+  const uint32_t seg = blockIdx.x % p.tiles_per_stream;
+  const int j0 = (int)(seg * p.NA);
+  int j1 = j0 + (int)p.NA;
+  if (j1 > (int)p.A) j1 = (int)p.A;
+  if (j0 >= j1) return;
+
+  // ---- segment geometry -------------------------------------------------------------------------------------
+  int ibase = p.f0 + j0 * (int)Da - (int)(Ta - 1) - 1;        // first output computed here (its d is not used)
+  const bool use_hist = ibase <= 0;                           // segment starts at the call start: take old state
+  if (use_hist) ibase = 0;
+  const int i_end = p.f0 + (j1 - 1) * (int)Da;                // newest d needed
+  const int nst = (i_end - ibase) / NYT + 1;                  // sub-tiles
+  int cs = (int)D * ibase - (int)p.phase_x;                   // chunk index of sub-tile sample s' = 0 (even)
+
+  // ---- taps: T/2 wave-uniform pairs -> SGPRs ------------------------------------------------------------------
+  f2_t hp[T / 2];
+#pragma unroll
+  for (int k = 0; k < T / 2; ++k) hp[k] = f2_t{p.h[2 * k], p.h[2 * k + 1]};
+
+  // ---- per-lane LDS addresses (computed once) -----------------------------------------------------------------
+  const unsigned char* win = xb + lane * RS;                  // lane window = positions [RD*lane, RD*lane + NW)
+  unsigned char* wr[QSTEP];                                   // staging destinations of loads q = 0..QSTEP-1
+#pragma unroll
+  for (int q = 0; q < QSTEP; ++q) {
+    const int u = HP + 128 * q + 2 * lane;
+    wr[q] = xb + (u / RD) * RS + (u % RD) * 8;
+  }
+  const int hu = NST + 2 * lane;                              // halo carry: lane < HP/2 copies positions hu,hu+1 -> 2*lane
+  const unsigned char* hsrc = xb + (hu / RD) * RS + (hu % RD) * 8;
+  unsigned char* hdst = xb + ((2 * lane) / RD) * RS + ((2 * lane) % RD) * 8;
+
+  // ---- typed-load descriptor of this stream's chunk -----------------------------------------------------------
+  const unsigned long long gaddr = (unsigned long long)(p.iq + (size_t)stream * p.iq_stride);
+  const i4_t rsrc = {(int)(unsigned)gaddr, (int)(unsigned)(gaddr >> 32), (int)(2u * p.N), SDRFM_RSRC_U8X4_USCALED};
+
+  f4_t pre[NLOAD];
+#pragma unroll
+  for (int q = 0; q < NLOAD; ++q) pre[q] = llvm_amdgcn_raw_buffer_load_format_v4f32(rsrc, 2 * cs + (64 * q + lane) * 4, 0, 0);
+
+  // ---- prologue: halo of the first sub-tile, d history ------------------------------------------------------
+  for (int u = lane; u < HP; u += 64) {
+    const int c = cs - HP + u;
+    const float2 x = (c >= -(int)(T - 1)) ? load_x(p, stream, c) : make_float2(0.f, 0.f);
+    *reinterpret_cast<float2*>(xb + (u / RD) * RS + (u % RD) * 8) = x;
+  }
+  for (uint32_t k = lane; k < Ta - 1; k += 64)
+    dbuf[DOFF - (Ta - 1) + k] = use_hist ? p.hist_d_in[(size_t)stream * (Ta - 1) + k] : 0.0f;
+  f2_t carry = {0.f, 0.f};                                    // y[ibase-1]
+  if (use_hist) { const float2 yp = p.yprev_in[stream]; carry = f2_t{yp.x, yp.y}; }
+
+  for (int st = 0; st < nst; ++st) {
+    const int ib = ibase + st * NYT;                          // first output of this sub-tile
+    // ---- stage: DC shift + write the prefetched sub-tile, then prefetch the next one -------------------------
+#pragma unroll
+    for (int q = 0; q < NLOAD; ++q) {
+      const f4_t v = pre[q] - 127.5f;
+      *reinterpret_cast<f4_t*>(wr[q % QSTEP] + (q / QSTEP) * QROWS * RS) = v;
+    }
+    cs += NST;
+    if (st + 1 < nst) {
+#pragma unroll
+      for (int q = 0; q < NLOAD; ++q) pre[q] = llvm_amdgcn_raw_buffer_load_format_v4f32(rsrc, 2 * cs + (64 * q + lane) * 4, 0, 0);
     }
     __syncthreads();
-    if (tid == 0) p.yprev_out[stream] = (M > 0) ? ys[Ta - 1] : p.yprev_in[stream];
-    // new d history = d[M-(Ta-1) .. M-1]
-    for (int q = (int)tid; q + 1 < (int)Ta; q += (int)nthr) {
-      const int i = M - (int)(Ta - 1) + q;
-      float d;
-      if (i < 0) {
-        d = p.hist_d_in[(size_t)stream * (Ta - 1) + (Ta - 1 + i)];
-      } else {
-        const float2 y = ys[i - ylo];
-        const float2 pr = ys[i - 1 - ylo];  // i-1 >= -1 == ylo + (Ta-1-M) ... always inside ys (i-1-ylo >= 0)
-        d = sdrfm_discriminate(y.x, y.y, pr.x, pr.y);
+    if (st == 0 && cs - NST < 0) {                            // samples before the chunk start come from the old history
+      const int nneg = -(cs - NST);
+      for (int s = lane; s < nneg; s += 64) {
+        const int u = HP + s;
+        *reinterpret_cast<float2*>(xb + (u / RD) * RS + (u % RD) * 8) = load_x(p, stream, cs - NST + s);
       }
-      p.hist_d_out[(size_t)stream * (Ta - 1) + q] = d;
+      __syncthreads();
+    }
+    // ---- K2: R outputs per lane, oldest sample first ---------------------------------------------------------
+    f2_t acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = f2_t{0.f, 0.f};
+#pragma unroll
+    for (int j2 = 0; j2 < NW / 2; ++j2) {
+      constexpr int dummy = 0; (void)dummy;
+      const int row = (2 * j2) / RD, col = (2 * j2) % RD;
+      const f4_t v = *reinterpret_cast<const f4_t*>(win + row * RS + col * 8);
+      const f2_t x0 = {v.x, v.y}, x1 = {v.z, v.w};
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int p0 = 2 * j2 - r * D;                        // position of x0 in output r's window (0 = oldest)
+        if (p0 >= 0 && p0 < T) {
+          const int k = T - 1 - p0;
+          if (k & 1) pk_fma_bcast<1>(acc[r], hp[k / 2], x0); else pk_fma_bcast<0>(acc[r], hp[k / 2], x0);
+        }
+        const int p1 = p0 + 1;
+        if (p1 >= 0 && p1 < T) {
+          const int k = T - 1 - p1;
+          if (k & 1) pk_fma_bcast<1>(acc[r], hp[k / 2], x1); else pk_fma_bcast<0>(acc[r], hp[k / 2], x1);
+        }
+      }
+    }
+    // ---- K3: discriminator; y[m-1] of the lane's first output comes from the neighbour lane -------------------
+    f2_t prev;
+    prev.x = __shfl_up(acc[R - 1].x, 1);
+    prev.y = __shfl_up(acc[R - 1].y, 1);
+    if (lane == 0) prev = carry;
+    carry.x = __shfl(acc[R - 1].x, 63);
+    carry.y = __shfl(acc[R - 1].y, 63);
+    float dv[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      dv[r] = sdrfm_discriminate(acc[r].x, acc[r].y, prev.x, prev.y);
+      prev = acc[r];
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) dbuf[DOFF + R * lane + r] = dv[r];
+    __syncthreads();
+    // ---- K4: audio outputs whose newest d lies in this sub-tile ------------------------------------------------
+    {
+      int jl = (ib - p.f0 + (int)Da - 1);
+      jl = jl > 0 ? jl / (int)Da : 0;                         // ceil((ib - f0)/Da), clamped at 0
+      if (jl < j0) jl = j0;
+      int jh = (ib + NYT - 1 - p.f0);
+      jh = jh >= 0 ? jh / (int)Da + 1 : 0;
+      if (jh > j1) jh = j1;
+      for (int j = jl + lane; j < jh; j += 64) {
+        const float* w = dbuf + DOFF + (p.f0 + j * (int)Da - ib) - (int)(Ta - 1);
+        float a = 0.0f;
+        for (uint32_t k = 0; k < Ta; ++k) a = __builtin_fmaf(p.g[Ta - 1 - k], w[k], a);
+        p.audio[(size_t)stream * p.audio_stride + j] = a;
+      }
+    }
+    // ---- carry: x halo and d history for the next sub-tile ------------------------------------------------------
+    if (st + 1 < nst) {
+      if (lane < HP / 2) *reinterpret_cast<f4_t*>(hdst) = *reinterpret_cast<const f4_t*>(hsrc);
+      float keep[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t k = lane + 64 * i;
+        keep[i] = (k < Ta - 1) ? dbuf[DOFF + NYT - (Ta - 1) + k] : 0.0f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t k = lane + 64 * i;
+        if (k < Ta - 1) dbuf[DOFF - (Ta - 1) + k] = keep[i];
+      }
+      __syncthreads();
     }
   }
 }
+
+struct FastVariant {
+  uint32_t T, D, R;
+  void (*kernel)(CallParams);
+  uint32_t xbytes;
+};
+#define SDRFM_FAST(T_, D_, R_)                                                                                       \
+  { T_, D_, R_, k_fast<T_, D_, R_>,                                                                                  \
+    (uint32_t)((((T_ - D_) + 64 * R_ * D_ + R_ * D_ - 1) / (R_ * D_)) * ((R_ * D_ + ((((R_ * D_) / 2) % 2 == 0) ? 2 : 0)) * 8)) }
+const FastVariant kFastVariants[] = {
+    SDRFM_FAST(64, 10, 4),
+    SDRFM_FAST(16, 10, 4),
+    SDRFM_FAST(32, 10, 4),
+};
 
 }  // namespace
 
@@ -210,7 +454,14 @@ struct sdrfm {
   // generic kernel geometry
   uint32_t NA;
   size_t lds_bytes;
+  // fast kernel (when one is instantiated for this T/D)
+  const FastVariant* fast;
+  size_t fast_lds;
+  uint32_t waves_target;   // resident waves the fast kernel aims for (CUs x waves that fit by LDS)
+  uint32_t min_subtiles;   // minimum sub-tiles per segment (bounds the per-segment halo recompute)
   char kernel_name[64];
+  char generic_name[64];
+  char fast_name[64];
 };
 
 #define HIP_TRY(expr, code)                                                                          \
@@ -280,7 +531,7 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
   if (!out) return SDRFM_EINVAL;
   *out = nullptr;
   if (!cfg || cfg->struct_size != sizeof(sdrfm_config)) return SDRFM_EINVAL;
-  if (!cfg->n_streams || !cfg->fir_coeffs || !cfg->audio_coeffs || cfg->flags) return SDRFM_EINVAL;
+  if (!cfg->n_streams || !cfg->fir_coeffs || !cfg->audio_coeffs || (cfg->flags & ~SDRFM_CFG_FORCE_GENERIC)) return SDRFM_EINVAL;
   if (!cfg->fir_taps || cfg->fir_taps > SDRFM_MAX_TAPS || !cfg->audio_taps || cfg->audio_taps > SDRFM_MAX_TAPS)
     return SDRFM_EINVAL;
   if (!cfg->fir_decim || cfg->fir_decim > SDRFM_MAX_DECIM || !cfg->audio_decim || cfg->audio_decim > SDRFM_MAX_DECIM)
@@ -346,8 +597,33 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_generic), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)h->lds_bytes) != hipSuccess) { free_handle(h); return SDRFM_NOT_SUPPORTED; }
   }
-  snprintf(h->kernel_name, sizeof(h->kernel_name), "generic T%u D%u Ta%u Da%u NA%u", cfg->fir_taps, cfg->fir_decim,
+  snprintf(h->generic_name, sizeof(h->generic_name), "generic T%u D%u Ta%u Da%u NA%u", cfg->fir_taps, cfg->fir_decim,
            cfg->audio_taps, cfg->audio_decim, NA);
+  snprintf(h->kernel_name, sizeof(h->kernel_name), "%s", h->generic_name);
+  if (!(cfg->flags & SDRFM_CFG_FORCE_GENERIC)) {
+    for (const FastVariant& v : kFastVariants) {
+      if (v.T != cfg->fir_taps || v.D != cfg->fir_decim) continue;
+      const uint32_t NYT = 64 * v.R, DOFF = (cfg->audio_taps - 1 + 3u) & ~3u;
+      if (cfg->audio_taps - 1 > NYT || DOFF + NYT < 2 * (cfg->audio_taps + 1)) continue;
+      const size_t lds = (size_t)v.xbytes + (size_t)(DOFF + NYT + v.T) * 4;
+      if (lds > 160 * 1024) continue;
+      if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(v.kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        continue;
+      h->fast = &v;
+      h->fast_lds = lds;
+      uint32_t per_cu = (uint32_t)((160 * 1024) / lds);
+      if (per_cu > 16) per_cu = 16;
+      if (const char* e = getenv("SDRFM_WAVES_PER_CU")) per_cu = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : per_cu;
+      h->waves_target = (uint32_t)prop.multiProcessorCount * per_cu;
+      h->min_subtiles = 4;
+      if (const char* e = getenv("SDRFM_MIN_SUBTILES")) h->min_subtiles = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : 4;
+      snprintf(h->fast_name, sizeof(h->fast_name), "fast T%u D%u R%u Ta%u Da%u", v.T, v.D, v.R, cfg->audio_taps,
+               cfg->audio_decim);
+      snprintf(h->kernel_name, sizeof(h->kernel_name), "%s", h->fast_name);
+      break;
+    }
+  }
   const int rc = sdrfm_reset(h);
   if (rc != SDRFM_OK) { free_handle(h); return rc; }
   *out = h;
@@ -424,11 +700,30 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
   p.N = N; p.M = M; p.A = A;
   p.e0 = (int32_t)(c.fir_decim - 1 - h->phase_x);
   p.f0 = (int32_t)(c.audio_decim - 1 - h->phase_d);
-  p.NA = h->NA;
-  p.tiles_per_stream = (A + h->NA - 1) / h->NA;
   p.n_streams = c.n_streams;
-  const uint32_t grid = c.n_streams * p.tiles_per_stream + c.n_streams;
-  hipLaunchKernelGGL(k_generic, dim3(grid), dim3(256), h->lds_bytes, h->stream, p);
+  p.phase_x = h->phase_x;
+  const bool fast_ok = h->fast && A > 0 && (h->phase_x % 2 == 0) && ((uintptr_t)d_iq % 4 == 0) && (iq_stride % 4 == 0) &&
+                       N < (1u << 30);
+  if (fast_ok) {
+    // split every stream into segments so that ~waves_target waves are resident; each segment >= min_subtiles sub-tiles
+    const uint32_t NYT = 64 * h->fast->R;
+    const uint32_t sub_total = (M + NYT - 1) / NYT;
+    uint32_t segs = h->waves_target / c.n_streams;
+    const uint32_t seg_cap = sub_total / h->min_subtiles;
+    if (segs > seg_cap) segs = seg_cap;
+    if (segs < 1) segs = 1;
+    p.NA = (A + segs - 1) / segs;
+    p.tiles_per_stream = (A + p.NA - 1) / p.NA;
+    const uint32_t grid = c.n_streams * p.tiles_per_stream + c.n_streams;
+    hipLaunchKernelGGL(h->fast->kernel, dim3(grid), dim3(64), h->fast_lds, h->stream, p);
+    snprintf(h->kernel_name, sizeof(h->kernel_name), "%s", h->fast_name);
+  } else {
+    p.NA = h->NA;
+    p.tiles_per_stream = (A + h->NA - 1) / h->NA;
+    const uint32_t grid = c.n_streams * p.tiles_per_stream + c.n_streams;
+    hipLaunchKernelGGL(k_generic, dim3(grid), dim3(256), h->lds_bytes, h->stream, p);
+    snprintf(h->kernel_name, sizeof(h->kernel_name), "%s", h->generic_name);
+  }
   HIP_TRY(hipGetLastError(), SDRFM_FAIL);
 
   h->cur ^= 1;

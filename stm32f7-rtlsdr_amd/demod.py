@@ -20,6 +20,7 @@ class FmConfig:
     n_streams: int = 1
     max_bytes_per_call: int = 1 << 20
     device: int = 0
+    force_generic: bool = False     # SDRFM_CFG_FORCE_GENERIC: never use a (T,D)-specialised kernel (tests)
 
 
 class FmDemod:
@@ -39,7 +40,7 @@ class FmDemod:
         c.audio_coeffs = g.ctypes.data_as(C.POINTER(C.c_float))
         c.max_bytes_per_call = cfg.max_bytes_per_call
         c.device = cfg.device
-        c.flags = 0
+        c.flags = 1 if cfg.force_generic else 0
         self._h = C.c_void_p()
         st = self._lib.sdrfm_create(C.byref(c), C.byref(self._h))
         if st != _l.OK:
