@@ -123,6 +123,11 @@ const char* sdrfm_strerror(int status);
 float sdrfm_host_atan2f(float y, float x);
 float sdrfm_host_discriminate(float yr, float yi, float pr, float pi);
 
+/* Profiling aid: with SDRFM_PHASE_PROFILE=1 in the environment at create time the (T,D)-specialised kernel runs an
+ * instrumented build; this returns cumulative shader cycles per phase summed over waves: out[0..4] = stage, FIR,
+ * discriminator, audio, carry; out[5] = sub-tiles; out[6] = waves; and resets them. SDRFM_NOT_SUPPORTED otherwise. */
+int sdrfm_debug_phase_cycles(sdrfm_t* h, unsigned long long* out8);
+
 #ifdef __cplusplus
 }
 #endif

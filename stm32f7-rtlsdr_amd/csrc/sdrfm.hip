@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <type_traits>
 
 #include "../../include/sdrfm.h"
 #include "sdrfm_math.h"
@@ -36,6 +37,10 @@ typedef float f4_t __attribute__((ext_vector_type(4)));
 typedef int i4_t __attribute__((ext_vector_type(4)));
 __device__ f4_t llvm_amdgcn_raw_buffer_load_format_v4f32(i4_t rsrc, int voffset, int soffset, int aux) __asm(
     "llvm.amdgcn.raw.buffer.load.format.v4f32");
+__device__ int llvm_amdgcn_raw_buffer_load_i32(i4_t rsrc, int voffset, int soffset, int aux) __asm(
+    "llvm.amdgcn.raw.buffer.load.i32");
+__device__ i4_t llvm_amdgcn_raw_buffer_load_v4i32(i4_t rsrc, int voffset, int soffset, int aux) __asm(
+    "llvm.amdgcn.raw.buffer.load.v4i32");
 
 namespace {
 
@@ -50,6 +55,8 @@ struct CallParams {
   float2* yprev_out;
   const float* hist_d_in;
   float* hist_d_out;
+  const uint8_t* hist_b_in;   // raw I/Q bytes of the last T-1 inputs (2*(T-1) per stream), same samples as hist_x
+  uint8_t* hist_b_out;
   const float* h;  // T taps
   const float* g;  // Ta taps
   uint32_t T, D, Ta, Da;
@@ -62,6 +69,9 @@ struct CallParams {
   uint32_t tiles_per_stream;  // tiles (generic) / segments (fast) per stream
   uint32_t n_streams;
   uint32_t phase_x;           // inputs already consumed towards y[0] (0..D-1)
+  uint32_t AB;                // fast kernel: sub-tiles of d buffered per audio flush
+  uint32_t warm_ahead;        // fast kernel: L2 warm-up distance in sub-tiles (0 = off)
+  unsigned long long* dbg;    // phase-cycle accumulators (profiling build of the fast kernel only), else nullptr
 };
 
 // ---- virtual input: chunk index s in [-(T-1), N) ---------------------------------------------------------------
@@ -73,6 +83,13 @@ __device__ __forceinline__ float2 load_x(const CallParams& p, uint32_t stream, i
 }
 
 
+// raw I/Q byte pair of chunk index s in [-(T-1), N) (low byte = I)
+__device__ __forceinline__ unsigned load_raw(const CallParams& p, uint32_t stream, int s) {
+  const uint8_t* b = (s < 0) ? p.hist_b_in + ((size_t)stream * (p.T - 1) + (p.T - 1 + s)) * 2
+                             : p.iq + (size_t)stream * p.iq_stride + 2 * (size_t)s;
+  return *reinterpret_cast<const unsigned short*>(b);
+}
+
 // ---- state hand-over of one stream: new FIR history, y[M-1], new discriminator history -------------------------
 // Runs in its own block(s) of the same launch as the audio tiles; reads only the call's inputs and the OLD state set,
 // writes only the NEW state set, so it is independent of every other block.
@@ -83,8 +100,11 @@ __device__ __forceinline__ void state_handover(const CallParams& p, uint32_t str
   const uint32_t tid = threadIdx.x, nthr = blockDim.x;
   const int N = (int)p.N, M = (int)p.M;
   // new input history = last T-1 samples of [old history | chunk]
-  for (uint32_t k = tid; k + 1 < T; k += nthr)
+  for (uint32_t k = tid; k + 1 < T; k += nthr) {
     p.hist_x_out[(size_t)stream * (T - 1) + k] = load_x(p, stream, N - (int)(T - 1) + (int)k);
+    reinterpret_cast<unsigned short*>(p.hist_b_out)[(size_t)stream * (T - 1) + k] =
+        (unsigned short)load_raw(p, stream, N - (int)(T - 1) + (int)k);
+  }
   // y[M-Ta .. M-1] (those that exist) -> ys[0..Ta)
   const int ylo = M - (int)Ta;
   const int yc0 = ylo > 0 ? ylo : 0;
@@ -240,12 +260,55 @@ __device__ __forceinline__ void pk_fma_bcast(f2_t& acc, f2_t tap_pair, f2_t x) {
 }
 
 constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
+// bytes of the x tile: positions [0, HP + NST) in rows of R*D samples, last row trimmed, rounded up to 16 B
+constexpr int fast_xbytes(int T, int D, int R) {
+  const int RD = R * D, HP = T - D, NST = 64 * RD, RS = (RD + (((RD / 2) % 2 == 0) ? 2 : 0)) * 8;
+  const int last = HP + NST - 1;
+  return (((last / RD) * RS + (last % RD + 1) * 8) + 15) & ~15;
+}
 
-template <int T, int D, int R>
-__global__ void __launch_bounds__(64) k_fast(CallParams p) {
+// ---- packed (2-wide) discriminator: two consecutive outputs per instruction stream --------------------------------
+__device__ __forceinline__ f2_t pk_splat(float c) { return f2_t{c, c}; }
+__device__ __forceinline__ f2_t atan2_pair(f2_t y, f2_t x) {
+  const f2_t ax = __builtin_elementwise_abs(x), ay = __builtin_elementwise_abs(y);
+  const f2_t mx = __builtin_elementwise_max(ax, ay), mn = __builtin_elementwise_min(ax, ay);
+  const f2_t t = mn * f2_t{__builtin_amdgcn_rcpf(mx.x), __builtin_amdgcn_rcpf(mx.y)};
+  const f2_t s = t * t;
+  f2_t q = pk_splat(0x1.57b128p-9f);
+  q = __builtin_elementwise_fma(q, s, pk_splat(-0x1.efda1p-7f));
+  q = __builtin_elementwise_fma(q, s, pk_splat(0x1.50dd96p-5f));
+  q = __builtin_elementwise_fma(q, s, pk_splat(-0x1.2dbcfap-4f));
+  q = __builtin_elementwise_fma(q, s, pk_splat(0x1.b11b74p-4f));
+  q = __builtin_elementwise_fma(q, s, pk_splat(-0x1.228754p-3f));
+  q = __builtin_elementwise_fma(q, s, pk_splat(0x1.99673ep-3f));
+  q = __builtin_elementwise_fma(q, s, pk_splat(-0x1.55546cp-2f));
+  f2_t a = __builtin_elementwise_fma(t, s * q, t);
+  float a0 = a.x, a1 = a.y;
+  if (ay.x > ax.x) a0 = 0x1.921fb6p+0f - a0;
+  if (ay.y > ax.y) a1 = 0x1.921fb6p+0f - a1;
+  if (x.x < 0.0f) a0 = 0x1.921fb6p+1f - a0;
+  if (x.y < 0.0f) a1 = 0x1.921fb6p+1f - a1;
+  return f2_t{__builtin_copysignf(a0, y.x), __builtin_copysignf(a1, y.y)};
+}
+// d for outputs (y0 | prev p0) and (y1 | prev y0): same roundings as sdrfm_discriminate, two at a time
+__device__ __forceinline__ f2_t discriminate_pair(f2_t y0, f2_t p0, f2_t y1) {
+  const f2_t yr = {y0.x, y1.x}, yi = {y0.y, y1.y}, pr = {p0.x, y0.x}, pi = {p0.y, y0.y};
+  const f2_t re = __builtin_elementwise_fma(yr, pr, yi * pi);
+  const f2_t im = yi * pr - yr * pi;
+  const f2_t a = atan2_pair(im, re);
+  return f2_t{(re.x == 0.0f && im.x == 0.0f) ? 0.0f : a.x, (re.y == 0.0f && im.y == 0.0f) ? 0.0f : a.y};
+}
+
+// MODE 0 = product kernel.  Other modes exist for timing experiments only and are reachable only through the
+// SDRFM_PHASE_PROFILE / SDRFM_ABLATE environment variables: 1 = per-phase cycle counters; 2 = no LDS staging writes;
+// 3 = no FIR arithmetic; 4 = no discriminator/audio; 5 = no LDS staging writes and no FIR LDS reads; 6 = staging only;
+// 7 = staging only and without the typed loads.
+template <int T, int D, int R, int MODE>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_fast(CallParams p) {
+  constexpr bool PROF = (MODE == 1);
   constexpr int RD = R * D, NYT = 64 * R, NST = 64 * RD, HP = T - D, NW = RD + HP;
   constexpr int ROWPAD = ((RD / 2) % 2 == 0) ? 2 : 0, RS = (RD + ROWPAD) * 8;
-  constexpr int NROWS = (HP + NST + RD - 1) / RD, XBYTES = NROWS * RS;
+  constexpr int XBYTES = fast_xbytes(T, D, R);
   constexpr int NLOAD = RD / 2;
   constexpr int QSTEP = RD / cgcd(128, RD);          // loads q and q+QSTEP land a whole number of rows apart
   constexpr int QROWS = 128 * QSTEP / RD;
@@ -253,25 +316,29 @@ __global__ void __launch_bounds__(64) k_fast(CallParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* xb = smem;                                   // x tile: position u <-> sub-tile sample s' = u - HP
   const uint32_t Ta = p.Ta, Da = p.Da;
-  const uint32_t DOFF = (Ta - 1 + 3u) & ~3u;                  // d ring: [DOFF-(Ta-1), DOFF) history | [DOFF, DOFF+NYT) new
+  const uint32_t DOFF = (Ta - 1 + 3u) & ~3u;                  // d ring: [DOFF-(Ta-1), DOFF) history | [DOFF, DOFF+AB*NYT) new
+  const int DCAP = (int)p.AB * NYT;                           // new d's buffered before the audio stage runs
   float* dbuf = reinterpret_cast<float*>(smem + XBYTES);
-  float* hs = dbuf + DOFF + NYT;                              // FIR taps (state blocks only)
+  float* gs = dbuf + DOFF + DCAP;                             // audio taps, reversed
+  float* hs = gs + Ta;                                        // FIR taps (state blocks only)
   const int lane = (int)threadIdx.x;
 
   const uint32_t n_seg_blocks = p.n_streams * p.tiles_per_stream;
   if (blockIdx.x >= n_seg_blocks) {
     for (uint32_t k = lane; k < (uint32_t)T; k += 64) hs[k] = p.h[k];
     __syncthreads();
-    float2* ys = reinterpret_cast<float2*>(dbuf);             // Ta+1 float2 fit: DOFF+NYT >= 2*(Ta+1) checked on host
+    float2* ys = reinterpret_cast<float2*>(dbuf);             // Ta+1 float2 fit: checked on the host
     state_handover(p, blockIdx.x - n_seg_blocks, reinterpret_cast<float2*>(xb), XBYTES / 8, ys, hs);
     return;
   }
-  const uint32_t stream = blockIdx.x / p.tiles_per_stream;
-  const uint32_t seg = blockIdx.x % p.tiles_per_stream;
+  const uint32_t sblk = blockIdx.x;
+  const uint32_t stream = sblk / p.tiles_per_stream;
+  const uint32_t seg = sblk % p.tiles_per_stream;
   const int j0 = (int)(seg * p.NA);
   int j1 = j0 + (int)p.NA;
   if (j1 > (int)p.A) j1 = (int)p.A;
   if (j0 >= j1) return;
+  for (uint32_t k = lane; k < Ta; k += 64) gs[k] = p.g[Ta - 1 - k];   // gs[k] multiplies the k-th oldest d
 
   // ---- segment geometry -------------------------------------------------------------------------------------
   int ibase = p.f0 + j0 * (int)Da - (int)(Ta - 1) - 1;        // first output computed here (its d is not used)
@@ -316,19 +383,41 @@ __global__ void __launch_bounds__(64) k_fast(CallParams p) {
     dbuf[DOFF - (Ta - 1) + k] = use_hist ? p.hist_d_in[(size_t)stream * (Ta - 1) + k] : 0.0f;
   f2_t carry = {0.f, 0.f};                                    // y[ibase-1]
   if (use_hist) { const float2 yp = p.yprev_in[stream]; carry = f2_t{yp.x, yp.y}; }
+  int warm = 0, warm_sink = 0;
+  int dpos = 0;                                               // new d's in the ring since the last audio flush
+  int ibA = ibase;                                            // output index of ring position DOFF
+  // PROF build only: shader cycles per phase (stage, fir, disc, audio, carry) accumulated in LDS (keeps SGPRs for the taps)
+  unsigned* tph = reinterpret_cast<unsigned*>(hs);            // hs is unused by segment blocks
+  unsigned tlast = 0;
+  if constexpr (PROF) {
+    if (lane < 8) tph[lane] = 0;
+    tlast = (unsigned)__builtin_readcyclecounter();
+  }
+#define SDRFM_TICK(i)                                                         \
+  if constexpr (PROF) {                                                       \
+    const unsigned tn = (unsigned)__builtin_readcyclecounter();               \
+    if (lane == 0) tph[i] += tn - tlast;                                      \
+    tlast = tn;                                                               \
+  }
 
   for (int st = 0; st < nst; ++st) {
-    const int ib = ibase + st * NYT;                          // first output of this sub-tile
     // ---- stage: DC shift + write the prefetched sub-tile, then prefetch the next one -------------------------
 #pragma unroll
     for (int q = 0; q < NLOAD; ++q) {
       const f4_t v = pre[q] - 127.5f;
-      *reinterpret_cast<f4_t*>(wr[q % QSTEP] + (q / QSTEP) * QROWS * RS) = v;
+      if constexpr (MODE == 2 || MODE == 5) asm volatile("" ::"v"(v));
+      else *reinterpret_cast<f4_t*>(wr[q % QSTEP] + (q / QSTEP) * QROWS * RS) = v;
     }
     cs += NST;
-    if (st + 1 < nst) {
+    if (st + 1 < nst && MODE != 7) {
 #pragma unroll
       for (int q = 0; q < NLOAD; ++q) pre[q] = llvm_amdgcn_raw_buffer_load_format_v4f32(rsrc, 2 * cs + (64 * q + lane) * 4, 0, 0);
+    }
+    if (p.warm_ahead) {
+      // L2 warm-up: one dword from each 128-B line of the sub-tile(s) after next (8 KiB per instruction, 1 VGPR).
+      // The typed loads above then hit L2 instead of paying the full HBM round trip with only NLOAD KiB in flight.
+      warm_sink ^= warm;
+      warm = llvm_amdgcn_raw_buffer_load_i32(rsrc, 2 * (cs + (int)p.warm_ahead * NST) + lane * 128, 0, 0);
     }
     __syncthreads();
     if (st == 0 && cs - NST < 0) {                            // samples before the chunk start come from the old history
@@ -339,30 +428,57 @@ __global__ void __launch_bounds__(64) k_fast(CallParams p) {
       }
       __syncthreads();
     }
+    SDRFM_TICK(0)
     // ---- K2: R outputs per lane, oldest sample first ---------------------------------------------------------
+    // Software-pipelined by hand: the window is read in batches of NB ds_read_b128, batch b+1 is issued before the
+    // FMAs of batch b (the compiler on its own keeps only ~2 reads in flight, which exposes the LDS latency).
     f2_t acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = f2_t{0.f, 0.f};
+    constexpr int NRD = (MODE == 6 || MODE == 7) ? 0 : NW / 2;  // ds_read_b128 per lane (2 samples each)
+    constexpr int NB = (NRD % 7 == 0) ? 7 : ((NRD % 6 == 0) ? 6 : ((NRD % 8 == 0) ? 8 : ((NRD % 5 == 0) ? 5 : 1)));
+    constexpr int NBATCH = NRD / NB;
+    f4_t wb[2][NB];
 #pragma unroll
-    for (int j2 = 0; j2 < NW / 2; ++j2) {
-      constexpr int dummy = 0; (void)dummy;
-      const int row = (2 * j2) / RD, col = (2 * j2) % RD;
-      const f4_t v = *reinterpret_cast<const f4_t*>(win + row * RS + col * 8);
-      const f2_t x0 = {v.x, v.y}, x1 = {v.z, v.w};
+    for (int i = 0; i < (NRD ? NB : 0); ++i) {
+      const int row = (2 * i) / RD, col = (2 * i) % RD;
+      wb[0][i] = *reinterpret_cast<const f4_t*>(win + row * RS + col * 8);
+    }
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int p0 = 2 * j2 - r * D;                        // position of x0 in output r's window (0 = oldest)
-        if (p0 >= 0 && p0 < T) {
-          const int k = T - 1 - p0;
-          if (k & 1) pk_fma_bcast<1>(acc[r], hp[k / 2], x0); else pk_fma_bcast<0>(acc[r], hp[k / 2], x0);
-        }
-        const int p1 = p0 + 1;
-        if (p1 >= 0 && p1 < T) {
-          const int k = T - 1 - p1;
-          if (k & 1) pk_fma_bcast<1>(acc[r], hp[k / 2], x1); else pk_fma_bcast<0>(acc[r], hp[k / 2], x1);
+    for (int b = 0; b < NBATCH; ++b) {
+      if (b + 1 < NBATCH) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          const int j2 = (b + 1) * NB + i;
+          const int row = (2 * j2) / RD, col = (2 * j2) % RD;
+          wb[(b + 1) & 1][i] = *reinterpret_cast<const f4_t*>(win + row * RS + col * 8);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int j2 = b * NB + i;
+        const f4_t v = wb[b & 1][i];
+        const f2_t x0 = {v.x, v.y}, x1 = {v.z, v.w};
+        if constexpr (MODE == 3) { acc[j2 % R] += x0 + x1; continue; }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int p0 = 2 * j2 - r * D;                      // position of x0 in output r's window (0 = oldest)
+          if (p0 >= 0 && p0 < T) {
+            const int k = T - 1 - p0;
+            if (k & 1) pk_fma_bcast<1>(acc[r], hp[k / 2], x0); else pk_fma_bcast<0>(acc[r], hp[k / 2], x0);
+          }
+          const int p1 = p0 + 1;
+          if (p1 >= 0 && p1 < T) {
+            const int k = T - 1 - p1;
+            if (k & 1) pk_fma_bcast<1>(acc[r], hp[k / 2], x1); else pk_fma_bcast<0>(acc[r], hp[k / 2], x1);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (PROF) asm volatile("" :: "v"(acc[0]), "v"(acc[R - 1]));
+    SDRFM_TICK(1)
     // ---- K3: discriminator; y[m-1] of the lane's first output comes from the neighbour lane -------------------
     f2_t prev;
     prev.x = __shfl_up(acc[R - 1].x, 1);
@@ -371,61 +487,367 @@ __global__ void __launch_bounds__(64) k_fast(CallParams p) {
     carry.x = __shfl(acc[R - 1].x, 63);
     carry.y = __shfl(acc[R - 1].y, 63);
     float dv[R];
+    if constexpr (MODE == 4 || MODE == 6 || MODE == 7) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      dv[r] = sdrfm_discriminate(acc[r].x, acc[r].y, prev.x, prev.y);
-      prev = acc[r];
+      for (int r = 0; r < R; ++r) dv[r] = acc[r].x + acc[r].y + prev.x;
+    } else {
+#pragma unroll
+    for (int r = 0; r + 1 < R; r += 2) {
+      const f2_t d2 = discriminate_pair(acc[r], r == 0 ? prev : acc[r - 1], acc[r + 1]);
+      dv[r] = d2.x;
+      dv[r + 1] = d2.y;
+    }
+    if constexpr (R % 2 == 1) {
+      const f2_t pv = (R == 1) ? prev : acc[R - 2];
+      dv[R - 1] = sdrfm_discriminate(acc[R - 1].x, acc[R - 1].y, pv.x, pv.y);
+    }
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) dbuf[DOFF + R * lane + r] = dv[r];
-    __syncthreads();
-    // ---- K4: audio outputs whose newest d lies in this sub-tile ------------------------------------------------
-    {
-      int jl = (ib - p.f0 + (int)Da - 1);
-      jl = jl > 0 ? jl / (int)Da : 0;                         // ceil((ib - f0)/Da), clamped at 0
+    for (int r = 0; r < R; ++r) dbuf[DOFF + dpos + R * lane + r] = dv[r];
+    dpos += NYT;
+    const bool last = (st + 1 == nst);
+    SDRFM_TICK(2)
+    if ((dpos == DCAP || last) && ((MODE != 4 && MODE != 6 && MODE != 7) || last)) {
+      __syncthreads();
+      // ---- K4: audio outputs whose newest d lies in ring positions [DOFF, DOFF + dpos) -------------------------
+      int jl = (ibA - p.f0 + (int)Da - 1);
+      jl = jl > 0 ? jl / (int)Da : 0;                         // ceil((ibA - f0)/Da), clamped at 0
       if (jl < j0) jl = j0;
-      int jh = (ib + NYT - 1 - p.f0);
+      int jh = (ibA + dpos - 1 - p.f0);
       jh = jh >= 0 ? jh / (int)Da + 1 : 0;
       if (jh > j1) jh = j1;
-      for (int j = jl + lane; j < jh; j += 64) {
-        const float* w = dbuf + DOFF + (p.f0 + j * (int)Da - ib) - (int)(Ta - 1);
-        float a = 0.0f;
-        for (uint32_t k = 0; k < Ta; ++k) a = __builtin_fmaf(p.g[Ta - 1 - k], w[k], a);
-        p.audio[(size_t)stream * p.audio_stride + j] = a;
+      // three outputs per lane at a time (independent chains share the tap reads; a single chain is LDS-latency bound)
+      for (int j = jl + lane; j < jh; j += 192) {
+        const int jb = j + 64, jc = j + 128;
+        const float* w0 = dbuf + DOFF + (p.f0 + j * (int)Da - ibA) - (int)(Ta - 1);
+        const float* w1 = (jb < jh) ? w0 + 64 * (int)Da : w0;
+        const float* w2 = (jc < jh) ? w0 + 128 * (int)Da : w0;
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+#pragma unroll 4
+        for (uint32_t k = 0; k < Ta; ++k) {
+          const float gk = gs[k];
+          a0 = __builtin_fmaf(gk, w0[k], a0);
+          a1 = __builtin_fmaf(gk, w1[k], a1);
+          a2 = __builtin_fmaf(gk, w2[k], a2);
+        }
+        float* o = p.audio + (size_t)stream * p.audio_stride;
+        o[j] = a0;
+        if (jb < jh) o[jb] = a1;
+        if (jc < jh) o[jc] = a2;
       }
+      if (!last) {                                            // d history for the next batch
+        float keep[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t k = lane + 64 * i;
+          keep[i] = (k < Ta - 1) ? dbuf[DOFF + dpos - (Ta - 1) + k] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t k = lane + 64 * i;
+          if (k < Ta - 1) dbuf[DOFF - (Ta - 1) + k] = keep[i];
+        }
+      }
+      ibA += dpos;
+      dpos = 0;
     }
-    // ---- carry: x halo and d history for the next sub-tile ------------------------------------------------------
-    if (st + 1 < nst) {
+    SDRFM_TICK(3)
+    // ---- carry the x halo for the next sub-tile -----------------------------------------------------------------
+    if (!last) {
       if (lane < HP / 2) *reinterpret_cast<f4_t*>(hdst) = *reinterpret_cast<const f4_t*>(hsrc);
-      float keep[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const uint32_t k = lane + 64 * i;
-        keep[i] = (k < Ta - 1) ? dbuf[DOFF + NYT - (Ta - 1) + k] : 0.0f;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const uint32_t k = lane + 64 * i;
-        if (k < Ta - 1) dbuf[DOFF - (Ta - 1) + k] = keep[i];
-      }
       __syncthreads();
     }
+    SDRFM_TICK(4)
+  }
+  if (warm_sink == 0x7fffffff && p.dbg) p.dbg[7] = (unsigned long long)warm;   // keeps the warm-up loads alive
+  if constexpr (PROF) {
+    if (lane == 0 && p.dbg) {
+      for (int i = 0; i < 5; ++i) atomicAdd(p.dbg + 8 * (blockIdx.x & 63) + i, (unsigned long long)tph[i]);
+      atomicAdd(p.dbg + 8 * (blockIdx.x & 63) + 5, (unsigned long long)nst);
+      atomicAdd(p.dbg + 8 * (blockIdx.x & 63) + 6, 1ull);
+    }
+  }
+#undef SDRFM_TICK
+}
+
+typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+// =================================================================================================================
+//  Fast kernel, design B ("bytes in LDS"): the wave's tile holds the RAW u8 I/Q bytes (2 B per sample instead of 8),
+//  every lane converts its own window on the fly and computes R = 8..12 consecutive outputs from it.
+//
+//    HBM --buffer_load_dwordx4 (16 B/lane, prefetched one sub-tile ahead in VGPRs)--> ds_write_b128 --> LDS raw tile
+//    LDS --ds_read_b128 (8 samples)--> v_cvt_f32_ubyte0..3 + v_pk_add_f32(-127.5) --> (I,Q) f32 pairs
+//        --> v_pk_fma_f32 with SGPR taps, up to T/D outputs per sample --> y --> discriminator --> d ring --> audio
+//
+//  Why (measured, tools/ubench): design A moves 8 B per sample through ds_write_b128, whose VGPR->LDS path costs ~13
+//  cycles per wave-instruction per CU; at two waves per SIMD that path, the LDS reads and the VALU work do not overlap
+//  and the kernel runs at ~3x the time of any one of them.  Here the store path carries 4x fewer bytes, LDS reads are
+//  ~8x fewer, and the only saturated resource is the VALU: conversion is repeated for the (T-D)-sample overlap between
+//  neighbouring lanes, (R*D+T-D)/(R*D) = 1.45x at R = 12, which costs less than the LDS round trip of the floats.
+//
+//  Requirements (else design A or the generic kernel): as design A, plus R*D % 8 == 0 and all T-1 history samples real
+//  (the zero-history start of a stream cannot be expressed in bytes: the first call after a reset runs elsewhere).
+// =================================================================================================================
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
   }
 }
 
+constexpr int fastb_hp(int T, int D) { return ((T - D) + 7) & ~7; }                      // halo samples (16-B granular)
+constexpr int fastb_rs(int D, int R) { return R * D * 2 + ((((R * D * 2) / 16) % 2 == 0) ? 16 : 0); }  // row stride, B
+constexpr int fastb_xbytes(int T, int D, int R) {
+  const int RD = R * D, last = fastb_hp(T, D) + 64 * RD - 1;
+  return (((last / RD) * fastb_rs(D, R) + (last % RD + 1) * 2) + 15) & ~15;
+}
+
+// (I - 127.5, Q - 127.5) of the low / high half of a dword holding two I/Q byte pairs
+template <int HIHALF>
+__device__ __forceinline__ f2_t cvt_iq(unsigned w) {
+  f2_t c;
+  if constexpr (HIHALF) { c.x = (float)((w >> 16) & 0xffu); c.y = (float)(w >> 24); }   // v_cvt_f32_ubyte2 / 3
+  else { c.x = (float)(w & 0xffu); c.y = (float)((w >> 8) & 0xffu); }                  // v_cvt_f32_ubyte0 / 1
+  return c - f2_t{127.5f, 127.5f};
+}
+
+template <int T, int D, int R, int MODE>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 3))) k_fastb(CallParams p) {
+  constexpr int RD = R * D, NYT = 64 * R, NST = 64 * RD, HALO = T - D, HP = fastb_hp(T, D), OFF = HP - HALO;
+  constexpr int NW = RD + HALO;                      // samples one lane needs
+  constexpr int NRD = (OFF + NW + 7) / 8;            // ds_read_b128 (8 samples) per lane
+  constexpr int RS = fastb_rs(D, R);                 // lane row stride in bytes (odd number of 16-B slots)
+  constexpr bool LINEAR = (RS == RD * 2);
+  constexpr int XBYTES = fastb_xbytes(T, D, R);
+  constexpr int NLOAD = RD / 8;                      // 16-B loads per lane per sub-tile
+  static_assert(T % 2 == 0 && D % 2 == 0 && T >= D && RD % 8 == 0 && R % 2 == 0, "design B geometry");
+  constexpr bool PROF = (MODE == 1);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* xb = smem;                                   // raw tile: position u <-> sub-tile sample s' = u - HP
+  const uint32_t Ta = p.Ta, Da = p.Da;
+  const uint32_t DOFF = (Ta - 1 + 3u) & ~3u;
+  const int DCAP = (int)p.AB * NYT;
+  float* dbuf = reinterpret_cast<float*>(smem + XBYTES);
+  float* gs = dbuf + DOFF + DCAP;
+  float* hs = gs + Ta;
+  const int lane = (int)threadIdx.x;
+
+  const uint32_t n_seg_blocks = p.n_streams * p.tiles_per_stream;
+  if (blockIdx.x >= n_seg_blocks) {
+    for (uint32_t k = lane; k < (uint32_t)T; k += 64) hs[k] = p.h[k];
+    __syncthreads();
+    state_handover(p, blockIdx.x - n_seg_blocks, reinterpret_cast<float2*>(xb), XBYTES / 8, reinterpret_cast<float2*>(dbuf), hs);
+    return;
+  }
+  const uint32_t stream = blockIdx.x / p.tiles_per_stream;
+  const uint32_t seg = blockIdx.x % p.tiles_per_stream;
+  const int j0 = (int)(seg * p.NA);
+  int j1 = j0 + (int)p.NA;
+  if (j1 > (int)p.A) j1 = (int)p.A;
+  if (j0 >= j1) return;
+  for (uint32_t k = lane; k < Ta; k += 64) gs[k] = p.g[Ta - 1 - k];
+
+  int ibase = p.f0 + j0 * (int)Da - (int)(Ta - 1) - 1;
+  const bool use_hist = ibase <= 0;
+  if (use_hist) ibase = 0;
+  const int i_end = p.f0 + (j1 - 1) * (int)Da;
+  const int nst = (i_end - ibase) / NYT + 1;
+  int cs = (int)D * ibase - (int)p.phase_x;                   // chunk index of sub-tile sample s' = 0 (even)
+
+  f2_t hp[T / 2];
+#pragma unroll
+  for (int k = 0; k < T / 2; ++k) hp[k] = f2_t{p.h[2 * k], p.h[2 * k + 1]};
+
+  auto pos_addr = [&](int u) -> unsigned char* {              // LDS address of tile position u
+    if constexpr (LINEAR) return xb + 2 * u;
+    else return xb + (u / RD) * RS + (u % RD) * 2;
+  };
+  const unsigned char* win = xb + lane * RS;                  // window of this lane: positions [RD*lane, RD*lane + 8*NRD)
+
+  const unsigned long long gaddr = (unsigned long long)(p.iq + (size_t)stream * p.iq_stride);
+  const i4_t rsrc = {(int)(unsigned)gaddr, (int)(unsigned)(gaddr >> 32), (int)(2u * p.N), 0x00020000};
+
+  i4_t pre[NLOAD];
+#pragma unroll
+  for (int q = 0; q < NLOAD; ++q) pre[q] = llvm_amdgcn_raw_buffer_load_v4i32(rsrc, 2 * cs + (64 * q + lane) * 16, 0, 0);
+
+  // prologue: halo of the first sub-tile (raw bytes, from the old raw history where the chunk has not started), d history
+  for (int u = lane; u < HP; u += 64) {
+    const int c = cs - HP + u;
+    *reinterpret_cast<unsigned short*>(pos_addr(u)) = (c >= -(int)(T - 1)) ? (unsigned short)load_raw(p, stream, c) : (unsigned short)0;
+  }
+  for (uint32_t k = lane; k < Ta - 1; k += 64)
+    dbuf[DOFF - (Ta - 1) + k] = use_hist ? p.hist_d_in[(size_t)stream * (Ta - 1) + k] : 0.0f;
+  f2_t carry = {0.f, 0.f};
+  if (use_hist) { const float2 yp = p.yprev_in[stream]; carry = f2_t{yp.x, yp.y}; }
+  int dpos = 0, ibA = ibase;
+  unsigned* tph = reinterpret_cast<unsigned*>(hs);
+  unsigned tlast = 0;
+  if constexpr (PROF) {
+    if (lane < 8) tph[lane] = 0;
+    tlast = (unsigned)__builtin_readcyclecounter();
+  }
+#define SDRFM_TICK(i)                                                         \
+  if constexpr (PROF) {                                                       \
+    const unsigned tn = (unsigned)__builtin_readcyclecounter();               \
+    if (lane == 0) tph[i] += tn - tlast;                                      \
+    tlast = tn;                                                               \
+  }
+
+  for (int st = 0; st < nst; ++st) {
+    // ---- stage the prefetched raw bytes, then prefetch the next sub-tile --------------------------------------
+#pragma unroll
+    for (int q = 0; q < NLOAD; ++q) {
+      const int u = HP + 8 * (64 * q + lane);
+      *reinterpret_cast<i4_t*>(pos_addr(u)) = pre[q];
+    }
+    cs += NST;
+    if (st + 1 < nst) {
+#pragma unroll
+      for (int q = 0; q < NLOAD; ++q) pre[q] = llvm_amdgcn_raw_buffer_load_v4i32(rsrc, 2 * cs + (64 * q + lane) * 16, 0, 0);
+    }
+    __syncthreads();
+    if (st == 0 && cs - NST < 0) {
+      // The chunk starts inside this sub-tile: 16-B loads that begin before byte 0 come back as zeros in full, so every
+      // sample of those loads is rewritten: from the old raw history (index < 0) or from the chunk itself.
+      const int nfix = (-(cs - NST) + 7) & ~7;
+      for (int s = lane; s < nfix; s += 64) {
+        const int c = cs - NST + s;
+        *reinterpret_cast<unsigned short*>(pos_addr(HP + s)) = (c < (int)p.N) ? (unsigned short)load_raw(p, stream, c) : (unsigned short)0;
+      }
+      __syncthreads();
+    }
+    SDRFM_TICK(0)
+    // ---- K1 + K2: convert the lane's window 8 samples at a time, feed every output the sample belongs to -----
+    f2_t acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = f2_t{0.f, 0.f};
+    u4_t cur = *reinterpret_cast<const u4_t*>(win), nxt = cur;
+    static_for<0, NRD>([&](auto J8) {
+      constexpr int j8 = decltype(J8)::value;
+      constexpr int jn = 8 * (j8 + 1);                       // first window position of the next 8-sample chunk
+      if constexpr (j8 + 1 < NRD) nxt = *reinterpret_cast<const u4_t*>(win + (jn / RD) * RS + (jn % RD) * 2);
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, 8>([&](auto S) {
+        constexpr int s = decltype(S)::value;
+        constexpr int j = j8 * 8 + s;                         // window position; output r uses positions OFF+r*D .. +T-1
+        if constexpr (j >= OFF && j < OFF + NW) {
+          const unsigned w = (s / 2 == 0) ? cur.x : (s / 2 == 1) ? cur.y : (s / 2 == 2) ? cur.z : cur.w;
+          const f2_t x = cvt_iq<(s & 1)>(w);
+          static_for<0, R>([&](auto RR) {
+            constexpr int r = decltype(RR)::value;
+            constexpr int p0 = j - OFF - r * D;               // 0 = oldest sample of output r
+            if constexpr (p0 >= 0 && p0 < T) {
+              constexpr int k = T - 1 - p0;
+              if constexpr (k & 1) pk_fma_bcast<1>(acc[r], hp[k / 2], x); else pk_fma_bcast<0>(acc[r], hp[k / 2], x);
+            }
+          });
+        }
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      cur = nxt;
+    });
+    if constexpr (PROF) asm volatile("" :: "v"(acc[0]), "v"(acc[R - 1]));
+    SDRFM_TICK(1)
+    // ---- K3 -------------------------------------------------------------------------------------------------------
+    f2_t prev;
+    prev.x = __shfl_up(acc[R - 1].x, 1);
+    prev.y = __shfl_up(acc[R - 1].y, 1);
+    if (lane == 0) prev = carry;
+    carry.x = __shfl(acc[R - 1].x, 63);
+    carry.y = __shfl(acc[R - 1].y, 63);
+    float dv[R];
+#pragma unroll
+    for (int r = 0; r + 1 < R; r += 2) {
+      const f2_t d2 = discriminate_pair(acc[r], r == 0 ? prev : acc[r - 1], acc[r + 1]);
+      dv[r] = d2.x;
+      dv[r + 1] = d2.y;
+    }
+#pragma unroll
+    for (int r = 0; r < R; r += 4) {
+      if (r + 4 <= R) *reinterpret_cast<f4_t*>(dbuf + DOFF + dpos + R * lane + r) = f4_t{dv[r], dv[r + 1], dv[r + 2], dv[r + 3]};
+      else { dbuf[DOFF + dpos + R * lane + r] = dv[r]; dbuf[DOFF + dpos + R * lane + r + 1] = dv[r + 1]; }
+    }
+    dpos += NYT;
+    const bool last = (st + 1 == nst);
+    SDRFM_TICK(2)
+    if (dpos == DCAP || last) {
+      __syncthreads();
+      int jl = (ibA - p.f0 + (int)Da - 1);
+      jl = jl > 0 ? jl / (int)Da : 0;
+      if (jl < j0) jl = j0;
+      int jh = (ibA + dpos - 1 - p.f0);
+      jh = jh >= 0 ? jh / (int)Da + 1 : 0;
+      if (jh > j1) jh = j1;
+      // three outputs per lane at a time (independent chains share the tap reads; a single chain is LDS-latency bound)
+      for (int j = jl + lane; j < jh; j += 192) {
+        const int jb = j + 64, jc = j + 128;
+        const float* w0 = dbuf + DOFF + (p.f0 + j * (int)Da - ibA) - (int)(Ta - 1);
+        const float* w1 = (jb < jh) ? w0 + 64 * (int)Da : w0;
+        const float* w2 = (jc < jh) ? w0 + 128 * (int)Da : w0;
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+#pragma unroll 4
+        for (uint32_t k = 0; k < Ta; ++k) {
+          const float gk = gs[k];
+          a0 = __builtin_fmaf(gk, w0[k], a0);
+          a1 = __builtin_fmaf(gk, w1[k], a1);
+          a2 = __builtin_fmaf(gk, w2[k], a2);
+        }
+        float* o = p.audio + (size_t)stream * p.audio_stride;
+        o[j] = a0;
+        if (jb < jh) o[jb] = a1;
+        if (jc < jh) o[jc] = a2;
+      }
+      if (!last) {
+        float keep[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t k = lane + 64 * i;
+          keep[i] = (k < Ta - 1) ? dbuf[DOFF + dpos - (Ta - 1) + k] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t k = lane + 64 * i;
+          if (k < Ta - 1) dbuf[DOFF - (Ta - 1) + k] = keep[i];
+        }
+      }
+      ibA += dpos;
+      dpos = 0;
+    }
+    SDRFM_TICK(3)
+    // ---- carry the raw halo: positions [NST, NST+HP) -> [0, HP) ---------------------------------------------------
+    if (!last) {
+      if (lane < HP / 8) *reinterpret_cast<i4_t*>(pos_addr(8 * lane)) = *reinterpret_cast<const i4_t*>(pos_addr(NST + 8 * lane));
+      __syncthreads();
+    }
+    SDRFM_TICK(4)
+  }
+  if constexpr (PROF) {
+    if (lane == 0 && p.dbg) {
+      for (int i = 0; i < 5; ++i) atomicAdd(p.dbg + 8 * (blockIdx.x & 63) + i, (unsigned long long)tph[i]);
+      atomicAdd(p.dbg + 8 * (blockIdx.x & 63) + 5, (unsigned long long)nst);
+      atomicAdd(p.dbg + 8 * (blockIdx.x & 63) + 6, 1ull);
+    }
+  }
+#undef SDRFM_TICK
+}
+
 struct FastVariant {
+  char kind;                         // 'a' = float tile (design A), 'b' = raw-byte tile (design B)
   uint32_t T, D, R;
-  void (*kernel)(CallParams);
+  void (*kernel[8])(CallParams);   // [0] product; [1..7] timing experiments (profile / ablations)
   uint32_t xbytes;
 };
-#define SDRFM_FAST(T_, D_, R_)                                                                                       \
-  { T_, D_, R_, k_fast<T_, D_, R_>,                                                                                  \
-    (uint32_t)((((T_ - D_) + 64 * R_ * D_ + R_ * D_ - 1) / (R_ * D_)) * ((R_ * D_ + ((((R_ * D_) / 2) % 2 == 0) ? 2 : 0)) * 8)) }
+#define SDRFM_FAST(T_, D_, R_) { 'a', T_, D_, R_, {k_fast<T_, D_, R_, 0>, k_fast<T_, D_, R_, 1>, k_fast<T_, D_, R_, 2>, k_fast<T_, D_, R_, 3>, k_fast<T_, D_, R_, 4>, k_fast<T_, D_, R_, 5>, k_fast<T_, D_, R_, 6>, k_fast<T_, D_, R_, 7>}, (uint32_t)fast_xbytes(T_, D_, R_) }
+#define SDRFM_FASTB(T_, D_, R_) { 'b', T_, D_, R_, {k_fastb<T_, D_, R_, 0>, k_fastb<T_, D_, R_, 1>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, (uint32_t)fastb_xbytes(T_, D_, R_) }
 const FastVariant kFastVariants[] = {
-    SDRFM_FAST(64, 10, 4),
-    SDRFM_FAST(16, 10, 4),
-    SDRFM_FAST(32, 10, 4),
+    SDRFM_FASTB(64, 10, 12), SDRFM_FASTB(64, 10, 8), SDRFM_FASTB(16, 10, 12), SDRFM_FASTB(16, 10, 8), SDRFM_FASTB(32, 10, 12), SDRFM_FASTB(32, 10, 8),
+    SDRFM_FAST(64, 10, 2), SDRFM_FAST(64, 10, 3), SDRFM_FAST(64, 10, 4),
+    SDRFM_FAST(16, 10, 2), SDRFM_FAST(16, 10, 4),
+    SDRFM_FAST(32, 10, 2), SDRFM_FAST(32, 10, 4),
 };
 
 }  // namespace
@@ -443,6 +865,8 @@ struct sdrfm {
   float2* d_hist_x[2];
   float2* d_yprev[2];
   float* d_hist_d[2];
+  uint8_t* d_hist_b[2];   // raw-byte twin of hist_x (design B reads its halo from it)
+  uint64_t n_seen;        // IQ samples consumed since reset (history is all-real once >= T-1)
   int cur;  // index of the state set holding the current state
   uint32_t phase_x, phase_d;
   // staging for host-pointer calls
@@ -459,6 +883,10 @@ struct sdrfm {
   size_t fast_lds;
   uint32_t waves_target;   // resident waves the fast kernel aims for (CUs x waves that fit by LDS)
   uint32_t min_subtiles;   // minimum sub-tiles per segment (bounds the per-segment halo recompute)
+  uint32_t AB;             // sub-tiles of d buffered per audio flush
+  unsigned long long* d_dbg;  // phase profile accumulators (only with SDRFM_PHASE_PROFILE=1)
+  uint32_t warm_ahead;        // L2 warm-up distance (sub-tiles)
+  int fast_mode;              // 0 product; 1..5 timing experiments selected by environment variables
   char kernel_name[64];
   char generic_name[64];
   char fast_name[64];
@@ -488,9 +916,11 @@ static void free_handle(sdrfm* h) {
     if (h->d_hist_x[i]) (void)hipFree(h->d_hist_x[i]);
     if (h->d_yprev[i]) (void)hipFree(h->d_yprev[i]);
     if (h->d_hist_d[i]) (void)hipFree(h->d_hist_d[i]);
+    if (h->d_hist_b[i]) (void)hipFree(h->d_hist_b[i]);
   }
   if (h->d_iq) (void)hipFree(h->d_iq);
   if (h->d_audio) (void)hipFree(h->d_audio);
+  if (h->d_dbg) (void)hipFree(h->d_dbg);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   free(const_cast<float*>(h->cfg.fir_coeffs));
   free(const_cast<float*>(h->cfg.audio_coeffs));
@@ -578,6 +1008,7 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
     CR(hipMalloc(&h->d_hist_x[i], sizeof(float2) * ns * hx));
     CR(hipMalloc(&h->d_yprev[i], sizeof(float2) * ns));
     CR(hipMalloc(&h->d_hist_d[i], sizeof(float) * ns * hd));
+    CR(hipMalloc(&h->d_hist_b[i], 2 * ns * hx));
   }
   CR(hipMemcpy(h->d_h, hc, sizeof(float) * T, hipMemcpyHostToDevice));
   CR(hipMemcpy(h->d_g, gc, sizeof(float) * Ta, hipMemcpyHostToDevice));
@@ -601,15 +1032,36 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
            cfg->audio_taps, cfg->audio_decim, NA);
   snprintf(h->kernel_name, sizeof(h->kernel_name), "%s", h->generic_name);
   if (!(cfg->flags & SDRFM_CFG_FORCE_GENERIC)) {
+    char want_kind = 'b';
+    if (const char* e = getenv("SDRFM_FAST_KIND")) want_kind = e[0];
+    uint32_t want_r = (want_kind == 'b') ? 12 : 3;
+    if (const char* e = getenv("SDRFM_FAST_R")) want_r = (uint32_t)atoi(e);
+    uint32_t ab_env = 0;
+    if (const char* e = getenv("SDRFM_AUDIO_BATCH")) ab_env = (uint32_t)atoi(e);
+    for (int pass = 0; pass < 3 && !h->fast; ++pass)
     for (const FastVariant& v : kFastVariants) {
       if (v.T != cfg->fir_taps || v.D != cfg->fir_decim) continue;
+      if (pass == 0 && (v.R != want_r || v.kind != want_kind)) continue;
+      if (pass == 1 && v.kind != want_kind) continue;
       const uint32_t NYT = 64 * v.R, DOFF = (cfg->audio_taps - 1 + 3u) & ~3u;
-      if (cfg->audio_taps - 1 > NYT || DOFF + NYT < 2 * (cfg->audio_taps + 1)) continue;
-      const size_t lds = (size_t)v.xbytes + (size_t)(DOFF + NYT + v.T) * 4;
+      // audio flush every AB sub-tiles: AB = Da makes every flush exactly 64*R outputs (all lanes busy)
+      uint32_t AB = ab_env ? ab_env : (v.kind == 'b' ? 1u : cfg->audio_decim);
+      if (AB > 8) AB = 8;
+      while (AB > 1 && (size_t)v.xbytes + (size_t)(DOFF + AB * NYT + v.T + cfg->audio_taps) * 4 > 40 * 1024) --AB;
+      if (cfg->audio_taps - 1 > AB * NYT || DOFF + AB * NYT < 2 * (cfg->audio_taps + 1)) continue;
+      const size_t lds = (size_t)v.xbytes + (size_t)(DOFF + AB * NYT + v.T + cfg->audio_taps) * 4;
       if (lds > 160 * 1024) continue;
-      if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(v.kernel),
+      if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(v.kernel[0]),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         continue;
+      h->AB = AB;
+      h->warm_ahead = 0;
+      if (const char* e = getenv("SDRFM_WARM_AHEAD")) h->warm_ahead = (uint32_t)atoi(e);
+      if (const char* e = getenv("SDRFM_ABLATE")) { const int m = atoi(e); if (m >= 2 && m <= 7 && v.kernel[m]) h->fast_mode = m; }
+      if (getenv("SDRFM_PHASE_PROFILE") && !h->d_dbg) {
+        if (hipMalloc(&h->d_dbg, 512 * sizeof(unsigned long long)) != hipSuccess) h->d_dbg = nullptr;
+        else { (void)hipMemset(h->d_dbg, 0, 512 * sizeof(unsigned long long)); h->fast_mode = 1; }
+      }
       h->fast = &v;
       h->fast_lds = lds;
       uint32_t per_cu = (uint32_t)((160 * 1024) / lds);
@@ -618,8 +1070,8 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
       h->waves_target = (uint32_t)prop.multiProcessorCount * per_cu;
       h->min_subtiles = 4;
       if (const char* e = getenv("SDRFM_MIN_SUBTILES")) h->min_subtiles = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : 4;
-      snprintf(h->fast_name, sizeof(h->fast_name), "fast T%u D%u R%u Ta%u Da%u", v.T, v.D, v.R, cfg->audio_taps,
-               cfg->audio_decim);
+      snprintf(h->fast_name, sizeof(h->fast_name), "fast-%c T%u D%u R%u Ta%u Da%u AB%u", v.kind, v.T, v.D, v.R,
+               cfg->audio_taps, cfg->audio_decim, AB);
       snprintf(h->kernel_name, sizeof(h->kernel_name), "%s", h->fast_name);
       break;
     }
@@ -646,10 +1098,12 @@ int sdrfm_reset(sdrfm_t* h) {
     HIP_TRY(hipMemsetAsync(h->d_hist_x[i], 0, sizeof(float2) * ns * hx, h->stream), SDRFM_FAIL);
     HIP_TRY(hipMemsetAsync(h->d_yprev[i], 0, sizeof(float2) * ns, h->stream), SDRFM_FAIL);
     HIP_TRY(hipMemsetAsync(h->d_hist_d[i], 0, sizeof(float) * ns * hd, h->stream), SDRFM_FAIL);
+    HIP_TRY(hipMemsetAsync(h->d_hist_b[i], 0, 2 * ns * hx, h->stream), SDRFM_FAIL);
   }
   HIP_TRY(hipStreamSynchronize(h->stream), SDRFM_FAIL);
   h->cur = 0;
   h->phase_x = h->phase_d = 0;
+  h->n_seen = 0;
   return SDRFM_OK;
 }
 
@@ -695,6 +1149,7 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
   p.hist_x_in = h->d_hist_x[h->cur]; p.hist_x_out = h->d_hist_x[h->cur ^ 1];
   p.yprev_in = h->d_yprev[h->cur]; p.yprev_out = h->d_yprev[h->cur ^ 1];
   p.hist_d_in = h->d_hist_d[h->cur]; p.hist_d_out = h->d_hist_d[h->cur ^ 1];
+  p.hist_b_in = h->d_hist_b[h->cur]; p.hist_b_out = h->d_hist_b[h->cur ^ 1];
   p.h = h->d_h; p.g = h->d_g;
   p.T = c.fir_taps; p.D = c.fir_decim; p.Ta = c.audio_taps; p.Da = c.audio_decim;
   p.N = N; p.M = M; p.A = A;
@@ -702,6 +1157,9 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
   p.f0 = (int32_t)(c.audio_decim - 1 - h->phase_d);
   p.n_streams = c.n_streams;
   p.phase_x = h->phase_x;
+  p.AB = h->AB;
+  p.dbg = h->d_dbg;
+  p.warm_ahead = h->warm_ahead;
   const bool fast_ok = h->fast && A > 0 && (h->phase_x % 2 == 0) && ((uintptr_t)d_iq % 4 == 0) && (iq_stride % 4 == 0) &&
                        N < (1u << 30);
   if (fast_ok) {
@@ -715,8 +1173,20 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
     p.NA = (A + segs - 1) / segs;
     p.tiles_per_stream = (A + p.NA - 1) / p.NA;
     const uint32_t grid = c.n_streams * p.tiles_per_stream + c.n_streams;
-    hipLaunchKernelGGL(h->fast->kernel, dim3(grid), dim3(64), h->fast_lds, h->stream, p);
+    hipLaunchKernelGGL(h->fast->kernel[h->fast_mode], dim3(grid), dim3(64), h->fast_lds, h->stream, p);
     snprintf(h->kernel_name, sizeof(h->kernel_name), "%s", h->fast_name);
+    if (h->fast->kind == 'b' && h->n_seen + 1 < c.fir_taps) {
+      // Design B reads its halo as bytes, which cannot express the zero history at the start of a stream: the few audio
+      // outputs that depend on inputs before the first real sample are recomputed by the generic kernel (tile 0..k only).
+      const uint32_t y_aff = (c.fir_taps + c.fir_decim - 1) / c.fir_decim + 1;            // outputs touching n < 0
+      const uint32_t a_aff = (y_aff + c.audio_taps + c.audio_decim - 1) / c.audio_decim;  // audio outputs touching them
+      CallParams q = p;
+      q.NA = h->NA;
+      q.tiles_per_stream = (a_aff + h->NA - 1) / h->NA;
+      const uint32_t full = (A + h->NA - 1) / h->NA;
+      if (q.tiles_per_stream > full) q.tiles_per_stream = full;
+      hipLaunchKernelGGL(k_generic, dim3(c.n_streams * q.tiles_per_stream), dim3(256), h->lds_bytes, h->stream, q);
+    }
   } else {
     p.NA = h->NA;
     p.tiles_per_stream = (A + h->NA - 1) / h->NA;
@@ -727,6 +1197,7 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
   HIP_TRY(hipGetLastError(), SDRFM_FAIL);
 
   h->cur ^= 1;
+  h->n_seen += N;
   h->phase_x = (uint32_t)(((uint64_t)h->phase_x + N) % c.fir_decim);
   h->phase_d = (uint32_t)(((uint64_t)h->phase_d + M) % c.audio_decim);
   return SDRFM_OK;
@@ -774,6 +1245,22 @@ int sdrfm_process(sdrfm_t* h, const uint8_t* iq, uint32_t nbytes, float* audio, 
   (void)sdrfm_audio_count(h, nbytes, &A);
   if (A > audio_cap) return SDRFM_ECAPACITY;
   return sdrfm_process_batch(h, iq, nbytes, nbytes, audio, audio_cap, n_audio, 0);
+}
+
+/* Profiling aid (SDRFM_PHASE_PROFILE=1 at create): cumulative shader cycles per phase of the fast kernel, summed over
+ * waves: out[0..4] = stage, FIR, discriminator, audio, carry; out[5] = sub-tiles; out[6] = waves. Resets the counters. */
+int sdrfm_debug_phase_cycles(sdrfm_t* h, unsigned long long* out8) {
+  if (!h || !out8) return SDRFM_EINVAL;
+  if (!h->d_dbg) return SDRFM_NOT_SUPPORTED;
+  HIP_TRY(hipSetDevice(h->device), SDRFM_FAIL);
+  HIP_TRY(hipStreamSynchronize(h->stream), SDRFM_FAIL);
+  unsigned long long tmp[512];
+  HIP_TRY(hipMemcpy(tmp, h->d_dbg, sizeof(tmp), hipMemcpyDeviceToHost), SDRFM_FAIL);
+  HIP_TRY(hipMemset(h->d_dbg, 0, sizeof(tmp)), SDRFM_FAIL);
+  for (int i = 0; i < 8; ++i) out8[i] = 0;
+  for (int g = 0; g < 64; ++g)
+    for (int i = 0; i < 8; ++i) out8[i] += tmp[8 * g + i];
+  return SDRFM_OK;
 }
 
 /* Host evaluation of the device's atan2 / discriminator arithmetic (same header, same rounding) so that its accuracy

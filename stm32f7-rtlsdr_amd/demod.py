@@ -88,6 +88,13 @@ class FmDemod:
     def synchronize(self):
         self._ck(self._lib.sdrfm_synchronize(self._h), "sdrfm_synchronize")
 
+    def phase_cycles(self):
+        """sdrfm_debug_phase_cycles: dict of cumulative shader cycles per kernel phase (profiling builds only)."""
+        out = (C.c_uint64 * 8)()
+        self._ck(self._lib.sdrfm_debug_phase_cycles(self._h, out), "sdrfm_debug_phase_cycles")
+        names = ["stage", "fir", "disc", "audio", "carry", "subtiles", "waves"]
+        return {n: int(out[i]) for i, n in enumerate(names)}
+
     # -- host buffers -----------------------------------------------------------------------------------------
     def process(self, iq: np.ndarray) -> np.ndarray:
         """sdrfm_process: single stream, uint8 interleaved I/Q in, float32 audio out."""

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Per-phase shader-cycle breakdown of the fast kernel on the bench workload (needs SDRFM_PHASE_PROFILE=1)."""
+import importlib, os, sys
+os.environ["SDRFM_PHASE_PROFILE"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+pkg = importlib.import_module("stm32f7-rtlsdr_amd")
+ns, nsamp = 256, 240000
+h, g = pkg.default_config(int(os.environ.get("TAPS", "64")))
+dm = pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=ns))
+iq = torch.from_numpy(np.tile(pkg.make_iq(16, nsamp), (16, 1))).cuda()
+audio = torch.zeros((ns, 4801), dtype=torch.float32, device="cuda")
+for _ in range(3):
+    dm.process_batch_device(iq, audio)
+dm.synchronize(); dm.phase_cycles()
+reps = 20
+t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+torch.cuda.synchronize(); t0.record()
+for _ in range(reps):
+    dm.process_batch_device(iq, audio)
+dm.synchronize(); t1.record(); torch.cuda.synchronize()
+pc = dm.phase_cycles()
+st = pc["subtiles"]
+tot = sum(pc[k] for k in ("stage", "fir", "disc", "audio", "carry"))
+print(dm.kernel_name, "| us/launch (instrumented, stream-sync'd): %.1f" % (t0.elapsed_time(t1) * 1e3 / reps))
+print("waves/launch %d  subtiles/wave %.1f  cycles/subtile %.0f" % (pc["waves"] / reps, st / pc["waves"], tot / st))
+for k in ("stage", "fir", "disc", "audio", "carry"):
+    print("  %-6s %8.0f cycles/subtile  %5.1f%%" % (k, pc[k] / st, 100.0 * pc[k] / tot))

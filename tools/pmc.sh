@@ -1,0 +1,22 @@
+#!/bin/bash
+# tools/pmc.sh <tag> — PMC passes only (fast), summary printed as one line per counter for the dominant kernel
+TAG=${1:-x}; shift || true
+OUT=$PWD/gpurun_out/pmc_$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
+ARGS="--steps 20 --warmup 3 --no-cpu-baseline $*"
+for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY" \
+           "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU" \
+           "SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_INST_LEVEL_LDS" \
+           "GRBM_GUI_ACTIVE"; do
+  name=$(echo $grp | tr ' ' '_' | cut -c1-30)
+  rocprofv3 --output-format csv --pmc $grp -d "$OUT/$name" -o pmc -- python3 bench.py $ARGS > "$OUT/$name.log" 2>&1
+done
+python3 - "$OUT" <<'PY'
+import csv, glob, sys, os
+from collections import defaultdict
+acc = defaultdict(float); cnt = defaultdict(int)
+for fn in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
+    for row in csv.DictReader(open(fn)):
+        if "k_fast" in row["Kernel_Name"] or "k_generic" in row["Kernel_Name"]:
+            acc[row["Counter_Name"]] += float(row["Counter_Value"]); cnt[row["Counter_Name"]] += 1
+print(" ".join("%s=%.3g" % (k, acc[k] / cnt[k]) for k in sorted(acc)))
+PY
