@@ -71,6 +71,7 @@ struct CallParams {
   uint32_t phase_x;           // inputs already consumed towards y[0] (0..D-1)
   uint32_t AB;                // fast kernel: sub-tiles of d buffered per audio flush
   uint32_t warm_ahead;        // fast kernel: L2 warm-up distance in sub-tiles (0 = off)
+  uint32_t fold_state;        // design B: the last segment's wave hands the state over (no state blocks in the grid)
   unsigned long long* dbg;    // phase-cycle accumulators (profiling build of the fast kernel only), else nullptr
 };
 
@@ -613,7 +614,16 @@ __device__ __forceinline__ f2_t cvt_iq(unsigned w) {
   return c - f2_t{127.5f, 127.5f};
 }
 
-template <int T, int D, int R, int MODE>
+// same with the tap pair held in a (wave-uniform) VGPR pair: frees SGPRs when the kernel is SGPR-bound
+template <int HI>
+__device__ __forceinline__ void pk_fma_bcast_v(f2_t& acc, f2_t tap_pair, f2_t x) {
+  if constexpr (HI == 0)
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(tap_pair), "v"(x));
+  else
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(tap_pair), "v"(x));
+}
+
+template <int T, int D, int R, int TA, int DA, int MODE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 3))) k_fastb(CallParams p) {
   constexpr int RD = R * D, NYT = 64 * R, NST = 64 * RD, HALO = T - D, HP = fastb_hp(T, D), OFF = HP - HALO;
   constexpr int NW = RD + HALO;                      // samples one lane needs
@@ -626,16 +636,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 3)))
   constexpr bool PROF = (MODE == 1);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* xb = smem;                                   // raw tile: position u <-> sub-tile sample s' = u - HP
-  const uint32_t Ta = p.Ta, Da = p.Da;
-  const uint32_t DOFF = (Ta - 1 + 3u) & ~3u;
-  const int DCAP = (int)p.AB * NYT;
+  constexpr uint32_t Ta = TA, Da = DA;                         // audio stage geometry is compile-time in design B
+  constexpr uint32_t DOFF = (Ta - 1 + 3u) & ~3u;
+  constexpr int DCAP = NYT;                                   // one audio flush per sub-tile (AB = 1)
   float* dbuf = reinterpret_cast<float*>(smem + XBYTES);
   float* gs = dbuf + DOFF + DCAP;
   float* hs = gs + Ta;
   const int lane = (int)threadIdx.x;
+  unsigned t_entry = 0;
+  unsigned long long rt_entry = 0;
+  if constexpr (PROF) { t_entry = (unsigned)__builtin_readcyclecounter(); rt_entry = __builtin_amdgcn_s_memrealtime(); }
 
   const uint32_t n_seg_blocks = p.n_streams * p.tiles_per_stream;
-  if (blockIdx.x >= n_seg_blocks) {
+  if (blockIdx.x >= n_seg_blocks) {   // only launched when the state is not folded into the last segment (see below)
     for (uint32_t k = lane; k < (uint32_t)T; k += 64) hs[k] = p.h[k];
     __syncthreads();
     state_handover(p, blockIdx.x - n_seg_blocks, reinterpret_cast<float2*>(xb), XBYTES / 8, reinterpret_cast<float2*>(dbuf), hs);
@@ -652,13 +665,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 3)))
   int ibase = p.f0 + j0 * (int)Da - (int)(Ta - 1) - 1;
   const bool use_hist = ibase <= 0;
   if (use_hist) ibase = 0;
-  const int i_end = p.f0 + (j1 - 1) * (int)Da;
+  int i_end = p.f0 + (j1 - 1) * (int)Da;                      // newest d needed by this segment's audio
+  // The wave of the LAST segment also hands the streaming state over (y[M-1], the last Ta-1 d's, the last T-1 inputs):
+  // it already holds all of it at the end of its last sub-tile, so no separate state blocks (and no tail) are needed.
+  const bool hand_over = p.fold_state && (j1 == (int)p.A);
+  if (hand_over && (int)p.M - 1 > i_end) i_end = (int)p.M - 1;
   const int nst = (i_end - ibase) / NYT + 1;
   int cs = (int)D * ibase - (int)p.phase_x;                   // chunk index of sub-tile sample s' = 0 (even)
 
+  // taps: wave-uniform pairs; the first NVT pairs live in VGPRs, the rest in SGPRs (64 taps alone would take 64 of the
+  // ~100 usable SGPRs and push kernel arguments into spills)
+  constexpr int NVT = (T >= 64) ? 12 : 0;
   f2_t hp[T / 2];
 #pragma unroll
-  for (int k = 0; k < T / 2; ++k) hp[k] = f2_t{p.h[2 * k], p.h[2 * k + 1]};
+  for (int k = 0; k < T / 2; ++k) {
+    hp[k] = f2_t{p.h[2 * k], p.h[2 * k + 1]};
+    if (k < NVT) asm volatile("" : "+v"(hp[k]));
+  }
 
   auto pos_addr = [&](int u) -> unsigned char* {              // LDS address of tile position u
     if constexpr (LINEAR) return xb + 2 * u;
@@ -682,7 +705,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 3)))
     dbuf[DOFF - (Ta - 1) + k] = use_hist ? p.hist_d_in[(size_t)stream * (Ta - 1) + k] : 0.0f;
   f2_t carry = {0.f, 0.f};
   if (use_hist) { const float2 yp = p.yprev_in[stream]; carry = f2_t{yp.x, yp.y}; }
-  int dpos = 0, ibA = ibase;
+  int dpos = 0, ibA = ibase, ibA_last = ibase;
   unsigned* tph = reinterpret_cast<unsigned*>(hs);
   unsigned tlast = 0;
   if constexpr (PROF) {
@@ -696,6 +719,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 3)))
     tlast = tn;                                                               \
   }
 
+  if constexpr (PROF) {
+    __syncthreads();
+    const unsigned tn = (unsigned)__builtin_readcyclecounter();
+    if (lane == 0) tph[7] = tn - t_entry;                     // prologue cycles of this segment (kernel entry -> loop)
+    tlast = tn;
+  }
   for (int st = 0; st < nst; ++st) {
     // ---- stage the prefetched raw bytes, then prefetch the next sub-tile --------------------------------------
 #pragma unroll
@@ -741,7 +770,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 3)))
             constexpr int p0 = j - OFF - r * D;               // 0 = oldest sample of output r
             if constexpr (p0 >= 0 && p0 < T) {
               constexpr int k = T - 1 - p0;
-              if constexpr (k & 1) pk_fma_bcast<1>(acc[r], hp[k / 2], x); else pk_fma_bcast<0>(acc[r], hp[k / 2], x);
+              if constexpr (k / 2 < NVT) {
+                if constexpr (k & 1) pk_fma_bcast_v<1>(acc[r], hp[k / 2], x); else pk_fma_bcast_v<0>(acc[r], hp[k / 2], x);
+              } else {
+                if constexpr (k & 1) pk_fma_bcast<1>(acc[r], hp[k / 2], x); else pk_fma_bcast<0>(acc[r], hp[k / 2], x);
+              }
             }
           });
         }
@@ -773,6 +806,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 3)))
     dpos += NYT;
     const bool last = (st + 1 == nst);
     SDRFM_TICK(2)
+    if (last && hand_over) {                                  // park y[M-1] in LDS; the hand-over itself runs after the loop
+      const int o = (int)p.M - 1 - (ibase + st * NYT);        // y[M-1] is output o of this sub-tile (0 <= o < NYT)
+      if (lane == o / R) {
+        f2_t y = acc[0];
+#pragma unroll
+        for (int r = 1; r < R; ++r) if (o % R == r) y = acc[r];
+        *reinterpret_cast<f2_t*>(hs + 16) = y;
+      }
+      ibA_last = ibA;
+    }
     if (dpos == DCAP || last) {
       __syncthreads();
       int jl = (ibA - p.f0 + (int)Da - 1);
@@ -825,11 +868,28 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 3)))
     }
     SDRFM_TICK(4)
   }
+  if (hand_over) {
+    // state hand-over by the wave that computed the end of the stream's chunk (outside the loop: the taps are dead here).
+    // Ring position of d[i] is DOFF + (i - ibA_last); d[M-(Ta-1) .. M-1] all lie inside the ring because M >= Ta.
+    __syncthreads();
+    if (lane == 0) { const f2_t y = *reinterpret_cast<const f2_t*>(hs + 16); p.yprev_out[stream] = make_float2(y.x, y.y); }
+    for (uint32_t k = lane; k + 1 < Ta; k += 64)
+      p.hist_d_out[(size_t)stream * (Ta - 1) + k] = dbuf[(int)DOFF + ((int)p.M - (int)(Ta - 1) + (int)k - ibA_last)];
+    for (uint32_t k = lane; k + 1 < (uint32_t)T; k += 64) {
+      const int c = (int)p.N - (int)(T - 1) + (int)k;
+      p.hist_x_out[(size_t)stream * (T - 1) + k] = load_x(p, stream, c);
+      reinterpret_cast<unsigned short*>(p.hist_b_out)[(size_t)stream * (T - 1) + k] = (unsigned short)load_raw(p, stream, c);
+    }
+  }
   if constexpr (PROF) {
     if (lane == 0 && p.dbg) {
       for (int i = 0; i < 5; ++i) atomicAdd(p.dbg + 8 * (blockIdx.x & 63) + i, (unsigned long long)tph[i]);
       atomicAdd(p.dbg + 8 * (blockIdx.x & 63) + 5, (unsigned long long)nst);
       atomicAdd(p.dbg + 8 * (blockIdx.x & 63) + 6, 1ull);
+      atomicAdd(p.dbg + 8 * (blockIdx.x & 63) + 7, (unsigned long long)tph[7]);
+      // whole-wave duration in 100 MHz real-time ticks and in shader cycles -> effective shader clock
+      atomicAdd(p.dbg + 8 * (blockIdx.x & 63) + 4, ((__builtin_amdgcn_s_memrealtime() - rt_entry) << 32));
+      atomicAdd(p.dbg + 8 * (blockIdx.x & 63) + 6, ((unsigned long long)((unsigned)__builtin_readcyclecounter() - t_entry)) << 20);
     }
   }
 #undef SDRFM_TICK
@@ -838,11 +898,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 3)))
 struct FastVariant {
   char kind;                         // 'a' = float tile (design A), 'b' = raw-byte tile (design B)
   uint32_t T, D, R;
+  uint32_t Ta, Da;                   // design B only: compile-time audio geometry (0 = any)
   void (*kernel[8])(CallParams);   // [0] product; [1..7] timing experiments (profile / ablations)
   uint32_t xbytes;
 };
-#define SDRFM_FAST(T_, D_, R_) { 'a', T_, D_, R_, {k_fast<T_, D_, R_, 0>, k_fast<T_, D_, R_, 1>, k_fast<T_, D_, R_, 2>, k_fast<T_, D_, R_, 3>, k_fast<T_, D_, R_, 4>, k_fast<T_, D_, R_, 5>, k_fast<T_, D_, R_, 6>, k_fast<T_, D_, R_, 7>}, (uint32_t)fast_xbytes(T_, D_, R_) }
-#define SDRFM_FASTB(T_, D_, R_) { 'b', T_, D_, R_, {k_fastb<T_, D_, R_, 0>, k_fastb<T_, D_, R_, 1>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, (uint32_t)fastb_xbytes(T_, D_, R_) }
+#define SDRFM_FAST(T_, D_, R_) { 'a', T_, D_, R_, 0, 0, {k_fast<T_, D_, R_, 0>, k_fast<T_, D_, R_, 1>, k_fast<T_, D_, R_, 2>, k_fast<T_, D_, R_, 3>, k_fast<T_, D_, R_, 4>, k_fast<T_, D_, R_, 5>, k_fast<T_, D_, R_, 6>, k_fast<T_, D_, R_, 7>}, (uint32_t)fast_xbytes(T_, D_, R_) }
+#define SDRFM_FASTB(T_, D_, R_) { 'b', T_, D_, R_, 32, 5, {k_fastb<T_, D_, R_, 32, 5, 0>, k_fastb<T_, D_, R_, 32, 5, 1>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, (uint32_t)fastb_xbytes(T_, D_, R_) }
 const FastVariant kFastVariants[] = {
     SDRFM_FASTB(64, 10, 12), SDRFM_FASTB(64, 10, 8), SDRFM_FASTB(16, 10, 12), SDRFM_FASTB(16, 10, 8), SDRFM_FASTB(32, 10, 12), SDRFM_FASTB(32, 10, 8),
     SDRFM_FAST(64, 10, 2), SDRFM_FAST(64, 10, 3), SDRFM_FAST(64, 10, 4),
@@ -1041,6 +1102,7 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
     for (int pass = 0; pass < 3 && !h->fast; ++pass)
     for (const FastVariant& v : kFastVariants) {
       if (v.T != cfg->fir_taps || v.D != cfg->fir_decim) continue;
+      if (v.Ta && (v.Ta != cfg->audio_taps || v.Da != cfg->audio_decim)) continue;
       if (pass == 0 && (v.R != want_r || v.kind != want_kind)) continue;
       if (pass == 1 && v.kind != want_kind) continue;
       const uint32_t NYT = 64 * v.R, DOFF = (cfg->audio_taps - 1 + 3u) & ~3u;
@@ -1172,7 +1234,11 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
     if (segs < 1) segs = 1;
     p.NA = (A + segs - 1) / segs;
     p.tiles_per_stream = (A + p.NA - 1) / p.NA;
-    const uint32_t grid = c.n_streams * p.tiles_per_stream + c.n_streams;
+    uint32_t grid = c.n_streams * p.tiles_per_stream + c.n_streams;
+    // design B: state hand-over folded into the last segment's wave (needs M >= Ta so that the d ring alone holds the
+    // new history, and the last sub-tile must contain y[M-1], which the kernel arranges)
+    p.fold_state = (h->fast->kind == 'b' && M >= c.audio_taps && !getenv("SDRFM_NO_FOLD")) ? 1u : 0u;
+    if (p.fold_state) grid -= c.n_streams;
     hipLaunchKernelGGL(h->fast->kernel[h->fast_mode], dim3(grid), dim3(64), h->fast_lds, h->stream, p);
     snprintf(h->kernel_name, sizeof(h->kernel_name), "%s", h->fast_name);
     if (h->fast->kind == 'b' && h->n_seen + 1 < c.fir_taps) {

@@ -92,7 +92,7 @@ class FmDemod:
         """sdrfm_debug_phase_cycles: dict of cumulative shader cycles per kernel phase (profiling builds only)."""
         out = (C.c_uint64 * 8)()
         self._ck(self._lib.sdrfm_debug_phase_cycles(self._h, out), "sdrfm_debug_phase_cycles")
-        names = ["stage", "fir", "disc", "audio", "carry", "subtiles", "waves"]
+        names = ["stage", "fir", "disc", "audio", "carry", "subtiles", "waves", "prologue"]
         return {n: int(out[i]) for i, n in enumerate(names)}
 
     # -- host buffers -----------------------------------------------------------------------------------------

@@ -20,9 +20,14 @@ for _ in range(reps):
     dm.process_batch_device(iq, audio)
 dm.synchronize(); t1.record(); torch.cuda.synchronize()
 pc = dm.phase_cycles()
+rt_ticks = pc["carry"] >> 32; pc["carry"] &= (1 << 32) - 1
+wave_cyc = pc["waves"] >> 20; pc["waves"] &= (1 << 20) - 1
 st = pc["subtiles"]
 tot = sum(pc[k] for k in ("stage", "fir", "disc", "audio", "carry"))
 print(dm.kernel_name, "| us/launch (instrumented, stream-sync'd): %.1f" % (t0.elapsed_time(t1) * 1e3 / reps))
 print("waves/launch %d  subtiles/wave %.1f  cycles/subtile %.0f" % (pc["waves"] / reps, st / pc["waves"], tot / st))
 for k in ("stage", "fir", "disc", "audio", "carry"):
     print("  %-6s %8.0f cycles/subtile  %5.1f%%" % (k, pc[k] / st, 100.0 * pc[k] / tot))
+if rt_ticks:
+    print("  whole wave: %.0f cycles, %.2f us real time  => shader clock %.2f GHz" % (wave_cyc / pc["waves"], rt_ticks / pc["waves"] / 100.0, wave_cyc / (rt_ticks / 100.0) / 1e3))
+print("  prologue %8.0f cycles/wave; loop %8.0f cycles/wave" % (pc["prologue"] / pc["waves"], tot / pc["waves"]))
