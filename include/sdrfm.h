@@ -128,6 +128,11 @@ float sdrfm_host_discriminate(float yr, float yi, float pr, float pi);
  * discriminator, audio, carry; out[5] = sub-tiles; out[6] = waves; and resets them. SDRFM_NOT_SUPPORTED otherwise. */
 int sdrfm_debug_phase_cycles(sdrfm_t* h, unsigned long long* out8);
 
+/* Test hook: stage K3 evaluated ON THE DEVICE for n operand sets (host arrays): out_scalar = the scalar routine of the
+ * generic kernel / state hand-over, out_pair = the packed two-at-a-time routine of the specialised kernels. */
+int sdrfm_debug_discriminate(int device, const float* yr, const float* yi, const float* pr, const float* pi,
+                             float* out_scalar, float* out_pair, uint32_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -895,6 +895,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 3)))
 #undef SDRFM_TICK
 }
 
+// test hook: evaluates K3 on the device both ways the kernels do (scalar form and packed-pair form)
+__global__ void k_debug_discriminate(const float* yr, const float* yi, const float* pr, const float* pi, float* out_scalar,
+                                     float* out_pair, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out_scalar[i] = sdrfm_discriminate(yr[i], yi[i], pr[i], pi[i]);
+  // pair form: element .x is (y | p); element .y is fed the same operands through the second slot
+  const f2_t d2 = discriminate_pair(f2_t{pr[i], pi[i]}, f2_t{0.f, 0.f}, f2_t{yr[i], yi[i]});
+  out_pair[i] = d2.y;   // second slot computes disc(y1 = (yr,yi) | y0 = (pr,pi))
+}
+
 struct FastVariant {
   char kind;                         // 'a' = float tile (design A), 'b' = raw-byte tile (design B)
   uint32_t T, D, R;
@@ -1327,6 +1338,29 @@ int sdrfm_debug_phase_cycles(sdrfm_t* h, unsigned long long* out8) {
   for (int g = 0; g < 64; ++g)
     for (int i = 0; i < 8; ++i) out8[i] += tmp[8 * g + i];
   return SDRFM_OK;
+}
+
+/* Test hook: K3 evaluated ON THE DEVICE for n operand sets (host arrays in, host arrays out): out_scalar uses the scalar
+ * routine of the generic kernel / state hand-over, out_pair the packed two-at-a-time routine of the fast kernels. */
+int sdrfm_debug_discriminate(int device, const float* yr, const float* yi, const float* pr, const float* pi,
+                             float* out_scalar, float* out_pair, uint32_t n) {
+  if (!yr || !yi || !pr || !pi || !out_scalar || !out_pair) return SDRFM_EINVAL;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return SDRFM_NO_DEVICE;
+  HIP_TRY(hipSetDevice(device), SDRFM_NO_DEVICE);
+  float* d = nullptr;
+  const size_t bytes = sizeof(float) * n;
+  HIP_TRY(hipMalloc(&d, 6 * bytes + 64), SDRFM_ENOMEM);
+  const float* in[4] = {yr, yi, pr, pi};
+  for (int k = 0; k < 4; ++k)
+    if (hipMemcpy(d + (size_t)k * n, in[k], bytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return SDRFM_FAIL; }
+  hipLaunchKernelGGL(k_debug_discriminate, dim3((n + 255) / 256), dim3(256), 0, 0, d, d + n, d + 2 * (size_t)n, d + 3 * (size_t)n,
+                     d + 4 * (size_t)n, d + 5 * (size_t)n, (int)n);
+  int rc = SDRFM_OK;
+  if (hipMemcpy(out_scalar, d + 4 * (size_t)n, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = SDRFM_FAIL;
+  if (hipMemcpy(out_pair, d + 5 * (size_t)n, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = SDRFM_FAIL;
+  (void)hipFree(d);
+  return rc;
 }
 
 /* Host evaluation of the device's atan2 / discriminator arithmetic (same header, same rounding) so that its accuracy

@@ -201,3 +201,71 @@ def test_caller_stream_is_honoured(pkg, oracle_mod):
     assert scaled_err(audio.cpu().numpy(), oracle_mod.process_batch(h, g, iq_host)) <= TOL
     dm.set_stream(None)
     dm.close()
+
+
+# ---- kernel-variant coverage ---------------------------------------------------------------------------------------
+def _run_chunks(dm, iq, cuts):
+    parts, pos = [], 0
+    for c in list(cuts) + [iq.size]:
+        parts.append(dm.process(iq[pos:c]))
+        pos = c
+    return np.concatenate(parts)
+
+
+@pytest.mark.parametrize("T", [16, 64])
+@pytest.mark.parametrize("kind", ["b", "a"])
+def test_specialised_kernels_equal_generic_kernel_bitwise(pkg, oracle_mod, monkeypatch, T, kind):
+    """The (T,D)-specialised kernels (design A: float tile, design B: raw-byte tile) and the generic kernel run the same
+    fp32 chains in the same order, so their audio must be identical bit for bit — first call (zero history), later calls
+    (carried state) and ragged cut points included."""
+    monkeypatch.setenv("SDRFM_FAST_KIND", kind)
+    h, g = pkg.default_config(T)
+    iq = pkg.make_iq(1, 180000, mode="fm", first_id=77)[0]
+    cuts = [2 * 5000, 2 * 5000 + 2 * 61000, 2 * 140008]          # all even sample counts -> specialised path stays eligible
+    fast = pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, max_bytes_per_call=400000))
+    gen = pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, max_bytes_per_call=400000, force_generic=True))
+    a_fast = _run_chunks(fast, iq, cuts)
+    assert fast.kernel_name.startswith("fast-" + kind), fast.kernel_name
+    a_gen = _run_chunks(gen, iq, cuts)
+    assert gen.kernel_name.startswith("generic")
+    assert np.array_equal(a_fast.view(np.uint32), a_gen.view(np.uint32))
+    assert scaled_err(a_fast, oracle_mod.Oracle(h, g).process(iq)) <= TOL
+    fast.close(); gen.close()
+
+
+def test_odd_sample_counts_fall_back_and_recover(pkg, oracle_mod):
+    """A chunk with an odd number of IQ samples makes the decimator phase odd: the next calls use the generic kernel
+    until the phase is even again; the audio is unaffected."""
+    h, g = pkg.default_config(64)
+    iq = pkg.make_iq(1, 90001, mode="fm", first_id=78)[0]
+    dm = pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g))
+    names, parts, pos = [], [], 0
+    for n in (40000, 10001, 10000, 10001, 19999):                # samples per call
+        parts.append(dm.process(iq[pos:pos + 2 * n]))
+        names.append(dm.kernel_name.split()[0])
+        pos += 2 * n
+    assert pos == iq.size
+    assert names[0].startswith("fast") and names[2] == "generic" and names[4].startswith("fast"), names
+    assert scaled_err(np.concatenate(parts), oracle_mod.Oracle(h, g).process(iq)) <= TOL
+    dm.close()
+
+
+def test_device_discriminator_arithmetic(pkg):
+    """K3 on the device: both code forms (scalar, packed pair) against double-precision atan2 of the exact products."""
+    import ctypes as C
+    lib = pkg.load_library()
+    rng = np.random.default_rng(3)
+    n = 200000
+    yr, yi, pr, pi = [(rng.standard_normal(n) * 10 ** rng.uniform(-3, 2.5, n)).astype(np.float32) for _ in range(4)]
+    yr[:4], yi[:4], pr[:4], pi[:4] = [1, 5, 0, -3], [0, 7, 1, 0.5], [0, 5, 1, 0], [0, 7, 0, 0]   # zero / equal cases
+    o1 = np.empty(n, np.float32); o2 = np.empty(n, np.float32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert lib.sdrfm_debug_discriminate(0, vp(yr), vp(yi), vp(pr), vp(pi), vp(o1), vp(o2), n) == 0
+    re = np.float32(yr) * np.float32(pr)  # reference in double from the SAME fp32 products the spec defines
+    re = (yr.astype(np.float64) * pr.astype(np.float64) + (yi * pi).astype(np.float64)).astype(np.float32)
+    im = ((yi * pr) - (yr * pi)).astype(np.float32)
+    want = np.where((re == 0) & (im == 0), 0.0, np.arctan2(im.astype(np.float64), re.astype(np.float64)))
+    assert o1[0] == 0.0 and o1[1] == 0.0 and o2[0] == 0.0 and o2[1] == 0.0
+    for got in (o1, o2):
+        assert np.max(np.abs(got.astype(np.float64) - want)) <= 1.0e-6
+    assert np.array_equal(o1.view(np.uint32), o2.view(np.uint32)), "scalar and packed K3 disagree"
