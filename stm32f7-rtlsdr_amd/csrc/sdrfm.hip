@@ -71,6 +71,8 @@ struct CallParams {
   uint32_t phase_x;           // inputs already consumed towards y[0] (0..D-1)
   uint32_t AB;                // fast kernel: sub-tiles of d buffered per audio flush
   uint32_t warm_ahead;        // fast kernel: L2 warm-up distance in sub-tiles (0 = off)
+  uint32_t prio_balance;      // design B: wave priority falls with progress (keeps the two waves of a SIMD in step)
+  uint32_t dbg_tag;           // profiling build: 1 on the one launch whose wave start/end skew is recorded
   uint32_t fold_state;        // design B: the last segment's wave hands the state over (no state blocks in the grid)
   unsigned long long* dbg;    // phase-cycle accumulators (profiling build of the fast kernel only), else nullptr
 };
@@ -726,6 +728,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 3)))
     tlast = tn;
   }
   for (int st = 0; st < nst; ++st) {
+    // The two waves of a SIMD are arbitrated oldest-first, so one runs ahead and the other finishes alone at the
+    // single-wave issue rate (measured: first wave done at 28 us, last at 47 us).  Priority falls with progress, so
+    // whichever wave is behind wins the issue slot and the pair finishes together.
+    if (p.prio_balance) {
+      const int left = nst - 1 - st;
+      if (left >= 3) __builtin_amdgcn_s_setprio(3);
+      else if (left == 2) __builtin_amdgcn_s_setprio(2);
+      else if (left == 1) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    }
     // ---- stage the prefetched raw bytes, then prefetch the next sub-tile --------------------------------------
 #pragma unroll
     for (int q = 0; q < NLOAD; ++q) {
@@ -839,9 +851,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 3)))
           a2 = __builtin_fmaf(gk, w2[k], a2);
         }
         float* o = p.audio + (size_t)stream * p.audio_stride;
-        o[j] = a0;
-        if (jb < jh) o[jb] = a1;
-        if (jc < jh) o[jc] = a2;
+        __builtin_nontemporal_store(a0, o + j);               // streamed out once: do not leave dirty lines in L2
+        if (jb < jh) __builtin_nontemporal_store(a1, o + jb);
+        if (jc < jh) __builtin_nontemporal_store(a2, o + jc);
       }
       if (!last) {
         float keep[4];
@@ -887,6 +899,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 3)))
       atomicAdd(p.dbg + 8 * (blockIdx.x & 63) + 5, (unsigned long long)nst);
       atomicAdd(p.dbg + 8 * (blockIdx.x & 63) + 6, 1ull);
       atomicAdd(p.dbg + 8 * (blockIdx.x & 63) + 7, (unsigned long long)tph[7]);
+      // launch-wide skew: earliest/latest wave start and end (100 MHz real-time ticks), in the last 4 debug slots
+      const unsigned long long rt_end = __builtin_amdgcn_s_memrealtime();
+      // (real-time counters are per XCD and not synchronised: compare waves of XCC 0 only; HW_REG_XCC_ID = hwreg 20)
+      if (p.dbg_tag && (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15) == 0) { atomicMin(p.dbg + 512, rt_entry); atomicMax(p.dbg + 513, rt_entry); atomicMin(p.dbg + 514, rt_end); atomicMax(p.dbg + 515, rt_end); }
       // whole-wave duration in 100 MHz real-time ticks and in shader cycles -> effective shader clock
       atomicAdd(p.dbg + 8 * (blockIdx.x & 63) + 4, ((__builtin_amdgcn_s_memrealtime() - rt_entry) << 32));
       atomicAdd(p.dbg + 8 * (blockIdx.x & 63) + 6, ((unsigned long long)((unsigned)__builtin_readcyclecounter() - t_entry)) << 20);
@@ -958,6 +974,7 @@ struct sdrfm {
   uint32_t AB;             // sub-tiles of d buffered per audio flush
   unsigned long long* d_dbg;  // phase profile accumulators (only with SDRFM_PHASE_PROFILE=1)
   uint32_t warm_ahead;        // L2 warm-up distance (sub-tiles)
+  uint32_t dbg_launches;      // launches since the debug counters were last reset
   int fast_mode;              // 0 product; 1..5 timing experiments selected by environment variables
   char kernel_name[64];
   char generic_name[64];
@@ -1132,8 +1149,8 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
       if (const char* e = getenv("SDRFM_WARM_AHEAD")) h->warm_ahead = (uint32_t)atoi(e);
       if (const char* e = getenv("SDRFM_ABLATE")) { const int m = atoi(e); if (m >= 2 && m <= 7 && v.kernel[m]) h->fast_mode = m; }
       if (getenv("SDRFM_PHASE_PROFILE") && !h->d_dbg) {
-        if (hipMalloc(&h->d_dbg, 512 * sizeof(unsigned long long)) != hipSuccess) h->d_dbg = nullptr;
-        else { (void)hipMemset(h->d_dbg, 0, 512 * sizeof(unsigned long long)); h->fast_mode = 1; }
+        if (hipMalloc(&h->d_dbg, 520 * sizeof(unsigned long long)) != hipSuccess) h->d_dbg = nullptr;
+        else { (void)hipMemset(h->d_dbg, 0, 520 * sizeof(unsigned long long)); (void)hipMemset(h->d_dbg + 512, 0xff, 8); (void)hipMemset(h->d_dbg + 514, 0xff, 8); h->fast_mode = 1; }
       }
       h->fast = &v;
       h->fast_lds = lds;
@@ -1232,6 +1249,8 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
   p.phase_x = h->phase_x;
   p.AB = h->AB;
   p.dbg = h->d_dbg;
+  p.prio_balance = getenv("SDRFM_NO_PRIO") ? 0u : 1u;
+  p.dbg_tag = (h->d_dbg && ++h->dbg_launches == 16) ? 1u : 0u;
   p.warm_ahead = h->warm_ahead;
   const bool fast_ok = h->fast && A > 0 && (h->phase_x % 2 == 0) && ((uintptr_t)d_iq % 4 == 0) && (iq_stride % 4 == 0) &&
                        N < (1u << 30);
@@ -1334,6 +1353,8 @@ int sdrfm_debug_phase_cycles(sdrfm_t* h, unsigned long long* out8) {
   unsigned long long tmp[512];
   HIP_TRY(hipMemcpy(tmp, h->d_dbg, sizeof(tmp), hipMemcpyDeviceToHost), SDRFM_FAIL);
   HIP_TRY(hipMemset(h->d_dbg, 0, sizeof(tmp)), SDRFM_FAIL);
+  (void)hipMemset(h->d_dbg + 512, 0, 8 * sizeof(unsigned long long)); (void)hipMemset(h->d_dbg + 512, 0xff, 8); (void)hipMemset(h->d_dbg + 514, 0xff, 8);
+  h->dbg_launches = 0;
   for (int i = 0; i < 8; ++i) out8[i] = 0;
   for (int g = 0; g < 64; ++g)
     for (int i = 0; i < 8; ++i) out8[i] += tmp[8 * g + i];
@@ -1361,6 +1382,16 @@ int sdrfm_debug_discriminate(int device, const float* yr, const float* yi, const
   if (hipMemcpy(out_pair, d + 5 * (size_t)n, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = SDRFM_FAIL;
   (void)hipFree(d);
   return rc;
+}
+
+/* Profiling aid: raw dump of the 520 debug words (slots 512..515 = min/max wave start, min/max wave end in 100 MHz ticks). */
+int sdrfm_debug_raw(sdrfm_t* h, unsigned long long* out512) {
+  if (!h || !out512) return SDRFM_EINVAL;
+  if (!h->d_dbg) return SDRFM_NOT_SUPPORTED;
+  HIP_TRY(hipSetDevice(h->device), SDRFM_FAIL);
+  HIP_TRY(hipStreamSynchronize(h->stream), SDRFM_FAIL);
+  HIP_TRY(hipMemcpy(out512, h->d_dbg, 520 * sizeof(unsigned long long), hipMemcpyDeviceToHost), SDRFM_FAIL);
+  return SDRFM_OK;
 }
 
 /* Host evaluation of the device's atan2 / discriminator arithmetic (same header, same rounding) so that its accuracy

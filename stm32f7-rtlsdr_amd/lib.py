@@ -15,7 +15,7 @@ F_DEVICE_PTRS = 1
 ABI_SYMBOLS = [
     "sdrfm_create", "sdrfm_destroy", "sdrfm_reset", "sdrfm_audio_count", "sdrfm_process", "sdrfm_process_batch",
     "sdrfm_set_stream", "sdrfm_synchronize", "sdrfm_kernel_name", "sdrfm_abi_version", "sdrfm_strerror",
-    "sdrfm_host_atan2f", "sdrfm_host_discriminate", "sdrfm_debug_phase_cycles", "sdrfm_debug_discriminate",
+    "sdrfm_host_atan2f", "sdrfm_host_discriminate", "sdrfm_debug_phase_cycles", "sdrfm_debug_discriminate", "sdrfm_debug_raw",
 ]
 
 
@@ -87,6 +87,8 @@ def load_library():
     lib.sdrfm_host_discriminate.restype = C.c_float
     lib.sdrfm_debug_phase_cycles.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.sdrfm_debug_phase_cycles.restype = C.c_int
+    lib.sdrfm_debug_raw.argtypes = [vp, C.POINTER(C.c_uint64)]
+    lib.sdrfm_debug_raw.restype = C.c_int
     lib.sdrfm_debug_discriminate.argtypes = [C.c_int] + [vp] * 6 + [u32]
     lib.sdrfm_debug_discriminate.restype = C.c_int
     _lib = lib
