@@ -136,6 +136,40 @@ int sdrfm_debug_raw(sdrfm_t* h, unsigned long long* out520);
 int sdrfm_debug_discriminate(int device, const float* yr, const float* yi, const float* pr, const float* pi,
                              float* out_scalar, float* out_pair, uint32_t n);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Multi-channel WBFM (BASELINE configs[4]): one wide capture (3.2 MS/s) -> 16-band critically-sampled polyphase
+ * channelizer (prototype low-pass p[0..P), P a multiple of 16; each band at fs/16 = 200 kS/s) -> per-band FM
+ * discriminator -> rational L/M resampler (6/25 -> 48 kHz) with prototype g[0..Tg) given at the L-times-upsampled rate.
+ * Same hand-off contract as sdrfm_process_batch (buffer format, status codes, threading); arithmetic: DESIGN.md.
+ * audio layout: audio[(stream * 16 + band) * band_stride + j].
+ * ------------------------------------------------------------------------------------------------------------------ */
+#define SDRFM_WBFM_BANDS 16
+
+typedef struct sdrfm_wbfm_config {
+  uint32_t struct_size;           /* = sizeof(sdrfm_wbfm_config) */
+  uint32_t n_streams;
+  uint32_t proto_taps;            /* P: multiple of 16, <= 512 */
+  const float* proto_coeffs;
+  uint32_t resamp_taps;           /* Tg <= 512 */
+  uint32_t resamp_up;             /* L <= 64 */
+  uint32_t resamp_down;           /* M <= 256 */
+  const float* resamp_coeffs;
+  uint32_t max_bytes_per_call;    /* per stream; 0 = 1 MiB */
+  int32_t  device;
+  uint32_t flags;                 /* must be 0 */
+} sdrfm_wbfm_config;
+
+typedef struct sdrfm_wbfm sdrfm_wbfm_t;
+
+int  sdrfm_wbfm_create(const sdrfm_wbfm_config* cfg, sdrfm_wbfm_t** out);
+void sdrfm_wbfm_destroy(sdrfm_wbfm_t* h);
+int  sdrfm_wbfm_reset(sdrfm_wbfm_t* h);
+int  sdrfm_wbfm_audio_count(const sdrfm_wbfm_t* h, uint32_t nbytes, uint32_t* n_audio_per_band);
+int  sdrfm_wbfm_process_batch(sdrfm_wbfm_t* h, const uint8_t* iq, size_t iq_stride, uint32_t nbytes_per_stream,
+                              float* audio, size_t band_stride, uint32_t* n_audio_per_band, uint32_t flags);
+int  sdrfm_wbfm_set_stream(sdrfm_wbfm_t* h, void* hip_stream);
+int  sdrfm_wbfm_synchronize(sdrfm_wbfm_t* h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -91,3 +91,56 @@ def process_batch(h, g, iq2d, D=10, Da=5):
         outs.append(o.process(iq2d[s]))
         o.close()
     return np.stack(outs)
+
+
+# ---- multi-channel WBFM (BASELINE configs[4]) --------------------------------------------------------------------
+_wlib = None
+
+
+def _wload():
+    global _wlib
+    if _wlib is None:
+        path = os.path.join(_HERE, "libsdrfm_wbfm_oracle.so")
+        if not os.path.exists(path):
+            raise ImportError("%s missing: run `make -C oracle`" % path)
+        lib = C.CDLL(path)
+        vp = C.c_void_p
+        lib.sdrfm_wbfm_oracle_create.argtypes = [C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]
+        lib.sdrfm_wbfm_oracle_create.restype = vp
+        lib.sdrfm_wbfm_oracle_destroy.argtypes = [vp]
+        lib.sdrfm_wbfm_oracle_destroy.restype = None
+        lib.sdrfm_wbfm_oracle_process.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t]
+        lib.sdrfm_wbfm_oracle_process.restype = C.c_long
+        _wlib = lib
+    return _wlib
+
+
+class WbfmOracle:
+    """One stream of the 16-band channelizer + per-band FM demod + L/M resampler oracle."""
+    NB = 16
+
+    def __init__(self, p, g, L=6, M=25):
+        self._lib = _wload()
+        self.p = np.ascontiguousarray(p, dtype=np.float32)
+        self.g = np.ascontiguousarray(g, dtype=np.float32)
+        self.L, self.M = int(L), int(M)
+        self._o = self._lib.sdrfm_wbfm_oracle_create(self.p.size, self.p.ctypes.data, self.g.size, self.L, self.M, self.g.ctypes.data)
+        if not self._o:
+            raise ValueError("sdrfm_wbfm_oracle_create failed")
+
+    def close(self):
+        if self._o:
+            self._lib.sdrfm_wbfm_oracle_destroy(self._o)
+            self._o = None
+
+    def __del__(self):
+        self.close()
+
+    def process(self, iq):
+        iq = np.ascontiguousarray(iq, dtype=np.uint8).reshape(-1)
+        cap = (iq.size // 2 // self.NB + 2) * self.L // self.M + 2
+        out = np.zeros((self.NB, cap), dtype=np.float32)
+        n = self._lib.sdrfm_wbfm_oracle_process(self._o, iq.ctypes.data, iq.size, out.ctypes.data, cap)
+        if n < 0:
+            raise ValueError("sdrfm_wbfm_oracle_process rejected its arguments")
+        return out[:, :n].copy()

@@ -16,6 +16,8 @@ ABI_SYMBOLS = [
     "sdrfm_create", "sdrfm_destroy", "sdrfm_reset", "sdrfm_audio_count", "sdrfm_process", "sdrfm_process_batch",
     "sdrfm_set_stream", "sdrfm_synchronize", "sdrfm_kernel_name", "sdrfm_abi_version", "sdrfm_strerror",
     "sdrfm_host_atan2f", "sdrfm_host_discriminate", "sdrfm_debug_phase_cycles", "sdrfm_debug_discriminate", "sdrfm_debug_raw",
+    "sdrfm_wbfm_create", "sdrfm_wbfm_destroy", "sdrfm_wbfm_reset", "sdrfm_wbfm_audio_count", "sdrfm_wbfm_process_batch",
+    "sdrfm_wbfm_set_stream", "sdrfm_wbfm_synchronize",
 ]
 
 
@@ -37,6 +39,15 @@ class Config(C.Structure):
         ("fir_coeffs", C.POINTER(C.c_float)), ("audio_taps", C.c_uint32), ("audio_decim", C.c_uint32),
         ("audio_coeffs", C.POINTER(C.c_float)), ("max_bytes_per_call", C.c_uint32), ("device", C.c_int32),
         ("flags", C.c_uint32),
+    ]
+
+
+class WbfmConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("n_streams", C.c_uint32), ("proto_taps", C.c_uint32),
+        ("proto_coeffs", C.POINTER(C.c_float)), ("resamp_taps", C.c_uint32), ("resamp_up", C.c_uint32),
+        ("resamp_down", C.c_uint32), ("resamp_coeffs", C.POINTER(C.c_float)), ("max_bytes_per_call", C.c_uint32),
+        ("device", C.c_int32), ("flags", C.c_uint32),
     ]
 
 
@@ -91,5 +102,19 @@ def load_library():
     lib.sdrfm_debug_raw.restype = C.c_int
     lib.sdrfm_debug_discriminate.argtypes = [C.c_int] + [vp] * 6 + [u32]
     lib.sdrfm_debug_discriminate.restype = C.c_int
+    lib.sdrfm_wbfm_create.argtypes = [C.POINTER(WbfmConfig), C.POINTER(vp)]
+    lib.sdrfm_wbfm_create.restype = C.c_int
+    lib.sdrfm_wbfm_destroy.argtypes = [vp]
+    lib.sdrfm_wbfm_destroy.restype = None
+    lib.sdrfm_wbfm_reset.argtypes = [vp]
+    lib.sdrfm_wbfm_reset.restype = C.c_int
+    lib.sdrfm_wbfm_audio_count.argtypes = [vp, u32, u32p]
+    lib.sdrfm_wbfm_audio_count.restype = C.c_int
+    lib.sdrfm_wbfm_process_batch.argtypes = [vp, vp, C.c_size_t, u32, vp, C.c_size_t, u32p, u32]
+    lib.sdrfm_wbfm_process_batch.restype = C.c_int
+    lib.sdrfm_wbfm_set_stream.argtypes = [vp, vp]
+    lib.sdrfm_wbfm_set_stream.restype = C.c_int
+    lib.sdrfm_wbfm_synchronize.argtypes = [vp]
+    lib.sdrfm_wbfm_synchronize.restype = C.c_int
     _lib = lib
     return lib
