@@ -170,6 +170,18 @@ int  sdrfm_wbfm_process_batch(sdrfm_wbfm_t* h, const uint8_t* iq, size_t iq_stri
 int  sdrfm_wbfm_set_stream(sdrfm_wbfm_t* h, void* hip_stream);
 int  sdrfm_wbfm_synchronize(sdrfm_wbfm_t* h);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Host-only helpers (no GPU): the two pure computations the reference performs when it programs the RTL2832 for this
+ * stream, so that a non-MCU front end configures a dongle identically.
+ *   sdrfm_rtl_pack_fir  : RTLSDR_set_fir, state RTLSDR_FIR_CALC (Class/RTLSDR/Src/usbh_rtlsdr.c:552-575): RTLSDR_FIR[16]
+ *                         (8 x int8 then 8 x int12) -> 20 bytes for demod page 1 regs 0x1c..0x2f.
+ *   sdrfm_rtl_resampler : RTLSDR_set_sample_rate state 0 (usbh_rtlsdr.c:676-691); xtal_hz = 28 800 000 for the stock dongle.
+ * Both return SDRFM_EINVAL where the firmware would only log.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int sdrfm_rtl_pack_fir(const int* fir16, uint8_t* out20);
+int sdrfm_rtl_resampler(uint32_t samp_rate, uint32_t xtal_hz, uint32_t* rsamp_ratio, uint32_t* real_rsamp_ratio,
+                        double* real_rate);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,45 @@
+/*
+ * rtlctl.c — host-side restatement of the two pure-integer/double computations the reference performs when it
+ * configures the RTL2832 for the stream this library consumes.  Plain C, no GPU, no USB: a non-MCU
+ * front end can use it to program a dongle consistently with the firmware.  Known-answer tests: tests/test_rtlctl.py
+ * (values obtained from the reference's own code).
+ *
+ *   sdrfm_rtl_pack_fir      : RTLSDR_set_fir's RTLSDR_FIR_CALC state — 8 x int8 + 8 x int12 -> 20 register bytes for demod
+ *                             page 1, registers 0x1c..0x2f (Class/RTLSDR/Src/usbh_rtlsdr.c:552-575)
+ *   sdrfm_rtl_resampler     : RTLSDR_set_sample_rate state 0 — rsamp_ratio, the sign-extended "real" ratio and the exact
+ *                             rate (usbh_rtlsdr.c:676-691).  Unlike the firmware, which only logs, invalid input is refused.
+ */
+#include <stdint.h>
+
+#include "../../include/sdrfm.h"
+
+int sdrfm_rtl_pack_fir(const int* fir16, uint8_t* out20) {
+  if (!fir16 || !out20) return SDRFM_EINVAL;
+  for (int i = 0; i < 8; ++i) {                 /* outer taps: int8 */
+    if (fir16[i] < -128 || fir16[i] > 127) return SDRFM_EINVAL;
+    out20[i] = (uint8_t)fir16[i];
+  }
+  for (int i = 0; i < 8; i += 2) {              /* inner taps: two int12 in three bytes */
+    const int a = fir16[8 + i], b = fir16[8 + i + 1];
+    if (a < -2048 || a > 2047 || b < -2048 || b > 2047) return SDRFM_EINVAL;
+    uint8_t* o = out20 + 8 + i * 3 / 2;
+    o[0] = (uint8_t)(a >> 4);
+    o[1] = (uint8_t)((a << 4) | ((b >> 8) & 0x0f));
+    o[2] = (uint8_t)b;
+  }
+  return SDRFM_OK;
+}
+
+int sdrfm_rtl_resampler(uint32_t samp_rate, uint32_t xtal_hz, uint32_t* rsamp_ratio, uint32_t* real_rsamp_ratio, double* real_rate) {
+  if (!rsamp_ratio || !real_rsamp_ratio || !real_rate || !xtal_hz) return SDRFM_EINVAL;
+  /* the resampler's validity window (usbh_rtlsdr.c:677-678) */
+  if (samp_rate <= 225000u || samp_rate > 3200000u || (samp_rate > 300000u && samp_rate <= 900000u)) return SDRFM_EINVAL;
+  const double num = (double)xtal_hz * 4194304.0;          /* xtal * 2^22 */
+  uint32_t ratio = (uint32_t)(num / (double)samp_rate);
+  ratio &= 0x0ffffffcu;
+  const uint32_t real = ratio | ((ratio & 0x08000000u) << 1);
+  *rsamp_ratio = ratio;
+  *real_rsamp_ratio = real;
+  *real_rate = num / (double)real;
+  return SDRFM_OK;
+}
