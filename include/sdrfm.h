@@ -128,8 +128,8 @@ float sdrfm_host_discriminate(float yr, float yi, float pr, float pi);
  * discriminator, audio, carry; out[5] = sub-tiles; out[6] = waves; and resets them. SDRFM_NOT_SUPPORTED otherwise. */
 int sdrfm_debug_phase_cycles(sdrfm_t* h, unsigned long long* out8);
 
-/* Profiling aid: raw dump of the 520 debug words of the instrumented build. */
-int sdrfm_debug_raw(sdrfm_t* h, unsigned long long* out520);
+/* Profiling aid: raw dump of the 560 debug words of the instrumented build. */
+int sdrfm_debug_raw(sdrfm_t* h, unsigned long long* out560);
 
 /* Test hook: stage K3 evaluated ON THE DEVICE for n operand sets (host arrays): out_scalar = the scalar routine of the
  * generic kernel / state hand-over, out_pair = the packed two-at-a-time routine of the specialised kernels. */

@@ -902,7 +902,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 3)))
       // launch-wide skew: earliest/latest wave start and end (100 MHz real-time ticks), in the last 4 debug slots
       const unsigned long long rt_end = __builtin_amdgcn_s_memrealtime();
       // (real-time counters are per XCD and not synchronised: compare waves of XCC 0 only; HW_REG_XCC_ID = hwreg 20)
-      if (p.dbg_tag && (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15) == 0) { atomicMin(p.dbg + 512, rt_entry); atomicMax(p.dbg + 513, rt_entry); atomicMin(p.dbg + 514, rt_end); atomicMax(p.dbg + 515, rt_end); }
+      if (p.dbg_tag) {   // per XCC: slots 448 + 4*xcc + {0: min start, 1: max start, 2: min end, 3: max end}
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;
+        unsigned long long* q = p.dbg + 520 + 4 * xcc;
+        atomicMin(q, rt_entry); atomicMax(q + 1, rt_entry); atomicMin(q + 2, rt_end); atomicMax(q + 3, rt_end);
+      }
       // whole-wave duration in 100 MHz real-time ticks and in shader cycles -> effective shader clock
       atomicAdd(p.dbg + 8 * (blockIdx.x & 63) + 4, ((__builtin_amdgcn_s_memrealtime() - rt_entry) << 32));
       atomicAdd(p.dbg + 8 * (blockIdx.x & 63) + 6, ((unsigned long long)((unsigned)__builtin_readcyclecounter() - t_entry)) << 20);
@@ -1149,8 +1153,8 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
       if (const char* e = getenv("SDRFM_WARM_AHEAD")) h->warm_ahead = (uint32_t)atoi(e);
       if (const char* e = getenv("SDRFM_ABLATE")) { const int m = atoi(e); if (m >= 2 && m <= 7 && v.kernel[m]) h->fast_mode = m; }
       if (getenv("SDRFM_PHASE_PROFILE") && !h->d_dbg) {
-        if (hipMalloc(&h->d_dbg, 520 * sizeof(unsigned long long)) != hipSuccess) h->d_dbg = nullptr;
-        else { (void)hipMemset(h->d_dbg, 0, 520 * sizeof(unsigned long long)); (void)hipMemset(h->d_dbg + 512, 0xff, 8); (void)hipMemset(h->d_dbg + 514, 0xff, 8); h->fast_mode = 1; }
+        if (hipMalloc(&h->d_dbg, 560 * sizeof(unsigned long long)) != hipSuccess) h->d_dbg = nullptr;
+        else { (void)hipMemset(h->d_dbg, 0, 560 * sizeof(unsigned long long)); for (int x = 0; x < 8; ++x) { (void)hipMemset(h->d_dbg + 520 + 4 * x, 0xff, 8); (void)hipMemset(h->d_dbg + 522 + 4 * x, 0xff, 8); } h->fast_mode = 1; }
       }
       h->fast = &v;
       h->fast_lds = lds;
@@ -1353,7 +1357,8 @@ int sdrfm_debug_phase_cycles(sdrfm_t* h, unsigned long long* out8) {
   unsigned long long tmp[512];
   HIP_TRY(hipMemcpy(tmp, h->d_dbg, sizeof(tmp), hipMemcpyDeviceToHost), SDRFM_FAIL);
   HIP_TRY(hipMemset(h->d_dbg, 0, sizeof(tmp)), SDRFM_FAIL);
-  (void)hipMemset(h->d_dbg + 512, 0, 8 * sizeof(unsigned long long)); (void)hipMemset(h->d_dbg + 512, 0xff, 8); (void)hipMemset(h->d_dbg + 514, 0xff, 8);
+  (void)hipMemset(h->d_dbg + 512, 0, 48 * sizeof(unsigned long long));
+  for (int x = 0; x < 8; ++x) { (void)hipMemset(h->d_dbg + 520 + 4 * x, 0xff, 8); (void)hipMemset(h->d_dbg + 522 + 4 * x, 0xff, 8); }
   h->dbg_launches = 0;
   for (int i = 0; i < 8; ++i) out8[i] = 0;
   for (int g = 0; g < 64; ++g)
@@ -1384,13 +1389,13 @@ int sdrfm_debug_discriminate(int device, const float* yr, const float* yi, const
   return rc;
 }
 
-/* Profiling aid: raw dump of the 520 debug words (slots 512..515 = min/max wave start, min/max wave end in 100 MHz ticks). */
+/* Profiling aid: raw dump of the 560 debug words (slots 520+4x.. = per-XCC min/max wave start, min/max wave end in 100 MHz ticks). */
 int sdrfm_debug_raw(sdrfm_t* h, unsigned long long* out512) {
   if (!h || !out512) return SDRFM_EINVAL;
   if (!h->d_dbg) return SDRFM_NOT_SUPPORTED;
   HIP_TRY(hipSetDevice(h->device), SDRFM_FAIL);
   HIP_TRY(hipStreamSynchronize(h->stream), SDRFM_FAIL);
-  HIP_TRY(hipMemcpy(out512, h->d_dbg, 520 * sizeof(unsigned long long), hipMemcpyDeviceToHost), SDRFM_FAIL);
+  HIP_TRY(hipMemcpy(out512, h->d_dbg, 560 * sizeof(unsigned long long), hipMemcpyDeviceToHost), SDRFM_FAIL);
   return SDRFM_OK;
 }
 

@@ -46,6 +46,8 @@ struct WParams {
   uint32_t A;                   // audio samples per band this call
   uint32_t phase_x;
   unsigned long long n_d, n_a;  // d / audio samples produced before this call
+  int res_q0;                   // floor(n_a*M/L) - n_d   (call-relative index of the newest d of audio sample n_a)
+  uint32_t res_r0;              // (n_a*M) mod L
   uint32_t NT, tiles_per_stream, n_streams;
 };
 
@@ -171,15 +173,15 @@ __global__ void __launch_bounds__(256) k_wbfm_res(WParams w) {
   const uint32_t idx = (blockIdx.x % per_stream) * 256 + threadIdx.x;
   if (idx >= w.A * NB) return;
   const uint32_t b = idx / w.A, jl = idx % w.A;
-  const unsigned long long j = w.n_a + jl;
-  const unsigned long long tpos = j * w.M;
-  const long long nj = (long long)(tpos / w.L) - (long long)w.n_d;   // call-relative index of the newest d
-  const uint32_t phi = (uint32_t)(tpos % w.L);
+  // (n_a + jl)*M = n_a*M + jl*M: quotient and remainder by L from the host's 64-bit part and a 32-bit local part
+  const uint32_t loc = w.res_r0 + jl * w.M;
+  const int nj = w.res_q0 + (int)(loc / w.L);                // call-relative index of the newest d
+  const uint32_t phi = loc % w.L;
   const int imax = (int)((w.Tg - 1 - phi) / w.L);
   const size_t sb = (size_t)stream * NB + b;
   float acc = 0.0f;
   for (int i = imax; i >= 0; --i) {
-    const long long li = nj - i;
+    const int li = nj - i;
     const float d = (li < 0) ? w.hist_d_in[sb * HD + (HD + li)] : w.dbuf[sb * w.dcap + li];
     acc = __builtin_fmaf(w.g[phi + w.L * (uint32_t)i], d, acc);
   }
@@ -355,6 +357,8 @@ static int wenqueue(sdrfm_wbfm* h, const uint8_t* d_iq, size_t iq_stride, uint32
   w.dbuf = h->d_dbuf; w.p = h->d_p; w.g = h->d_g;
   w.P = c.proto_taps; w.Tg = c.resamp_taps; w.L = c.resamp_up; w.M = c.resamp_down; w.HD = h->HD; w.dcap = h->dcap;
   w.N = N; w.Tn = Tn; w.A = A; w.phase_x = h->phase_x; w.n_d = h->n_d; w.n_a = h->n_a;
+  w.res_q0 = (int)((long long)((h->n_a * c.resamp_down) / c.resamp_up) - (long long)h->n_d);
+  w.res_r0 = (uint32_t)((h->n_a * c.resamp_down) % c.resamp_up);
   w.NT = h->NT; w.tiles_per_stream = (Tn + h->NT - 1) / h->NT; w.n_streams = c.n_streams;
   hipLaunchKernelGGL(k_wbfm_chan, dim3(c.n_streams * w.tiles_per_stream + c.n_streams), dim3(256), h->lds_bytes, h->stream, w);
   WTRY(hipGetLastError(), SDRFM_FAIL);

@@ -20,10 +20,11 @@ for _ in range(reps):
     dm.process_batch_device(iq, audio)
 dm.synchronize(); t1.record(); torch.cuda.synchronize()
 import ctypes as C
-raw = (C.c_uint64 * 520)()
+raw = (C.c_uint64 * 560)()
 dm._lib.sdrfm_debug_raw(dm._h, raw)
-sk = [int(raw[i]) for i in range(512, 516)]
-print('  skew (us): first start 0, last start %.2f, first end %.2f, last end %.2f' % ((sk[1]-sk[0])/100.0, (sk[2]-sk[0])/100.0, (sk[3]-sk[0])/100.0))
+for x in range(8):
+    sk = [int(raw[520 + 4 * x + i]) for i in range(4)]
+    print('  XCC%d (us from its first wave start): last start %.2f, first end %.2f, last end %.2f' % (x, (sk[1]-sk[0])/100.0, (sk[2]-sk[0])/100.0, (sk[3]-sk[0])/100.0))
 pc = dm.phase_cycles()
 rt_ticks = pc["carry"] >> 32; pc["carry"] &= (1 << 32) - 1
 wave_cyc = pc["waves"] >> 20; pc["waves"] &= (1 << 20) - 1
