@@ -182,6 +182,12 @@ int sdrfm_rtl_pack_fir(const int* fir16, uint8_t* out20);
 int sdrfm_rtl_resampler(uint32_t samp_rate, uint32_t xtal_hz, uint32_t* rsamp_ratio, uint32_t* real_rsamp_ratio,
                         double* real_rate);
 
+/* Audio sink format of the reference board (host-side, plain C): de-emphasis y += alpha*(x - y) carried in *state, then
+ * int16 stereo-interleaved PCM (L = R) as BSP_AUDIO_OUT_Play(uint16_t*, Size) takes it
+ * (Utilities/STM32746G-Discovery/stm32746g_discovery_audio.c:224).  pcm_stereo receives 2*n samples. */
+int   sdrfm_pcm_deemph_s16(const float* audio, uint32_t n, float alpha, float gain, float* state, int16_t* pcm_stereo);
+float sdrfm_pcm_alpha(float fs_hz, float tau_s);   /* 1 - exp(-1/(fs*tau)); tau = 75e-6 (US) / 50e-6 (EU) */
+
 #ifdef __cplusplus
 }
 #endif
