@@ -137,6 +137,21 @@ int sdrfm_debug_discriminate(int device, const float* yr, const float* yi, const
                              float* out_scalar, float* out_pair, uint32_t n);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Streaming front-end adapter: a ring of n_buffers pinned host buffers of buffer_bytes each — the multi-buffer scheme the
+ * reference declares but never uses (DEFAULT_BUF_NUMBER 15 x DEFAULT_BUF_LENGTH 16*32*512, usbh_rtlsdr.h:277-278).
+ * Single-stream handles only.  submit() copies the just-filled USB buffer into the next free slot and enqueues
+ * H2D -> kernel -> D2H without waiting (the caller's buffer may be re-armed at once); collect() returns finished audio in
+ * submission order.  Both are non-blocking and answer SDRFM_BUSY (ring full / nothing ready), like the reference's FSM
+ * steps answer USBH_BUSY; collect(wait != 0) blocks for the oldest slot.  Do not mix with sdrfm_process on the same handle
+ * while slots are in flight.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct sdrfm_ring sdrfm_ring_t;
+int  sdrfm_ring_create(sdrfm_t* h, uint32_t n_buffers, uint32_t buffer_bytes, sdrfm_ring_t** out);
+void sdrfm_ring_destroy(sdrfm_ring_t* r);
+int  sdrfm_ring_submit(sdrfm_ring_t* r, const uint8_t* iq, uint32_t nbytes);
+int  sdrfm_ring_collect(sdrfm_ring_t* r, float* audio, uint32_t audio_cap, uint32_t* n_audio, int wait);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Multi-channel WBFM (BASELINE configs[4]): one wide capture (3.2 MS/s) -> 16-band critically-sampled polyphase
  * channelizer (prototype low-pass p[0..P), P a multiple of 16; each band at fs/16 = 200 kS/s) -> per-band FM
  * discriminator -> rational L/M resampler (6/25 -> 48 kHz) with prototype g[0..Tg) given at the L-times-upsampled rate.

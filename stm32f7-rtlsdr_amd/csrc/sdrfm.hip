@@ -985,6 +985,9 @@ struct sdrfm {
   char fast_name[64];
 };
 
+static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nbytes, float* d_audio, size_t audio_stride,
+                   uint32_t* n_audio);
+
 #define HIP_TRY(expr, code)                                                                          \
   do {                                                                                               \
     hipError_t e__ = (expr);                                                                         \
@@ -1345,6 +1348,128 @@ int sdrfm_process(sdrfm_t* h, const uint8_t* iq, uint32_t nbytes, float* audio, 
   (void)sdrfm_audio_count(h, nbytes, &A);
   if (A > audio_cap) return SDRFM_ECAPACITY;
   return sdrfm_process_batch(h, iq, nbytes, nbytes, audio, audio_cap, n_audio, 0);
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Streaming front-end adapter: a ring of pinned host buffers, the multi-buffer scheme the reference
+ * declares but never uses (DEFAULT_BUF_NUMBER 15 x DEFAULT_BUF_LENGTH 16*32*512, Class/RTLSDR/Inc/usbh_rtlsdr.h:277-278).
+ * submit() copies the just-filled USB buffer into the next free slot and enqueues H2D -> kernel -> D2H without waiting;
+ * collect() hands back finished audio in order.  Both are non-blocking and answer SDRFM_BUSY like the reference's FSM
+ * steps do (USBH_BUSY, usbh_def.h:303-311).  H2D of slot k+1 overlaps the kernel of slot k (separate copy streams).
+ * ------------------------------------------------------------------------------------------------------------------ */
+struct sdrfm_ring {
+  sdrfm* h;
+  uint32_t n, slot_bytes, audio_cap;
+  uint8_t** host_iq;      // pinned
+  float** host_audio;     // pinned
+  uint8_t** dev_iq;
+  float** dev_audio;
+  uint32_t* n_audio;      // per slot
+  hipEvent_t *ev_h2d, *ev_kernel, *ev_done;
+  hipStream_t s_h2d, s_d2h;
+  uint32_t head, tail, count;   // head: next slot to submit; tail: oldest slot in flight
+};
+
+static void ring_free(sdrfm_ring* r) {
+  if (!r) return;
+  (void)hipSetDevice(r->h->device);
+  if (r->s_h2d) (void)hipStreamSynchronize(r->s_h2d);
+  (void)hipStreamSynchronize(r->h->stream);
+  if (r->s_d2h) (void)hipStreamSynchronize(r->s_d2h);
+  for (uint32_t i = 0; i < r->n; ++i) {
+    if (r->host_iq && r->host_iq[i]) (void)hipHostFree(r->host_iq[i]);
+    if (r->host_audio && r->host_audio[i]) (void)hipHostFree(r->host_audio[i]);
+    if (r->dev_iq && r->dev_iq[i]) (void)hipFree(r->dev_iq[i]);
+    if (r->dev_audio && r->dev_audio[i]) (void)hipFree(r->dev_audio[i]);
+    if (r->ev_h2d && r->ev_h2d[i]) (void)hipEventDestroy(r->ev_h2d[i]);
+    if (r->ev_kernel && r->ev_kernel[i]) (void)hipEventDestroy(r->ev_kernel[i]);
+    if (r->ev_done && r->ev_done[i]) (void)hipEventDestroy(r->ev_done[i]);
+  }
+  if (r->s_h2d) (void)hipStreamDestroy(r->s_h2d);
+  if (r->s_d2h) (void)hipStreamDestroy(r->s_d2h);
+  free(r->host_iq); free(r->host_audio); free(r->dev_iq); free(r->dev_audio); free(r->n_audio);
+  free(r->ev_h2d); free(r->ev_kernel); free(r->ev_done);
+  delete r;
+}
+
+int sdrfm_ring_create(sdrfm_t* h, uint32_t n_buffers, uint32_t buffer_bytes, sdrfm_ring_t** out) {
+  if (!out) return SDRFM_EINVAL;
+  *out = nullptr;
+  if (!h || h->cfg.n_streams != 1 || n_buffers < 2 || n_buffers > 64 || !buffer_bytes || (buffer_bytes & 1u)) return SDRFM_EINVAL;
+  HIP_TRY(hipSetDevice(h->device), SDRFM_FAIL);
+  sdrfm_ring* r = new (std::nothrow) sdrfm_ring();
+  if (!r) return SDRFM_ENOMEM;
+  memset(static_cast<void*>(r), 0, sizeof(*r));
+  r->h = h; r->n = n_buffers; r->slot_bytes = buffer_bytes;
+  r->audio_cap = max_audio_for(h->cfg, buffer_bytes);
+  r->host_iq = (uint8_t**)calloc(n_buffers, sizeof(void*)); r->host_audio = (float**)calloc(n_buffers, sizeof(void*));
+  r->dev_iq = (uint8_t**)calloc(n_buffers, sizeof(void*)); r->dev_audio = (float**)calloc(n_buffers, sizeof(void*));
+  r->n_audio = (uint32_t*)calloc(n_buffers, sizeof(uint32_t));
+  r->ev_h2d = (hipEvent_t*)calloc(n_buffers, sizeof(hipEvent_t)); r->ev_kernel = (hipEvent_t*)calloc(n_buffers, sizeof(hipEvent_t));
+  r->ev_done = (hipEvent_t*)calloc(n_buffers, sizeof(hipEvent_t));
+  bool ok = r->host_iq && r->host_audio && r->dev_iq && r->dev_audio && r->n_audio && r->ev_h2d && r->ev_kernel && r->ev_done;
+  ok = ok && hipStreamCreateWithFlags(&r->s_h2d, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipStreamCreateWithFlags(&r->s_d2h, hipStreamNonBlocking) == hipSuccess;
+  for (uint32_t i = 0; ok && i < n_buffers; ++i) {
+    ok = ok && hipHostMalloc((void**)&r->host_iq[i], buffer_bytes, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&r->host_audio[i], sizeof(float) * r->audio_cap, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipMalloc((void**)&r->dev_iq[i], ((size_t)buffer_bytes + 255) & ~(size_t)255) == hipSuccess;
+    ok = ok && hipMalloc((void**)&r->dev_audio[i], sizeof(float) * r->audio_cap) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&r->ev_h2d[i], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&r->ev_kernel[i], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&r->ev_done[i], hipEventDisableTiming) == hipSuccess;
+  }
+  if (!ok) { ring_free(r); return SDRFM_ENOMEM; }
+  *out = r;
+  return SDRFM_OK;
+}
+
+void sdrfm_ring_destroy(sdrfm_ring_t* r) { ring_free(r); }
+
+int sdrfm_ring_submit(sdrfm_ring_t* r, const uint8_t* iq, uint32_t nbytes) {
+  if (!r || (nbytes && !iq)) return SDRFM_EINVAL;
+  if (nbytes & 1u) return SDRFM_EODD;
+  if (nbytes > r->slot_bytes) return SDRFM_ECAPACITY;
+  if (nbytes == 0) return SDRFM_OK;
+  if (r->count == r->n) return SDRFM_BUSY;                    // every slot in flight: collect first
+  sdrfm* h = r->h;
+  HIP_TRY(hipSetDevice(h->device), SDRFM_FAIL);
+  const uint32_t s = r->head;
+  memcpy(r->host_iq[s], iq, nbytes);                          // the caller's (single, reused) buffer is free again after this
+  HIP_TRY(hipMemcpyAsync(r->dev_iq[s], r->host_iq[s], nbytes, hipMemcpyHostToDevice, r->s_h2d), SDRFM_FAIL);
+  HIP_TRY(hipEventRecord(r->ev_h2d[s], r->s_h2d), SDRFM_FAIL);
+  HIP_TRY(hipStreamWaitEvent(h->stream, r->ev_h2d[s], 0), SDRFM_FAIL);
+  const int rc = enqueue(h, r->dev_iq[s], nbytes, nbytes, r->dev_audio[s], r->audio_cap, &r->n_audio[s]);
+  if (rc != SDRFM_OK) return rc;
+  HIP_TRY(hipEventRecord(r->ev_kernel[s], h->stream), SDRFM_FAIL);
+  HIP_TRY(hipStreamWaitEvent(r->s_d2h, r->ev_kernel[s], 0), SDRFM_FAIL);
+  if (r->n_audio[s])
+    HIP_TRY(hipMemcpyAsync(r->host_audio[s], r->dev_audio[s], sizeof(float) * r->n_audio[s], hipMemcpyDeviceToHost, r->s_d2h), SDRFM_FAIL);
+  HIP_TRY(hipEventRecord(r->ev_done[s], r->s_d2h), SDRFM_FAIL);
+  r->head = (s + 1) % r->n;
+  ++r->count;
+  return SDRFM_OK;
+}
+
+int sdrfm_ring_collect(sdrfm_ring_t* r, float* audio, uint32_t audio_cap, uint32_t* n_audio, int wait) {
+  if (!r || !n_audio) return SDRFM_EINVAL;
+  *n_audio = 0;
+  if (r->count == 0) return SDRFM_BUSY;                       // nothing in flight
+  HIP_TRY(hipSetDevice(r->h->device), SDRFM_FAIL);
+  const uint32_t s = r->tail;
+  if (wait) {
+    HIP_TRY(hipEventSynchronize(r->ev_done[s]), SDRFM_FAIL);
+  } else {
+    const hipError_t q = hipEventQuery(r->ev_done[s]);
+    if (q == hipErrorNotReady) return SDRFM_BUSY;
+    if (q != hipSuccess) return SDRFM_FAIL;
+  }
+  if (r->n_audio[s] > audio_cap || (r->n_audio[s] && !audio)) return SDRFM_ECAPACITY;
+  memcpy(audio, r->host_audio[s], sizeof(float) * r->n_audio[s]);
+  *n_audio = r->n_audio[s];
+  r->tail = (s + 1) % r->n;
+  --r->count;
+  return SDRFM_OK;
 }
 
 /* Profiling aid (SDRFM_PHASE_PROFILE=1 at create): cumulative shader cycles per phase of the fast kernel, summed over

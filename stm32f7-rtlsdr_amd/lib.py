@@ -19,6 +19,7 @@ ABI_SYMBOLS = [
     "sdrfm_wbfm_create", "sdrfm_wbfm_destroy", "sdrfm_wbfm_reset", "sdrfm_wbfm_audio_count", "sdrfm_wbfm_process_batch",
     "sdrfm_wbfm_set_stream", "sdrfm_wbfm_synchronize", "sdrfm_rtl_pack_fir", "sdrfm_rtl_resampler",
     "sdrfm_pcm_deemph_s16", "sdrfm_pcm_alpha",
+    "sdrfm_ring_create", "sdrfm_ring_destroy", "sdrfm_ring_submit", "sdrfm_ring_collect",
 ]
 
 
@@ -125,5 +126,13 @@ def load_library():
     lib.sdrfm_pcm_deemph_s16.restype = C.c_int
     lib.sdrfm_pcm_alpha.argtypes = [C.c_float, C.c_float]
     lib.sdrfm_pcm_alpha.restype = C.c_float
+    lib.sdrfm_ring_create.argtypes = [vp, u32, u32, C.POINTER(vp)]
+    lib.sdrfm_ring_create.restype = C.c_int
+    lib.sdrfm_ring_destroy.argtypes = [vp]
+    lib.sdrfm_ring_destroy.restype = None
+    lib.sdrfm_ring_submit.argtypes = [vp, vp, u32]
+    lib.sdrfm_ring_submit.restype = C.c_int
+    lib.sdrfm_ring_collect.argtypes = [vp, vp, u32, u32p, C.c_int]
+    lib.sdrfm_ring_collect.restype = C.c_int
     _lib = lib
     return lib
