@@ -22,13 +22,25 @@
 #include "../../include/sdrfm.h"
 #include "sdrfm_math.h"
 
+#include <type_traits>
+typedef int wi4_t __attribute__((ext_vector_type(4)));
+
 namespace {
 
 constexpr int NB = SDRFM_WBFM_BANDS;
 
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for_w(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for_w<I + 1, N>(f);
+  }
+}
+
 struct WParams {
   const uint8_t* iq;
   size_t iq_stride;
+  uint32_t iq_span;                                              // bytes from iq to the end of the last stream (fused kernel)
   float* audio;
   size_t band_stride;           // floats between bands; stream stride = NB * band_stride
   const float2* hist_x_in;      // [ns][P-1]
@@ -190,6 +202,253 @@ __global__ void __launch_bounds__(256) k_wbfm_res(WParams w) {
 
 }  // namespace
 
+// =================================================================================================================
+//  Fused WBFM kernel (P = 16*Q prototype taps, resampler history HD = ceil(Tg/L) <= HDMAX), no LDS tile, no barriers.
+//
+//  A group of 16 lanes owns a RUN of consecutive channelizer steps of one stream; lane k of the group computes polyphase
+//  branch r = bitrev4(k).  Per step every lane
+//    * loads ITS one new input sample (typed buffer load u8x2 -> 2 x f32; the 16 lanes of a group read 32 consecutive
+//      bytes), subtracts 127.5 and pushes it into its private Q-deep sliding window (registers, static renaming) — every
+//      input sample is converted exactly once, by exactly one lane;
+//    * runs the Q-tap chain of its branch (v_pk_fma_f32 on (I,Q), oldest sample first);
+//    * takes part in the 16-point DFT ACROSS the 16 lanes: the branches sit in bit-reversed lane order, stage m pairs
+//      lane k with lane k^(m/2) (one cross-lane exchange), both lanes of a pair evaluate T = w*B with the same
+//      instructions, the low lane keeps A+T, the high lane A-T — exactly the radix-2 DIT graph of the spec, so lane b ends
+//      up with c_b[t] bit-identical to the oracle;
+//    * (steps are processed in pairs) discriminates its band for two steps at once (packed K3), shifts its private
+//      d window and, when an audio sample is due (wave-uniform test), evaluates the L/M resampler chain from registers.
+//  Runs are warmed up by recomputing Q-1 + HD + 1 steps before their first output (from the old state when the run starts
+//  at the call start); the last run of a stream hands the streaming state over.
+// =================================================================================================================
+typedef float wf2_t __attribute__((ext_vector_type(2)));
+__device__ wf2_t wbfm_typed_load_xy(wi4_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.format.v2f32");
+// buffer resource word3: dst_sel = (R, G, 0, 1), num_format = USCALED (2), data_format = 8_8 (3)
+#define SDRFM_RSRC_U8X2_USCALED (4 | (5 << 3) | (0 << 6) | (1 << 9) | (2 << 12) | (3 << 15))
+
+namespace {
+
+template <int HI>
+__device__ __forceinline__ void wpk_fma_v(wf2_t& acc, wf2_t tap_pair, wf2_t x) {   // acc += tap * x, tap = half of a VGPR pair
+  if constexpr (HI == 0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(tap_pair), "v"(x));
+  else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(tap_pair), "v"(x));
+}
+
+// packed K3 for two consecutive steps of one band (same roundings as sdrfm_discriminate)
+__device__ __forceinline__ wf2_t watan2_pair(wf2_t y, wf2_t x) {
+  const wf2_t ax = __builtin_elementwise_abs(x), ay = __builtin_elementwise_abs(y);
+  const wf2_t mx = __builtin_elementwise_max(ax, ay), mn = __builtin_elementwise_min(ax, ay);
+  const wf2_t t = mn * wf2_t{__builtin_amdgcn_rcpf(mx.x), __builtin_amdgcn_rcpf(mx.y)};
+  const wf2_t s = t * t;
+  wf2_t q = wf2_t{0x1.57b128p-9f, 0x1.57b128p-9f};
+  q = __builtin_elementwise_fma(q, s, wf2_t{-0x1.efda1p-7f, -0x1.efda1p-7f});
+  q = __builtin_elementwise_fma(q, s, wf2_t{0x1.50dd96p-5f, 0x1.50dd96p-5f});
+  q = __builtin_elementwise_fma(q, s, wf2_t{-0x1.2dbcfap-4f, -0x1.2dbcfap-4f});
+  q = __builtin_elementwise_fma(q, s, wf2_t{0x1.b11b74p-4f, 0x1.b11b74p-4f});
+  q = __builtin_elementwise_fma(q, s, wf2_t{-0x1.228754p-3f, -0x1.228754p-3f});
+  q = __builtin_elementwise_fma(q, s, wf2_t{0x1.99673ep-3f, 0x1.99673ep-3f});
+  q = __builtin_elementwise_fma(q, s, wf2_t{-0x1.55546cp-2f, -0x1.55546cp-2f});
+  const wf2_t a = __builtin_elementwise_fma(t, s * q, t);
+  float a0 = a.x, a1 = a.y;
+  if (ay.x > ax.x) a0 = 0x1.921fb6p+0f - a0;
+  if (ay.y > ax.y) a1 = 0x1.921fb6p+0f - a1;
+  if (x.x < 0.0f) a0 = 0x1.921fb6p+1f - a0;
+  if (x.y < 0.0f) a1 = 0x1.921fb6p+1f - a1;
+  return wf2_t{__builtin_copysignf(a0, y.x), __builtin_copysignf(a1, y.y)};
+}
+__device__ __forceinline__ wf2_t wdisc_pair(wf2_t c0, wf2_t cm1, wf2_t c1) {   // (d[t], d[t+1]) from c[t-1], c[t], c[t+1]
+  const wf2_t yr = {c0.x, c1.x}, yi = {c0.y, c1.y}, pr = {cm1.x, c0.x}, pi = {cm1.y, c0.y};
+  const wf2_t re = __builtin_elementwise_fma(yr, pr, yi * pi);
+  const wf2_t im = yi * pr - yr * pi;
+  const wf2_t a = watan2_pair(im, re);
+  return wf2_t{(re.x == 0.0f && im.x == 0.0f) ? 0.0f : a.x, (re.y == 0.0f && im.y == 0.0f) ? 0.0f : a.y};
+}
+
+// One stage of the 16-point DFT across the 16 lanes of a group (a DPP row), butterfly partner = lane ^ HALF.
+// The spec's butterfly is (A, B) -> (A + W B, A - W B) with A in the low lane and B in the high lane.  Every lane first
+// forms z = high ? W v : v (a select, not a multiplication by (1, 0): that could turn a -0 into +0, and the sign of a zero
+// decides between +pi and -pi in K3), so z is W B in the high lane and A in the low one; then
+//     out = z(partner) + (high ? -z : z)          (low: A + W B;  high: A - W B, since x - y == x + (-y) exactly)
+// is one DPP add per component; the sign flip is an xor with a per-lane mask.  No LDS traffic.
+template <int CTRL, int BANK>
+__device__ __forceinline__ float dpp_partner(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, 0xF, BANK, BANK == 0xF));   // full mask: bound_ctrl lets the compiler fold the move into the add
+}
+template <int HALF>
+__device__ __forceinline__ wf2_t dft_partner(wf2_t z) {
+  if constexpr (HALF == 1) return wf2_t{dpp_partner<0xB1, 0xF>(0.f, z.x), dpp_partner<0xB1, 0xF>(0.f, z.y)};        // quad_perm [1,0,3,2]
+  else if constexpr (HALF == 2) return wf2_t{dpp_partner<0x4E, 0xF>(0.f, z.x), dpp_partner<0x4E, 0xF>(0.f, z.y)};   // quad_perm [2,3,0,1]
+  else if constexpr (HALF == 8) return wf2_t{dpp_partner<0x128, 0xF>(0.f, z.x), dpp_partner<0x128, 0xF>(0.f, z.y)}; // row_ror:8
+  else return wf2_t{dpp_partner<0x141, 0xF>(0.f, z.x), dpp_partner<0x141, 0xF>(0.f, z.y)};   // row_half_mirror: physical lane ^ 7 = logical index ^ 4
+
+}
+template <int HALF, bool UNIT>
+__device__ __forceinline__ wf2_t dft_stage(wf2_t v, float ar, float ai, int sign) {
+  wf2_t z = v;
+  if constexpr (!UNIT) {                                       // (stage m = 2 has W = 1 in every lane)
+    const float tr = __builtin_fmaf(ar, v.x, -(ai * v.y)), ti = __builtin_fmaf(ar, v.y, ai * v.x);
+    z.x = sign ? tr : v.x;
+    z.y = sign ? ti : v.y;
+  }
+  const wf2_t p = dft_partner<HALF>(z);
+  const float zx = z.x, zy = z.y;                              // (scalars first: bit_cast of a vector-element lvalue reads element 0)
+  const float sx = __int_as_float(__float_as_int(zx) ^ sign), sy = __int_as_float(__float_as_int(zy) ^ sign);
+  return wf2_t{p.x + sx, p.y + sy};                        // scalar adds: v_add_f32_dpp (a packed add cannot take DPP)
+}
+
+template <int Q, int HDMAX>
+__global__ void __launch_bounds__(256) k_wbfm_fused(WParams w) {
+  __shared__ float gsh[512];                                  // resampler taps (broadcast reads)
+  for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x) gsh[i] = i < w.Tg ? w.g[i] : 0.0f;   // zero-padded: taps past Tg add +0
+  __syncthreads();
+  // logical index k of this lane within its group: DPP offers lane ^ 1, ^ 2, ^ 8 and the half-row mirror (lane ^ 7) but not
+  // lane ^ 4, so lanes are numbered such that index ^ 4 is the mirror: k = lane with bits 0..2 flipped when bit 2 is set
+  const int lane = (int)(threadIdx.x & 63), k = (lane & 11) ^ ((lane & 4) ? 7 : 0);
+  const int r = ((k & 1) << 3) | ((k & 2) << 1) | ((k & 4) >> 1) | ((k & 8) >> 3);   // bit-reversed: lane k computes branch r
+  const uint32_t grp = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;                 // global 16-lane group = one run
+  const uint32_t total_runs = w.n_streams * w.tiles_per_stream;
+  const bool active = grp < total_runs;
+  const uint32_t stream = active ? grp / w.tiles_per_stream : 0;
+  const uint32_t run = active ? grp % w.tiles_per_stream : 0;
+  // run = steps [ta, tb) of the call; tiles_per_stream runs of w.NT steps each (the last one takes the remainder)
+  const int ta = (int)(run * w.NT);
+  const int tb = (run + 1 == w.tiles_per_stream) ? (int)w.Tn : ta + (int)w.NT;
+  const int HD = (int)w.HD;
+  // taps of this lane's branch: p[r + 16 q], q = 0..Q-1, as Q/2 pairs (q even in .x)
+  wf2_t tp[Q / 2];
+#pragma unroll
+  for (int q = 0; q < Q / 2; ++q) tp[q] = wf2_t{w.p[r + 16 * (2 * q)], w.p[r + 16 * (2 * q + 1)]};
+  // DFT constants of this lane: stage m = 2,4,8,16 -> partner k ^ (m/2), twiddle W16[(k mod m/2) * 16/m]
+  // high lanes (bit m/2 of k set) apply the twiddle and the minus sign
+  const int sg1 = (k & 1) ? (int)0x80000000 : 0, sg2 = (k & 2) ? (int)0x80000000 : 0, sg4 = (k & 4) ? (int)0x80000000 : 0,
+            sg8 = (k & 8) ? (int)0x80000000 : 0;
+  const float w2r = W16_RE[(k & 1) * 4], w2i = W16_IM[(k & 1) * 4];
+  const float w4r = W16_RE[(k & 3) * 2], w4i = W16_IM[(k & 3) * 2];
+  const float w8r = W16_RE[k & 7], w8i = W16_IM[k & 7];
+
+  // one wave-uniform descriptor over the whole batch (a per-stream descriptor would differ between the 4 groups of a wave
+  // and cost a waterfall loop per load); the host only selects this kernel when the batch spans < 4 GiB
+  const unsigned long long ga = (unsigned long long)w.iq;
+  const wi4_t rsrc = {(int)(unsigned)ga, (int)(unsigned)(ga >> 32), (int)w.iq_span, SDRFM_RSRC_U8X2_USCALED};
+  const uint32_t sbase = stream * (uint32_t)w.iq_stride + 2u * (uint32_t)(15 - (int)w.phase_x - r + 16);   // byte offset of step 0's sample, +32
+  auto sample_fast = [&](int s) -> wf2_t {                     // steps whose sample lies in this call's bytes (n >= 0);
+    const wf2_t c = wbfm_typed_load_xy(rsrc, (int)(sbase + 32u * (uint32_t)s - 32u), 0, 0);   // past the batch end -> 0, unused
+    return c - wf2_t{127.5f, 127.5f};
+  };
+  auto sample = [&](int s) -> wf2_t {                          // this lane's input of step s: x[16 s + 15 - r] (call-relative)
+    const int n = (s + 1) * 16 - 1 - (int)w.phase_x - r;
+    if (n < 0) { const float2 h = wload_x(w, stream, n); return wf2_t{h.x, h.y}; }
+    return sample_fast(s);
+  };
+
+  // ---- warm-up ---------------------------------------------------------------------------------------------------
+  wf2_t win[Q];                                                // win[0] = oldest
+  wf2_t cprev;
+  float dring[HDMAX];                                          // dring[0] = oldest, dring[HD-1] = d[t-1]
+#pragma unroll
+  for (int i = 0; i < HDMAX; ++i) dring[i] = 0.0f;
+  int t0;                                                      // first step whose c is computed
+  if (ta == 0) {
+    t0 = 0;
+    const float2 cp = w.cprev_in[(size_t)stream * NB + k];
+    cprev = wf2_t{cp.x, cp.y};
+    for (int i = 0; i < HD; ++i) {
+      const float v = w.hist_d_in[((size_t)stream * NB + k) * HD + i];
+#pragma unroll
+      for (int z = 0; z < HDMAX; ++z) if (z == i + (HDMAX - HD)) dring[z] = v;    // right-aligned: newest at HDMAX-1
+    }
+  } else {
+    t0 = ta - HD - 1;                                          // c from t0 (d from t0+1): fills the d window before step ta
+    cprev = wf2_t{0.f, 0.f};
+  }
+#pragma unroll
+  for (int q = 0; q < Q - 1; ++q) win[q + 1] = sample(t0 - (Q - 1) + q);          // win[1..Q-1] = steps t0-Q+1 .. t0-1
+
+  // resampler bookkeeping (wave-uniform per group; identical in all 16 lanes): next output index and its newest-d index
+  const unsigned long long gd0 = w.n_d;                        // global d index of call-relative step 0
+  unsigned long long jn = w.n_a;                               // next audio index (global)
+  {
+    // first output whose newest d lies at or after step ta: j = ceil((gd0 + ta) * L / M) but not before n_a
+    const unsigned long long need = ((gd0 + (unsigned long long)ta) * w.L + w.M - 1) / w.M;
+    if (need > jn) jn = need;
+  }
+  long long nj_rel = (long long)((jn * w.M) / w.L) - (long long)gd0;              // call-relative step of its newest d
+  uint32_t phi = (uint32_t)((jn * w.M) % w.L);
+  const uint32_t mq = w.M / w.L, mr = w.M % w.L;
+
+  wf2_t pf[Q];                                                 // samples of the next Q steps, loaded one block ahead
+  auto one_step = [&](int s, auto QI) -> wf2_t {               // returns c_b[s] of this lane's band; QI = static window phase
+    constexpr int qi = decltype(QI)::value;                    // the new sample goes to slot qi; oldest is slot (qi+1) % Q
+    (void)s;
+    win[qi] = pf[qi];
+    wf2_t acc = {0.f, 0.f};
+#pragma unroll
+    for (int q = Q - 1; q >= 0; --q) {                         // oldest first: q = Q-1 is the oldest sample, tap p[r+16q]
+      const wf2_t x = win[(qi + Q - q) % Q];
+      if (q & 1) wpk_fma_v<1>(acc, tp[q / 2], x); else wpk_fma_v<0>(acc, tp[q / 2], x);
+    }
+    wf2_t v = dft_stage<1, true>(acc, 1.0f, 0.0f, sg1);       // stage m = 2
+    v = dft_stage<2, false>(v, w2r, w2i, sg2);                // stage m = 4: twiddle W16[(k mod 2) * 4]
+    v = dft_stage<4, false>(v, w4r, w4i, sg4);                // stage m = 8: twiddle W16[(k mod 4) * 2]
+    v = dft_stage<8, false>(v, w8r, w8i, sg8);                // stage m = 16: twiddle W16[k mod 8]
+    return v;
+  };
+
+  auto push_and_emit = [&](float d, int s) {                   // s = call-relative step of d
+#pragma unroll
+    for (int z = 0; z + 1 < HDMAX; ++z) dring[z] = dring[z + 1];
+    dring[HDMAX - 1] = d;
+    while (active && s >= ta && nj_rel == (long long)s) {      // an audio sample whose newest d is this step (uniform)
+      float gt[HDMAX];                                         // taps g[phi + L i]; indices past Tg read the zero padding, and
+#pragma unroll                                                 // 0 * d + a == a, so the chain equals the spec's i <= imax chain
+      for (int i = 0; i < HDMAX; ++i) gt[i] = gsh[phi + w.L * (uint32_t)i];
+      float a = 0.0f;
+#pragma unroll
+      for (int i = HDMAX - 1; i >= 0; --i) a = __builtin_fmaf(gt[i], dring[HDMAX - 1 - i], a);
+      w.audio[((size_t)stream * NB + k) * w.band_stride + (size_t)(jn - w.n_a)] = a;
+      ++jn;                                                    // next output: position advances by M = mq*L + mr
+      phi += mr;
+      nj_rel += mq;
+      if (phi >= w.L) { phi -= w.L; ++nj_rel; }
+    }
+  };
+
+  // ---- main loop: pairs of steps, window phase unrolled by Q ---------------------------------------------------------
+  int s = t0;
+  // window slot of step s is (s - t0) % Q when slot bookkeeping starts at 0 for step t0: win[1..Q-1] hold the Q-1 older
+  // samples in age order, so step t0 writes slot 0 and the oldest is slot 1.
+  wf2_t pn[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) pn[q] = sample(t0 + q);
+  while (s < tb) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) pf[q] = pn[q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) pn[q] = sample_fast(s + Q + q);   // in flight during this block (s + Q >= 8: n >= 0)
+    static_for_w<0, Q / 2>([&](auto PI) {
+      constexpr int pi2 = decltype(PI)::value;
+      if (s < tb) {
+        const wf2_t c0 = one_step(s, std::integral_constant<int, (2 * pi2) % Q>{});
+        const wf2_t c1 = one_step(s + 1, std::integral_constant<int, (2 * pi2 + 1) % Q>{});   // may run one step past tb: unused
+        const wf2_t d2 = wdisc_pair(c0, cprev, c1);
+        if (s > t0 || ta == 0) push_and_emit(d2.x, s);        // d[t0] of a warmed-up run has no valid predecessor
+        if (s + 1 < tb) { push_and_emit(d2.y, s + 1); cprev = c1; } else { cprev = c0; }
+        s += 2;
+      }
+    });
+  }
+  // ---- state hand-over by the last run of the stream -------------------------------------------------------------------
+  if (active && run + 1 == w.tiles_per_stream) {
+    w.cprev_out[(size_t)stream * NB + k] = make_float2(cprev.x, cprev.y);
+#pragma unroll
+    for (int z = 0; z < HDMAX; ++z)
+      if (z >= HDMAX - HD) w.hist_d_out[((size_t)stream * NB + k) * HD + (z - (HDMAX - HD))] = dring[z];
+    for (uint32_t i = (uint32_t)k; i + 1 < w.P; i += 16)
+      w.hist_x_out[(size_t)stream * (w.P - 1) + i] = wload_x(w, stream, (int)w.N - (int)(w.P - 1) + (int)i);
+  }
+}
+
+}  // namespace
+
 struct sdrfm_wbfm {
   sdrfm_wbfm_config cfg;
   int device;
@@ -207,6 +466,10 @@ struct sdrfm_wbfm {
   float* d_audio; size_t d_band_stride;
   uint32_t max_bytes, NT;
   size_t lds_bytes;
+  bool fused_ok;          // P = 128, HD <= 10: the fused kernel applies
+  uint32_t n_cu;          // compute units (fused kernel: run-length choice)
+  uint32_t force_nt;      // SDRFM_WBFM_NT: fixed run length (experiments)
+  char kernel_name[48];
 };
 
 #define WTRY(expr, code)                                                                                     \
@@ -293,6 +556,11 @@ int sdrfm_wbfm_create(const sdrfm_wbfm_config* cfg, sdrfm_wbfm_t** out) {
     wfree(h);
     return SDRFM_NOT_SUPPORTED;
   }
+  h->fused_ok = (cfg->proto_taps == 128 && h->HD <= 10 && cfg->resamp_up * 10u <= 512u && !getenv("SDRFM_WBFM_GENERIC"));
+  h->n_cu = (uint32_t)prop.multiProcessorCount;
+  h->force_nt = 0;
+  if (const char* e = getenv("SDRFM_WBFM_NT")) h->force_nt = (uint32_t)atoi(e) & ~1u;
+  snprintf(h->kernel_name, sizeof(h->kernel_name), "%s", h->fused_ok ? "wbfm-fused" : "wbfm-generic");
   const int rc = sdrfm_wbfm_reset(h);
   if (rc != SDRFM_OK) { wfree(h); return rc; }
   *out = h;
@@ -359,6 +627,37 @@ static int wenqueue(sdrfm_wbfm* h, const uint8_t* d_iq, size_t iq_stride, uint32
   w.N = N; w.Tn = Tn; w.A = A; w.phase_x = h->phase_x; w.n_d = h->n_d; w.n_a = h->n_a;
   w.res_q0 = (int)((long long)((h->n_a * c.resamp_down) / c.resamp_up) - (long long)h->n_d);
   w.res_r0 = (uint32_t)((h->n_a * c.resamp_down) % c.resamp_up);
+  const uint64_t span = (uint64_t)(c.n_streams - 1) * iq_stride + nbytes;
+  w.iq_span = (uint32_t)span;
+  if (h->fused_ok && Tn >= 64 && span < (1ull << 32)) {
+    // fused kernel: every stream is cut into runs of NT steps, one 16-lane group per run, 16 runs per 256-thread block.
+    // NT is even (steps are processed in pairs) and, when affordable, a multiple of M so that every run sees the same
+    // audio-output pattern and the 4 runs sharing a wave emit on the same steps.  Among those the host picks the length
+    // that minimises (blocks per CU, rounded up) x (steps per run incl. ~20 warm-up steps): all blocks start together
+    // when they fit (3 waves per SIMD), so a CU holding one block more than the others sets the launch time.
+    uint32_t unit = (c.resamp_down & 1) ? 2 * c.resamp_down : c.resamp_down;
+    if (unit > Tn / 4 || unit > 512) unit = 2;
+    uint64_t best = ~0ull;
+    w.NT = unit;
+    for (uint32_t nt = (64 + unit - 1) / unit * unit; nt <= Tn + unit && nt <= 8192; nt += unit) {
+      const uint64_t groups = (uint64_t)c.n_streams * ((Tn + nt - 1) / nt);
+      const uint64_t blocks = (groups + 15) / 16;
+      uint64_t rounds = (blocks + h->n_cu - 1) / h->n_cu;
+      uint64_t cost = rounds * (nt + 20) * 10;
+      if (rounds == 1) cost = cost * 14 / 10;                 // one wave per SIMD cannot keep the VALU issuing
+      if (cost < best) { best = cost; w.NT = nt; }
+    }
+    if (h->force_nt) w.NT = h->force_nt;
+    w.tiles_per_stream = (Tn + w.NT - 1) / w.NT;
+    w.n_streams = c.n_streams;
+    const uint32_t total = c.n_streams * w.tiles_per_stream;
+    hipLaunchKernelGGL((k_wbfm_fused<8, 10>), dim3((total + 15) / 16), dim3(256), 0, h->stream, w);
+    WTRY(hipGetLastError(), SDRFM_FAIL);
+    h->cur ^= 1;
+    h->phase_x = (uint32_t)((h->phase_x + (uint64_t)N) % NB);
+    h->n_d += Tn; h->n_a += A;
+    return SDRFM_OK;
+  }
   w.NT = h->NT; w.tiles_per_stream = (Tn + h->NT - 1) / h->NT; w.n_streams = c.n_streams;
   hipLaunchKernelGGL(k_wbfm_chan, dim3(c.n_streams * w.tiles_per_stream + c.n_streams), dim3(256), h->lds_bytes, h->stream, w);
   WTRY(hipGetLastError(), SDRFM_FAIL);
