@@ -343,9 +343,9 @@ __global__ void __launch_bounds__(256) k_wbfm_fused(WParams w) {
   // ---- warm-up ---------------------------------------------------------------------------------------------------
   wf2_t win[Q];                                                // win[0] = oldest
   wf2_t cprev;
-  float dring[HDMAX];                                          // dring[0] = oldest, dring[HD-1] = d[t-1]
+  float dring[HDMAX + 1];                                      // after a pair (s, s+1): dring[HDMAX] = d[s+1], dring[HDMAX-1] = d[s], ...
 #pragma unroll
-  for (int i = 0; i < HDMAX; ++i) dring[i] = 0.0f;
+  for (int i = 0; i <= HDMAX; ++i) dring[i] = 0.0f;
   int t0;                                                      // first step whose c is computed
   if (ta == 0) {
     t0 = 0;
@@ -354,26 +354,28 @@ __global__ void __launch_bounds__(256) k_wbfm_fused(WParams w) {
     for (int i = 0; i < HD; ++i) {
       const float v = w.hist_d_in[((size_t)stream * NB + k) * HD + i];
 #pragma unroll
-      for (int z = 0; z < HDMAX; ++z) if (z == i + (HDMAX - HD)) dring[z] = v;    // right-aligned: newest at HDMAX-1
+      for (int z = 0; z <= HDMAX; ++z) if (z == i + (HDMAX + 1 - HD)) dring[z] = v;   // right-aligned: d[-1] at dring[HDMAX]
     }
   } else {
-    t0 = ta - HD - 1;                                          // c from t0 (d from t0+1): fills the d window before step ta
-    cprev = wf2_t{0.f, 0.f};
+    t0 = ta - (int)((w.HD + 2) & ~1u);                         // c from t0, d from t0+1: >= HD valid d's before step ta; an even
+    cprev = wf2_t{0.f, 0.f};                                   // lead keeps every run's pairs on even steps
   }
 #pragma unroll
   for (int q = 0; q < Q - 1; ++q) win[q + 1] = sample(t0 - (Q - 1) + q);          // win[1..Q-1] = steps t0-Q+1 .. t0-1
 
-  // resampler bookkeeping (wave-uniform per group; identical in all 16 lanes): next output index and its newest-d index
+  // resampler bookkeeping (uniform per group; identical in all 16 lanes): next output and the step of its newest d
   const unsigned long long gd0 = w.n_d;                        // global d index of call-relative step 0
-  unsigned long long jn = w.n_a;                               // next audio index (global)
+  unsigned long long jn0 = w.n_a;                              // next audio index (global)
   {
     // first output whose newest d lies at or after step ta: j = ceil((gd0 + ta) * L / M) but not before n_a
     const unsigned long long need = ((gd0 + (unsigned long long)ta) * w.L + w.M - 1) / w.M;
-    if (need > jn) jn = need;
+    if (need > jn0) jn0 = need;
   }
-  long long nj_rel = (long long)((jn * w.M) / w.L) - (long long)gd0;              // call-relative step of its newest d
-  uint32_t phi = (uint32_t)((jn * w.M) % w.L);
+  int nj_rel = (int)((long long)((jn0 * w.M) / w.L) - (long long)gd0);             // call-relative step of its newest d
+  uint32_t phi = (uint32_t)((jn0 * w.M) % w.L);
+  uint32_t jrel = (uint32_t)(jn0 - w.n_a);                     // its index in this call's output
   const uint32_t mq = w.M / w.L, mr = w.M % w.L;
+  float* const aout = w.audio + ((size_t)stream * NB + k) * w.band_stride;
 
   wf2_t pf[Q];                                                 // samples of the next Q steps, loaded one block ahead
   auto one_step = [&](int s, auto QI) -> wf2_t {               // returns c_b[s] of this lane's band; QI = static window phase
@@ -393,27 +395,33 @@ __global__ void __launch_bounds__(256) k_wbfm_fused(WParams w) {
     return v;
   };
 
-  auto push_and_emit = [&](float d, int s) {                   // s = call-relative step of d
-#pragma unroll
-    for (int z = 0; z + 1 < HDMAX; ++z) dring[z] = dring[z + 1];
-    dring[HDMAX - 1] = d;
-    while (active && s >= ta && nj_rel == (long long)s) {      // an audio sample whose newest d is this step (uniform)
-      float gt[HDMAX];                                         // taps g[phi + L i]; indices past Tg read the zero padding, and
+  auto emit = [&](auto OFF) {                                  // one audio sample; OFF = 1: its newest d is the pair's first step
+    constexpr int off = decltype(OFF)::value;
+    float gt[HDMAX];                                           // taps g[phi + L i]; indices past Tg read the zero padding, and
 #pragma unroll                                                 // 0 * d + a == a, so the chain equals the spec's i <= imax chain
-      for (int i = 0; i < HDMAX; ++i) gt[i] = gsh[phi + w.L * (uint32_t)i];
-      float a = 0.0f;
+    for (int i = 0; i < HDMAX; ++i) gt[i] = gsh[phi + w.L * (uint32_t)i];
+    float a = 0.0f;
 #pragma unroll
-      for (int i = HDMAX - 1; i >= 0; --i) a = __builtin_fmaf(gt[i], dring[HDMAX - 1 - i], a);
-      w.audio[((size_t)stream * NB + k) * w.band_stride + (size_t)(jn - w.n_a)] = a;
-      ++jn;                                                    // next output: position advances by M = mq*L + mr
+    for (int i = HDMAX - 1; i >= 0; --i) a = __builtin_fmaf(gt[i], dring[HDMAX - off - i], a);
+    aout[jrel] = a;                                            // (4-byte scattered stores: leave them to merge in L2)
+  };
+  auto push_pair_and_emit = [&](wf2_t d, int s) {              // d = (d[s], d[s+1])
+#pragma unroll
+    for (int z = 0; z + 2 <= HDMAX; ++z) dring[z] = dring[z + 2];
+    dring[HDMAX - 1] = d.x;
+    dring[HDMAX] = d.y;
+    while (active && nj_rel <= s + 1 && nj_rel < tb) {         // audio samples whose newest d is one of these two steps
+      if (nj_rel == s) emit(std::integral_constant<int, 1>{}); else emit(std::integral_constant<int, 0>{});
+      ++jrel;                                                  // next output: position advances by M = mq*L + mr
       phi += mr;
-      nj_rel += mq;
+      nj_rel += (int)mq;
       if (phi >= w.L) { phi -= w.L; ++nj_rel; }
     }
   };
 
   // ---- main loop: pairs of steps, window phase unrolled by Q ---------------------------------------------------------
   int s = t0;
+  wf2_t cprev0 = cprev;                                        // c of the last pair's first step (odd tail)
   // window slot of step s is (s - t0) % Q when slot bookkeeping starts at 0 for step t0: win[1..Q-1] hold the Q-1 older
   // samples in age order, so step t0 writes slot 0 and the oldest is slot 1.
   wf2_t pn[Q];
@@ -430,18 +438,23 @@ __global__ void __launch_bounds__(256) k_wbfm_fused(WParams w) {
         const wf2_t c0 = one_step(s, std::integral_constant<int, (2 * pi2) % Q>{});
         const wf2_t c1 = one_step(s + 1, std::integral_constant<int, (2 * pi2 + 1) % Q>{});   // may run one step past tb: unused
         const wf2_t d2 = wdisc_pair(c0, cprev, c1);
-        if (s > t0 || ta == 0) push_and_emit(d2.x, s);        // d[t0] of a warmed-up run has no valid predecessor
-        if (s + 1 < tb) { push_and_emit(d2.y, s + 1); cprev = c1; } else { cprev = c0; }
+        push_pair_and_emit(d2, s);
+        cprev0 = c0; cprev = c1;
         s += 2;
       }
     });
   }
   // ---- state hand-over by the last run of the stream -------------------------------------------------------------------
   if (active && run + 1 == w.tiles_per_stream) {
+    if (s > tb) {                                              // the last pair ran one step past the end: drop that step
+      cprev = cprev0;
+#pragma unroll
+      for (int z = HDMAX; z >= 1; --z) dring[z] = dring[z - 1];
+    }
     w.cprev_out[(size_t)stream * NB + k] = make_float2(cprev.x, cprev.y);
 #pragma unroll
-    for (int z = 0; z < HDMAX; ++z)
-      if (z >= HDMAX - HD) w.hist_d_out[((size_t)stream * NB + k) * HD + (z - (HDMAX - HD))] = dring[z];
+    for (int z = 0; z <= HDMAX; ++z)
+      if (z >= HDMAX + 1 - HD) w.hist_d_out[((size_t)stream * NB + k) * HD + (z - (HDMAX + 1 - HD))] = dring[z];
     for (uint32_t i = (uint32_t)k; i + 1 < w.P; i += 16)
       w.hist_x_out[(size_t)stream * (w.P - 1) + i] = wload_x(w, stream, (int)w.N - (int)(w.P - 1) + (int)i);
   }
