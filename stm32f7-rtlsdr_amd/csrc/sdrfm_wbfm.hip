@@ -304,11 +304,13 @@ __global__ void __launch_bounds__(256) k_wbfm_fused(WParams w) {
   // lane ^ 4, so lanes are numbered such that index ^ 4 is the mirror: k = lane with bits 0..2 flipped when bit 2 is set
   const int lane = (int)(threadIdx.x & 63), k = (lane & 11) ^ ((lane & 4) ? 7 : 0);
   const int r = ((k & 1) << 3) | ((k & 2) << 1) | ((k & 4) >> 1) | ((k & 8) >> 3);   // bit-reversed: lane k computes branch r
-  const uint32_t grp = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;                 // global 16-lane group = one run
-  const uint32_t total_runs = w.n_streams * w.tiles_per_stream;
-  const bool active = grp < total_runs;
-  const uint32_t stream = active ? grp / w.tiles_per_stream : 0;
-  const uint32_t run = active ? grp % w.tiles_per_stream : 0;
+  // 16-lane group = one run of one stream.  The 4 groups of a wave take the SAME run of 4 neighbouring streams: they share
+  // ta, tb and the audio-output pattern (all streams of a handle are in phase), so a wave never diverges.
+  const uint32_t wv = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, quads = (w.n_streams + 3) / 4;
+  const uint32_t run_raw = wv / quads, stream_raw = (wv % quads) * 4 + (uint32_t)(lane >> 4);
+  const bool active = run_raw < w.tiles_per_stream && stream_raw < w.n_streams;
+  const uint32_t stream = active ? stream_raw : 0;
+  const uint32_t run = active ? run_raw : 0;
   // run = steps [ta, tb) of the call; tiles_per_stream runs of w.NT steps each (the last one takes the remainder)
   const int ta = (int)(run * w.NT);
   const int tb = (run + 1 == w.tiles_per_stream) ? (int)w.Tn : ta + (int)w.NT;
@@ -643,28 +645,26 @@ static int wenqueue(sdrfm_wbfm* h, const uint8_t* d_iq, size_t iq_stride, uint32
   const uint64_t span = (uint64_t)(c.n_streams - 1) * iq_stride + nbytes;
   w.iq_span = (uint32_t)span;
   if (h->fused_ok && Tn >= 64 && span < (1ull << 32)) {
-    // fused kernel: every stream is cut into runs of NT steps, one 16-lane group per run, 16 runs per 256-thread block.
-    // NT is even (steps are processed in pairs) and, when affordable, a multiple of M so that every run sees the same
-    // audio-output pattern and the 4 runs sharing a wave emit on the same steps.  Among those the host picks the length
-    // that minimises (blocks per CU, rounded up) x (steps per run incl. ~20 warm-up steps): all blocks start together
-    // when they fit (3 waves per SIMD), so a CU holding one block more than the others sets the launch time.
-    uint32_t unit = (c.resamp_down & 1) ? 2 * c.resamp_down : c.resamp_down;
-    if (unit > Tn / 4 || unit > 512) unit = 2;
+    // fused kernel: every stream is cut into runs of NT steps (even: steps are processed in pairs); one 16-lane group per
+    // run, the 4 groups of a wave = the same run of 4 neighbouring streams, 4 waves per block.  All blocks start together
+    // when they fit (4 waves per SIMD), so the CU holding one block more than the others sets the launch time: the host
+    // picks the NT that minimises (blocks per CU, rounded up) x (steps per run incl. ~20 warm-up steps).
+    const uint64_t quads = (c.n_streams + 3) / 4;
     uint64_t best = ~0ull;
-    w.NT = unit;
-    for (uint32_t nt = (64 + unit - 1) / unit * unit; nt <= Tn + unit && nt <= 8192; nt += unit) {
-      const uint64_t groups = (uint64_t)c.n_streams * ((Tn + nt - 1) / nt);
-      const uint64_t blocks = (groups + 15) / 16;
-      uint64_t rounds = (blocks + h->n_cu - 1) / h->n_cu;
-      uint64_t cost = rounds * (nt + 20) * 10;
+    w.NT = 64;
+    for (uint32_t nt = 64; nt <= ((Tn + 1) & ~1u) && nt <= 8192; nt += 2) {
+      const uint64_t blocks = (quads * ((Tn + nt - 1) / nt) + 3) / 4;
+      const uint64_t rounds = (blocks + h->n_cu - 1) / h->n_cu;
+      uint64_t cost = rounds * (nt + 20) * 20;
       if (rounds == 1) cost = cost * 14 / 10;                 // one wave per SIMD cannot keep the VALU issuing
+      else if (rounds == 2) cost = cost * 21 / 20;
       if (cost < best) { best = cost; w.NT = nt; }
     }
     if (h->force_nt) w.NT = h->force_nt;
     w.tiles_per_stream = (Tn + w.NT - 1) / w.NT;
     w.n_streams = c.n_streams;
-    const uint32_t total = c.n_streams * w.tiles_per_stream;
-    hipLaunchKernelGGL((k_wbfm_fused<8, 10>), dim3((total + 15) / 16), dim3(256), 0, h->stream, w);
+    const uint32_t waves = (uint32_t)quads * w.tiles_per_stream;
+    hipLaunchKernelGGL((k_wbfm_fused<8, 10>), dim3((waves + 3) / 4), dim3(256), 0, h->stream, w);
     WTRY(hipGetLastError(), SDRFM_FAIL);
     h->cur ^= 1;
     h->phase_x = (uint32_t)((h->phase_x + (uint64_t)N) % NB);
