@@ -298,6 +298,7 @@ __device__ __forceinline__ wf2_t dft_stage(wf2_t v, float ar, float ai, int sign
 template <int Q, int HDMAX>
 __global__ void __launch_bounds__(256) k_wbfm_fused(WParams w) {
   __shared__ float gsh[512];                                  // resampler taps (broadcast reads)
+  __shared__ float osh[4][16][64];                             // per wave: 16 audio samples per lane, [slot][lane], lane-private columns
   for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x) gsh[i] = i < w.Tg ? w.g[i] : 0.0f;   // zero-padded: taps past Tg add +0
   __syncthreads();
   // logical index k of this lane within its group: DPP offers lane ^ 1, ^ 2, ^ 8 and the half-row mirror (lane ^ 7) but not
@@ -306,11 +307,14 @@ __global__ void __launch_bounds__(256) k_wbfm_fused(WParams w) {
   const int r = ((k & 1) << 3) | ((k & 2) << 1) | ((k & 4) >> 1) | ((k & 8) >> 3);   // bit-reversed: lane k computes branch r
   // 16-lane group = one run of one stream.  The 4 groups of a wave take the SAME run of 4 neighbouring streams: they share
   // ta, tb and the audio-output pattern (all streams of a handle are in phase), so a wave never diverges.
-  const uint32_t wv = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, quads = (w.n_streams + 3) / 4;
-  const uint32_t run_raw = wv / quads, stream_raw = (wv % quads) * 4 + (uint32_t)(lane >> 4);
-  const bool active = run_raw < w.tiles_per_stream && stream_raw < w.n_streams;
-  const uint32_t stream = active ? stream_raw : 0;
-  const uint32_t run = active ? run_raw : 0;
+  // The wave index is made explicitly wave-uniform so that ta, tb, the step counter and all resampler bookkeeping live in
+  // SGPRs and every branch on them is a scalar branch.
+  const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+  const uint32_t quads = (w.n_streams + 3) / 4;
+  const uint32_t run = wv / quads, stream_raw = (wv % quads) * 4 + (uint32_t)(lane >> 4);
+  if (run >= w.tiles_per_stream) return;                       // (whole wave; the only barrier is behind us)
+  const bool active = stream_raw < w.n_streams;                // a partial quad computes on its first stream and stores nothing
+  const uint32_t stream = active ? stream_raw : (wv % quads) * 4;
   // run = steps [ta, tb) of the call; tiles_per_stream runs of w.NT steps each (the last one takes the remainder)
   const int ta = (int)(run * w.NT);
   const int tb = (run + 1 == w.tiles_per_stream) ? (int)w.Tn : ta + (int)w.NT;
@@ -397,6 +401,20 @@ __global__ void __launch_bounds__(256) k_wbfm_fused(WParams w) {
     return v;
   };
 
+  typedef float f4u_t __attribute__((ext_vector_type(4), aligned(4)));
+  float* const ocol = &osh[(threadIdx.x >> 6) & 3][0][lane];
+  uint32_t nbuf = 0;                                           // samples waiting in the column BEFORE the current slot (uniform)
+  auto flush = [&](uint32_t before, uint32_t last_slot, uint32_t j_last) {   // slots last_slot-before .. last_slot -> aout[.. j_last]
+    if (!active) return;
+    float* const row = aout + (j_last - last_slot);            // address of slot 0
+    if (before == 15u && last_slot == 15u) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<f4u_t*>(row + 4 * q) = f4u_t{ocol[(4 * q) * 64], ocol[(4 * q + 1) * 64], ocol[(4 * q + 2) * 64], ocol[(4 * q + 3) * 64]};
+    } else {
+      for (uint32_t i = last_slot - before; i <= last_slot; ++i) row[i] = ocol[i * 64];
+    }
+  };
   auto emit = [&](auto OFF) {                                  // one audio sample; OFF = 1: its newest d is the pair's first step
     constexpr int off = decltype(OFF)::value;
     float gt[HDMAX];                                           // taps g[phi + L i]; indices past Tg read the zero padding, and
@@ -405,14 +423,19 @@ __global__ void __launch_bounds__(256) k_wbfm_fused(WParams w) {
     float a = 0.0f;
 #pragma unroll
     for (int i = HDMAX - 1; i >= 0; --i) a = __builtin_fmaf(gt[i], dring[HDMAX - off - i], a);
-    aout[jrel] = a;                                            // (4-byte scattered stores: leave them to merge in L2)
+    // Audio leaves through a lane-private LDS column and is written 16 samples (64 bytes of one band row) at a time: as
+    // single 4-byte stores the 64 rows of each of ~3000 waves kept ~25 MB of half-filled lines open, more than the L2s
+    // hold, and rocprof showed 7.6x the algorithmic write traffic.
+    const uint32_t slot = jrel & 15u;
+    ocol[slot * 64] = a;
+    if (slot == 15u) { flush(nbuf, 15u, jrel); nbuf = 0; } else ++nbuf;
   };
   auto push_pair_and_emit = [&](wf2_t d, int s) {              // d = (d[s], d[s+1])
 #pragma unroll
     for (int z = 0; z + 2 <= HDMAX; ++z) dring[z] = dring[z + 2];
     dring[HDMAX - 1] = d.x;
     dring[HDMAX] = d.y;
-    while (active && nj_rel <= s + 1 && nj_rel < tb) {         // audio samples whose newest d is one of these two steps
+    while (nj_rel <= s + 1 && nj_rel < tb) {         // audio samples whose newest d is one of these two steps
       if (nj_rel == s) emit(std::integral_constant<int, 1>{}); else emit(std::integral_constant<int, 0>{});
       ++jrel;                                                  // next output: position advances by M = mq*L + mr
       phi += mr;
@@ -446,8 +469,9 @@ __global__ void __launch_bounds__(256) k_wbfm_fused(WParams w) {
       }
     });
   }
+  if (nbuf) flush(nbuf - 1, (jrel - 1) & 15u, jrel - 1);       // the run's last, partial group of audio samples
   // ---- state hand-over by the last run of the stream -------------------------------------------------------------------
-  if (active && run + 1 == w.tiles_per_stream) {
+  if (run + 1 == w.tiles_per_stream && active) {
     if (s > tb) {                                              // the last pair ran one step past the end: drop that step
       cprev = cprev0;
 #pragma unroll
@@ -575,7 +599,7 @@ int sdrfm_wbfm_create(const sdrfm_wbfm_config* cfg, sdrfm_wbfm_t** out) {
   h->n_cu = (uint32_t)prop.multiProcessorCount;
   h->force_nt = 0;
   if (const char* e = getenv("SDRFM_WBFM_NT")) h->force_nt = (uint32_t)atoi(e) & ~1u;
-  snprintf(h->kernel_name, sizeof(h->kernel_name), "%s", h->fused_ok ? "wbfm-fused" : "wbfm-generic");
+  snprintf(h->kernel_name, sizeof(h->kernel_name), "%s", h->fused_ok ? "wbfm-fused (k_wbfm_fused<8,10>)" : "wbfm-generic (k_wbfm_chan + k_wbfm_res)");
   const int rc = sdrfm_wbfm_reset(h);
   if (rc != SDRFM_OK) { wfree(h); return rc; }
   *out = h;
@@ -625,6 +649,8 @@ int sdrfm_wbfm_synchronize(sdrfm_wbfm_t* h) {
   WTRY(hipStreamSynchronize(h->stream), SDRFM_FAIL);
   return SDRFM_OK;
 }
+
+const char* sdrfm_wbfm_kernel_name(const sdrfm_wbfm_t* h) { return h ? h->kernel_name : ""; }
 
 static int wenqueue(sdrfm_wbfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nbytes, float* d_audio, size_t band_stride) {
   const sdrfm_wbfm_config& c = h->cfg;

@@ -17,7 +17,7 @@ ABI_SYMBOLS = [
     "sdrfm_set_stream", "sdrfm_synchronize", "sdrfm_kernel_name", "sdrfm_abi_version", "sdrfm_strerror",
     "sdrfm_host_atan2f", "sdrfm_host_discriminate", "sdrfm_debug_phase_cycles", "sdrfm_debug_discriminate", "sdrfm_debug_raw",
     "sdrfm_wbfm_create", "sdrfm_wbfm_destroy", "sdrfm_wbfm_reset", "sdrfm_wbfm_audio_count", "sdrfm_wbfm_process_batch",
-    "sdrfm_wbfm_set_stream", "sdrfm_wbfm_synchronize", "sdrfm_rtl_pack_fir", "sdrfm_rtl_resampler",
+    "sdrfm_wbfm_set_stream", "sdrfm_wbfm_synchronize", "sdrfm_wbfm_kernel_name", "sdrfm_rtl_pack_fir", "sdrfm_rtl_resampler",
     "sdrfm_pcm_deemph_s16", "sdrfm_pcm_alpha",
     "sdrfm_ring_create", "sdrfm_ring_destroy", "sdrfm_ring_submit", "sdrfm_ring_collect",
 ]
@@ -118,6 +118,8 @@ def load_library():
     lib.sdrfm_wbfm_set_stream.restype = C.c_int
     lib.sdrfm_wbfm_synchronize.argtypes = [vp]
     lib.sdrfm_wbfm_synchronize.restype = C.c_int
+    lib.sdrfm_wbfm_kernel_name.argtypes = [vp]
+    lib.sdrfm_wbfm_kernel_name.restype = C.c_char_p
     lib.sdrfm_rtl_pack_fir.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_uint8)]
     lib.sdrfm_rtl_pack_fir.restype = C.c_int
     lib.sdrfm_rtl_resampler.argtypes = [u32, u32, u32p, u32p, C.POINTER(C.c_double)]

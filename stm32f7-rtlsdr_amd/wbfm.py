@@ -65,6 +65,10 @@ class WbfmDemod:
     def set_stream(self, ptr):
         self._ck(self._lib.sdrfm_wbfm_set_stream(self._h, C.c_void_p(int(ptr) if ptr else None)), "sdrfm_wbfm_set_stream")
 
+    @property
+    def kernel_name(self):
+        return self._lib.sdrfm_wbfm_kernel_name(self._h).decode()
+
     def synchronize(self):
         self._ck(self._lib.sdrfm_wbfm_synchronize(self._h), "sdrfm_wbfm_synchronize")
 

@@ -96,3 +96,51 @@ def test_device_buffers_and_errors(pkg, oracle_mod):
         dm.process_batch(np.zeros((4, 70000), np.uint8))
     assert e.value.status == 18
     dm.close()
+
+
+def _run(pkg, iq, n_streams, monkeypatch, env):
+    p, g = _taps(pkg)
+    for k in ("SDRFM_WBFM_GENERIC", "SDRFM_WBFM_NT"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    dm = pkg.WbfmDemod(pkg.WbfmConfig(proto_coeffs=p, resamp_coeffs=g, n_streams=n_streams))
+    name = dm.kernel_name
+    out = dm.process_batch(iq)
+    dm.close()
+    return name, out
+
+
+@pytest.mark.parametrize("n_streams,nsamp", [(1, 100000), (5, 40007), (8, 25601)])
+def test_fused_kernel_bitwise_equals_generic_kernels(pkg, monkeypatch, n_streams, nsamp):
+    """The fused kernel (lanes = branches, DFT across lanes) and the two-kernel generic path evaluate the same frozen
+    chains: identical bits, for stream counts that do and do not fill a wave's 4 groups and an odd number of steps."""
+    iq = pkg.make_iq(n_streams, nsamp, mode="fm", fs=3.2e6, first_id=70)
+    nf, fused = _run(pkg, iq, n_streams, monkeypatch, {})
+    ng, generic = _run(pkg, iq, n_streams, monkeypatch, {"SDRFM_WBFM_GENERIC": "1"})
+    assert nf.startswith("wbfm-fused") and ng.startswith("wbfm-generic")
+    assert np.array_equal(fused.view(np.uint32), generic.view(np.uint32))
+
+
+def test_fused_kernel_output_independent_of_run_length(pkg, monkeypatch):
+    iq = pkg.make_iq(4, 64000, mode="random", fs=3.2e6, first_id=80)
+    ref = None
+    for nt in ("64", "66", "130", "1000", "8000"):
+        _, out = _run(pkg, iq, 4, monkeypatch, {"SDRFM_WBFM_NT": nt})
+        if ref is None:
+            ref = out
+        assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), nt
+
+
+def test_degenerate_inputs_match_oracle_exactly_in_sign(pkg, oracle_mod, monkeypatch):
+    """Constant and silent inputs drive band outputs to exact zeros, where the sign of a zero picks +pi or -pi in K3:
+    both GPU paths must land on the oracle's side."""
+    p, g = _taps(pkg)
+    n = 20000
+    rows = [np.full(2 * n, 128, np.uint8), np.tile(np.array([255, 0], np.uint8), n), np.tile(np.array([127, 128, 128, 127], np.uint8), n // 2)]
+    iq = np.stack(rows)
+    for env in ({}, {"SDRFM_WBFM_GENERIC": "1"}):
+        _, got = _run(pkg, iq, 3, monkeypatch, env)
+        for s in range(3):
+            want = oracle_mod.WbfmOracle(p, g).process(iq[s])
+            assert scaled_err(got[s], want) <= TOL, (env, s)
