@@ -193,11 +193,20 @@ const char* sdrfm_wbfm_kernel_name(const sdrfm_wbfm_t* h);
  *   sdrfm_rtl_pack_fir  : RTLSDR_set_fir, state RTLSDR_FIR_CALC (Class/RTLSDR/Src/usbh_rtlsdr.c:552-575): RTLSDR_FIR[16]
  *                         (8 x int8 then 8 x int12) -> 20 bytes for demod page 1 regs 0x1c..0x2f.
  *   sdrfm_rtl_resampler : RTLSDR_set_sample_rate state 0 (usbh_rtlsdr.c:676-691); xtal_hz = 28 800 000 for the stock dongle.
- * Both return SDRFM_EINVAL where the firmware would only log.
+ *   sdrfm_e4k_pll_params: E4K_compute_pll_params (Class/RTLSDR/Src/tuner_e4k.c:689-737, band table :301-312): the E4000
+ *                         synthesiser word for a wanted LO — band divider R and its SYNTH7 code, integer part Z, 16-bit
+ *                         fraction X (Y = 65536) and the LO actually obtained, floor(fosc*(Z + X/Y) / R) in integers.
+ * All return SDRFM_EINVAL where the firmware would only log (or, for the PLL, return 0).
  * ------------------------------------------------------------------------------------------------------------------ */
 int sdrfm_rtl_pack_fir(const int* fir16, uint8_t* out20);
 int sdrfm_rtl_resampler(uint32_t samp_rate, uint32_t xtal_hz, uint32_t* rsamp_ratio, uint32_t* real_rsamp_ratio,
                         double* real_rate);
+typedef struct sdrfm_e4k_pll {   /* mirrors struct e4k_pll_params (Class/RTLSDR/Inc/tuner_e4k.h:227-236) */
+  uint32_t fosc, intended_flo, flo;
+  uint16_t x;
+  uint8_t z, r, r_idx, threephase;
+} sdrfm_e4k_pll;
+int sdrfm_e4k_pll_params(uint32_t fosc_hz, uint32_t intended_flo_hz, sdrfm_e4k_pll* out);
 
 /* Audio sink format of the reference board (host-side, plain C): de-emphasis y += alpha*(x - y) carried in *state, then
  * int16 stereo-interleaved PCM (L = R) as BSP_AUDIO_OUT_Play(uint16_t*, Size) takes it

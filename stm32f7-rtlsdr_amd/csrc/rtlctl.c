@@ -8,6 +8,7 @@
  *                             page 1, registers 0x1c..0x2f (Class/RTLSDR/Src/usbh_rtlsdr.c:552-575)
  *   sdrfm_rtl_resampler     : RTLSDR_set_sample_rate state 0 — rsamp_ratio, the sign-extended "real" ratio and the exact
  *                             rate (usbh_rtlsdr.c:676-691).  Unlike the firmware, which only logs, invalid input is refused.
+ *   sdrfm_e4k_pll_params    : E4K_compute_pll_params (Class/RTLSDR/Src/tuner_e4k.c:689-737) — the E4000 LO synthesiser word
  */
 #include <stdint.h>
 
@@ -41,5 +42,34 @@ int sdrfm_rtl_resampler(uint32_t samp_rate, uint32_t xtal_hz, uint32_t* rsamp_ra
   *rsamp_ratio = ratio;
   *real_rsamp_ratio = real;
   *real_rate = num / (double)real;
+  return SDRFM_OK;
+}
+
+/* E4000 LO bands: below `below_hz` the VCO runs at R x LO; `synth7` is the register code of that divider (bit 3 = 3-phase
+ * mixing).  Values are the chip's (tuner_e4k.c:301-312); above the last band the firmware keeps R = 2, code 0. */
+static const struct { uint32_t below_hz; uint8_t synth7, r; } e4k_bands[] = {
+  {72400000u, 0x0f, 48}, {81200000u, 0x0e, 40}, {108300000u, 0x0d, 32}, {162500000u, 0x0c, 24}, {216600000u, 0x0b, 16},
+  {325000000u, 0x0a, 12}, {350000000u, 0x09, 8}, {432000000u, 0x03, 8}, {667000000u, 0x02, 6}, {1200000000u, 0x01, 4},
+};
+
+int sdrfm_e4k_pll_params(uint32_t fosc_hz, uint32_t intended_flo_hz, sdrfm_e4k_pll* out) {
+  if (!out || fosc_hz < 16000000u || fosc_hz > 30000000u) return SDRFM_EINVAL;   /* is_fosc_valid, tuner_e4k.c:325-333 */
+  uint8_t r = 2, code = 0;
+  for (unsigned i = 0; i < sizeof(e4k_bands) / sizeof(e4k_bands[0]); ++i)
+    if (intended_flo_hz < e4k_bands[i].below_hz) { r = e4k_bands[i].r; code = e4k_bands[i].synth7; break; }
+  const uint64_t fvco = (uint64_t)intended_flo_hz * r;        /* wanted VCO frequency */
+  const uint64_t z = fvco / fosc_hz;                           /* integer multiplier */
+  const uint64_t x = ((fvco - z * fosc_hz) << 16) / fosc_hz;   /* fraction in 1/65536 */
+  /* what the chip then produces: fosc*Z + floor(fosc*X / 65536), divided by R (compute_fvco / compute_flo, :340-360) —
+   * Z and X enter truncated to their register widths, as in the firmware's call */
+  const uint64_t got = (uint64_t)fosc_hz * (uint8_t)z + (((uint64_t)fosc_hz * (uint16_t)x) >> 16);
+  out->fosc = fosc_hz;
+  out->intended_flo = intended_flo_hz;
+  out->flo = (uint32_t)(got / r);
+  out->x = (uint16_t)x;
+  out->z = (uint8_t)z;
+  out->r = r;
+  out->r_idx = code;
+  out->threephase = (code & 0x08) ? 1 : 0;
   return SDRFM_OK;
 }

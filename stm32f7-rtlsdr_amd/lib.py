@@ -17,7 +17,7 @@ ABI_SYMBOLS = [
     "sdrfm_set_stream", "sdrfm_synchronize", "sdrfm_kernel_name", "sdrfm_abi_version", "sdrfm_strerror",
     "sdrfm_host_atan2f", "sdrfm_host_discriminate", "sdrfm_debug_phase_cycles", "sdrfm_debug_discriminate", "sdrfm_debug_raw",
     "sdrfm_wbfm_create", "sdrfm_wbfm_destroy", "sdrfm_wbfm_reset", "sdrfm_wbfm_audio_count", "sdrfm_wbfm_process_batch",
-    "sdrfm_wbfm_set_stream", "sdrfm_wbfm_synchronize", "sdrfm_wbfm_kernel_name", "sdrfm_rtl_pack_fir", "sdrfm_rtl_resampler",
+    "sdrfm_wbfm_set_stream", "sdrfm_wbfm_synchronize", "sdrfm_wbfm_kernel_name", "sdrfm_rtl_pack_fir", "sdrfm_rtl_resampler", "sdrfm_e4k_pll_params",
     "sdrfm_pcm_deemph_s16", "sdrfm_pcm_alpha",
     "sdrfm_ring_create", "sdrfm_ring_destroy", "sdrfm_ring_submit", "sdrfm_ring_collect",
 ]
@@ -124,6 +124,8 @@ def load_library():
     lib.sdrfm_rtl_pack_fir.restype = C.c_int
     lib.sdrfm_rtl_resampler.argtypes = [u32, u32, u32p, u32p, C.POINTER(C.c_double)]
     lib.sdrfm_rtl_resampler.restype = C.c_int
+    lib.sdrfm_e4k_pll_params.argtypes = [u32, u32, vp]
+    lib.sdrfm_e4k_pll_params.restype = C.c_int
     lib.sdrfm_pcm_deemph_s16.argtypes = [vp, u32, C.c_float, C.c_float, C.POINTER(C.c_float), vp]
     lib.sdrfm_pcm_deemph_s16.restype = C.c_int
     lib.sdrfm_pcm_alpha.argtypes = [C.c_float, C.c_float]

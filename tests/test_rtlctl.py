@@ -36,3 +36,36 @@ def test_resampler_validity_window(pkg):
         assert lib.sdrfm_rtl_resampler(bad, 28800000, C.byref(r), C.byref(rr), C.byref(f)) == 16
     for ok in (225001, 300000, 900001, 3200000):
         assert lib.sdrfm_rtl_resampler(ok, 28800000, C.byref(r), C.byref(rr), C.byref(f)) == 0
+
+
+class _E4kPll(C.Structure):
+    _fields_ = [("fosc", C.c_uint32), ("intended_flo", C.c_uint32), ("flo", C.c_uint32), ("x", C.c_uint16),
+                ("z", C.c_uint8), ("r", C.c_uint8), ("r_idx", C.c_uint8), ("threephase", C.c_uint8)]
+
+
+@pytest.mark.parametrize("want_hz,flo,z,x,r,r_idx,three", [
+    (99700000, 99699993, 110, 50972, 32, 13, 1),          # E4K_compute_pll_params(fosc = 28.8 MHz) run here
+    (433920000, 433919970, 90, 26214, 6, 2, 0),
+    (1090000000, 1089999975, 151, 25486, 4, 1, 0),
+])
+def test_e4k_pll_known_answers(pkg, want_hz, flo, z, x, r, r_idx, three):
+    lib = pkg.load_library()
+    p = _E4kPll()
+    assert lib.sdrfm_e4k_pll_params(28800000, want_hz, C.byref(p)) == 0
+    assert (p.flo, p.z, p.x, p.r, p.r_idx, p.threephase) == (flo, z, x, r, r_idx, three)
+    assert p.fosc == 28800000 and p.intended_flo == want_hz
+    assert 0 <= want_hz - p.flo < 28800000 / 65536 / r + 1   # the fraction has 1/65536 resolution, truncated
+
+
+def test_e4k_pll_bands_and_errors(pkg):
+    lib = pkg.load_library()
+    p = _E4kPll()
+    for hz, r in ((60000000, 48), (72399999, 48), (72400000, 40), (200000000, 16), (349999999, 8), (350000000, 8),
+                  (500000000, 6), (1199999999, 4), (1200000000, 2), (1700000000, 2)):
+        assert lib.sdrfm_e4k_pll_params(28800000, hz, C.byref(p)) == 0
+        assert p.r == r, hz
+        assert p.threephase == (1 if hz < 350000000 else 0)
+        assert abs(p.flo - hz) <= 500
+    assert lib.sdrfm_e4k_pll_params(15999999, 100000000, C.byref(p)) == 16
+    assert lib.sdrfm_e4k_pll_params(30000001, 100000000, C.byref(p)) == 16
+    assert lib.sdrfm_e4k_pll_params(28800000, 100000000, None) == 16
