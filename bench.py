@@ -35,8 +35,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--check", action="store_true", help="also verify a few streams against the oracle (not timed)")
-    ap.add_argument("--workload", choices=["fm", "wbfm"], default="fm",
-                    help="fm = BASELINE configs[2] (default, the headline); wbfm = configs[4] channelizer path, 128 streams/GPU")
+    ap.add_argument("--workload", choices=["fm", "wbfm", "spectrum"], default="fm",
+                    help="fm = BASELINE configs[2] (default, the headline); wbfm = configs[4] channelizer path, 128 streams/GPU; "
+                         "spectrum = FFT view (SURVEY 8f-3) of the configs[2] buffers")
+    ap.add_argument("--nfft", type=int, default=1024, help="spectrum workload: FFT length")
     return ap.parse_args()
 
 
@@ -113,6 +115,8 @@ def main():
     pkg = importlib.import_module("stm32f7-rtlsdr_amd")
     if args.workload == "wbfm":
         return main_wbfm(args, pkg, world, rank, local_rank)
+    if args.workload == "spectrum":
+        return main_spectrum(args, pkg, world, rank, local_rank)
     fs = 2.4e6
     ns = args.streams_per_gpu
     nsamp = int(round(args.seconds * fs))
@@ -276,6 +280,65 @@ def main_wbfm(args, pkg, world, rank, local_rank):
         print(json.dumps(res), flush=True)
     dm.set_stream(None)
     dm.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main_spectrum(args, pkg, world, rank, local_rank):
+    """FFT view of the BASELINE configs[2] buffers: 256 x 0.1 s of 2.4 MS/s IQ per GPU -> averaged power spectra."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    fs, ns, nfft = 2.4e6, args.streams_per_gpu, args.nfft
+    nsamp = int(round(args.seconds * fs))
+    iq_host = pkg.make_iq(ns, nsamp, mode="fm", fs=fs, first_id=rank * ns)
+    sv = pkg.SpectrumView(pkg.SpectrumConfig(nfft=nfft, n_streams=ns, device=local_rank, max_bytes_per_call=2 * nsamp))
+    stream = torch.cuda.Stream()
+    sv.set_stream(stream.cuda_stream)
+    with torch.cuda.stream(stream):
+        iq = torch.from_numpy(iq_host).cuda()
+        power = torch.zeros((ns, nfft), dtype=torch.float32, device="cuda")
+    stream.synchronize()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        sv.process_batch_device(iq, power)
+    fence()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    frames = 0
+    for a, b in evs:
+        a.record(stream)
+        frames = sv.process_batch_device(iq, power)
+        b.record(stream)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    if rank == 0:
+        alg = ns * frames * nfft * 2.0 + ns * nfft * 4.0
+        res = {"metric": "IQ MSamples/s through the windowed-FFT spectrum view", "value": round(world * ns * frames * nfft * args.steps / elapsed / 1e6, 1),
+               "unit": "MSamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "spectrum view (SURVEY 8f-3) of BASELINE configs[2] buffers: %d x 2.4 MS/s uint8 IQ streams per GPU x %.1f s, "
+                                      "%d-point Hann FFT, %d frames averaged per stream" % (ns, args.seconds, nfft, frames),
+                          "streams_per_gpu": ns, "bytes_per_stream": 2 * nsamp, "kernel": "k_spectrum<%d>" % int(np.log2(nfft))},
+               "roofline": {"bound": "hbm", "achieved": round(alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                            "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None, "kernel_ms_avg": round(ms, 4),
+                            "algorithmic_bytes_per_launch": alg}}
+        print(json.dumps(res), flush=True)
+    sv.set_stream(None)
+    sv.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

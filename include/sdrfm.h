@@ -188,6 +188,33 @@ int  sdrfm_wbfm_synchronize(sdrfm_wbfm_t* h);
 const char* sdrfm_wbfm_kernel_name(const sdrfm_wbfm_t* h);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Spectrum view of the IQ buffer — the reference's own next task ("Perform some FFT on the samples to check what we are
+ * receiving", README.md:29) on the same buffer contract (RTLSDR_CommItfTypedef.buff, usbh_rtlsdr.h:165-173): per stream
+ * the windowed nfft-point power spectrum averaged over the consecutive, non-overlapping frames of the buffer, DC in the
+ * middle: power[stream * power_stride + i], i = 0..nfft-1, bin i = frequency (i - nfft/2) * fs/nfft.  Stateless: each
+ * call views the buffer it is given; a tail shorter than nfft is ignored (*n_frames = 0 -> all zeros).
+ * Arithmetic (one fixed radix-2 DIT graph, fp32): DESIGN.md §4.6.  window = NULL selects a periodic Hann window.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct sdrfm_spectrum_config {
+  uint32_t struct_size;           /* = sizeof(sdrfm_spectrum_config) */
+  uint32_t n_streams;
+  uint32_t nfft;                  /* power of two, 64 .. 4096 */
+  const float* window;            /* nfft floats or NULL */
+  uint32_t max_bytes_per_call;    /* per stream; 0 = 1 MiB */
+  int32_t  device;
+  uint32_t flags;                 /* must be 0 */
+} sdrfm_spectrum_config;
+
+typedef struct sdrfm_spectrum sdrfm_spectrum_t;
+
+int  sdrfm_spectrum_create(const sdrfm_spectrum_config* cfg, sdrfm_spectrum_t** out);
+void sdrfm_spectrum_destroy(sdrfm_spectrum_t* h);
+int  sdrfm_spectrum_process_batch(sdrfm_spectrum_t* h, const uint8_t* iq, size_t iq_stride, uint32_t nbytes_per_stream,
+                                  float* power, size_t power_stride, uint32_t* n_frames, uint32_t flags);
+int  sdrfm_spectrum_set_stream(sdrfm_spectrum_t* h, void* hip_stream);
+int  sdrfm_spectrum_synchronize(sdrfm_spectrum_t* h);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Host-only helpers (no GPU): the two pure computations the reference performs when it programs the RTL2832 for this
  * stream, so that a non-MCU front end configures a dongle identically.
  *   sdrfm_rtl_pack_fir  : RTLSDR_set_fir, state RTLSDR_FIR_CALC (Class/RTLSDR/Src/usbh_rtlsdr.c:552-575): RTLSDR_FIR[16]

@@ -144,3 +144,55 @@ class WbfmOracle:
         if n < 0:
             raise ValueError("sdrfm_wbfm_oracle_process rejected its arguments")
         return out[:, :n].copy()
+
+
+_slib = None
+
+
+def _sload():
+    global _slib
+    if _slib is None:
+        path = os.path.join(_HERE, "libsdrfm_spectrum_oracle.so")
+        if not os.path.exists(path):
+            raise ImportError("%s missing: run `make -C oracle`" % path)
+        lib = C.CDLL(path)
+        vp = C.c_void_p
+        lib.sdrfm_spectrum_oracle_create.argtypes = [C.c_uint32, vp]
+        lib.sdrfm_spectrum_oracle_create.restype = vp
+        lib.sdrfm_spectrum_oracle_destroy.argtypes = [vp]
+        lib.sdrfm_spectrum_oracle_destroy.restype = None
+        lib.sdrfm_spectrum_oracle_process.argtypes = [vp, vp, C.c_uint64, vp]
+        lib.sdrfm_spectrum_oracle_process.restype = C.c_long
+        _slib = lib
+    return _slib
+
+
+class SpectrumOracle:
+    """Averaged windowed power spectrum of one IQ buffer (oracle/sdrfm_spectrum_oracle.c); window=None -> periodic Hann."""
+
+    def __init__(self, nfft=1024, window=None):
+        self._lib = _sload()
+        self.nfft = int(nfft)
+        self.window = None if window is None else np.ascontiguousarray(window, dtype=np.float32)
+        if self.window is not None and self.window.size != self.nfft:
+            raise ValueError("window length != nfft")
+        self._o = self._lib.sdrfm_spectrum_oracle_create(self.nfft, None if self.window is None else self.window.ctypes.data)
+        if not self._o:
+            raise ValueError("sdrfm_spectrum_oracle_create failed (nfft must be a power of two)")
+
+    def close(self):
+        if self._o:
+            self._lib.sdrfm_spectrum_oracle_destroy(self._o)
+            self._o = None
+
+    def __del__(self):
+        self.close()
+
+    def process(self, iq):
+        """-> (power[nfft] float32, DC in the middle; number of frames)"""
+        iq = np.ascontiguousarray(iq, dtype=np.uint8).reshape(-1)
+        out = np.zeros(self.nfft, dtype=np.float32)
+        n = self._lib.sdrfm_spectrum_oracle_process(self._o, iq.ctypes.data, iq.size, out.ctypes.data)
+        if n < 0:
+            raise ValueError("sdrfm_spectrum_oracle_process rejected its arguments")
+        return out, int(n)

@@ -1,0 +1,275 @@
+// sdrfm_spectrum.hip — spectrum view of the IQ buffer (reference README.md:29), gfx950 only.
+//
+// Spec (build-defined, oracle/sdrfm_spectrum_oracle.c): frames of N samples, x = ((I-127.5)*w[n], (Q-127.5)*w[n]), one fixed
+// radix-2 DIT graph (bit-reversed input; T = W*B with T.re = fmaf(W.re,B.re,-(W.im*B.im)), T.im = fmaf(W.re,B.im,W.im*B.re);
+// lo = A+T, hi = A-T), P = fmaf(re,re,im*im), S += P in frame order, out = fftshift(S) * (1/F).  Every operation is the
+// oracle's, in an order the graph allows, so the result is bit-identical.
+//
+// Kernel: one 256-thread workgroup per stream walks the stream's frames in order (the spec's sum over frames is
+// sequential) with the running sums in registers.  A frame lives in LDS as float2[N]; samples arrive through typed
+// buffer loads (u8 pair -> 2 floats in the texture unit), one frame ahead of the FFT; the DIT stages are applied two at a
+// time (a thread takes the 4 points that two consecutive stages couple, so each pass reads and writes a point once).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/sdrfm.h"
+
+typedef float sf2_t __attribute__((ext_vector_type(2)));
+typedef int si4_t __attribute__((ext_vector_type(4)));
+__device__ sf2_t spec_typed_load_xy(si4_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.format.v2f32");
+// buffer resource word3: dst_sel = (R, G, 0, 1), num_format = USCALED (2), data_format = 8_8 (3)
+#define SDRFM_SPEC_RSRC_U8X2 (4 | (5 << 3) | (0 << 6) | (1 << 9) | (2 << 12) | (3 << 15))
+
+namespace {
+
+struct SParams {
+  const uint8_t* iq;
+  size_t iq_stride;
+  uint32_t iq_span;       // bytes from iq to the end of the last stream's frames (descriptor range)
+  float* power;
+  size_t power_stride;
+  const float2* tw;       // N/2 twiddles
+  const float* win;       // N window values
+  uint32_t F;             // frames per stream
+  float inv_frames;       // 1.0f / F
+};
+
+__device__ __forceinline__ void butterfly(float2& a, float2& b, float2 w) {   // (A, B) -> (A + W B, A - W B)
+  const float tr = __builtin_fmaf(w.x, b.x, -(w.y * b.y));
+  const float ti = __builtin_fmaf(w.x, b.y, w.y * b.x);
+  const float2 A = a;
+  a = make_float2(A.x + tr, A.y + ti);
+  b = make_float2(A.x - tr, A.y - ti);
+}
+
+template <int LOGN>
+__global__ void __launch_bounds__(256) k_spectrum(SParams p) {
+  constexpr int N = 1 << LOGN, PPT = (N + 255) / 256;          // points per thread
+  __shared__ float2 X[N];
+  __shared__ float2 TW[N / 2];
+  const int t = (int)threadIdx.x;
+  const uint32_t stream = blockIdx.x;
+  for (int i = t; i < N / 2; i += 256) TW[i] = p.tw[i];
+  float wv[PPT], S[PPT];
+#pragma unroll
+  for (int q = 0; q < PPT; ++q) {
+    const int n = t + 256 * q;
+    wv[q] = n < N ? p.win[n] : 0.0f;
+    S[q] = 0.0f;
+  }
+  const unsigned long long ga = (unsigned long long)p.iq;
+  const si4_t rsrc = {(int)(unsigned)ga, (int)(unsigned)(ga >> 32), (int)p.iq_span, SDRFM_SPEC_RSRC_U8X2};
+  const uint32_t sbase = stream * (uint32_t)p.iq_stride;
+  sf2_t cur[PPT];
+#pragma unroll
+  for (int q = 0; q < PPT; ++q) cur[q] = spec_typed_load_xy(rsrc, (int)(sbase + 2u * (uint32_t)(t + 256 * q)), 0, 0);
+  __syncthreads();                                             // TW visible
+  for (uint32_t f = 0; f < p.F; ++f) {
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+      const int n = t + 256 * q;
+      if (n < N) {
+        const uint32_t u = __brev((uint32_t)n) >> (32 - LOGN);
+        X[u] = make_float2((cur[q].x - 127.5f) * wv[q], (cur[q].y - 127.5f) * wv[q]);
+      }
+    }
+    if (f + 1 < p.F) {                                         // next frame's bytes: in flight during this frame's FFT
+#pragma unroll
+      for (int q = 0; q < PPT; ++q)
+        cur[q] = spec_typed_load_xy(rsrc, (int)(sbase + 2u * ((f + 1) * (uint32_t)N + (uint32_t)(t + 256 * q))), 0, 0);
+    }
+    __syncthreads();
+    // stages s and s+1 together: group g of 4 points {i, i+h, i+2h, i+3h} (h = 2^(s-1)) is closed under both stages
+    int s = 1;
+    for (; s + 1 <= LOGN; s += 2) {
+      const int h = 1 << (s - 1);
+      for (int g = t; g < N / 4; g += 256) {
+        const int pos = g & (h - 1), i = ((g >> (s - 1)) << (s + 1)) + pos;
+        float2 a = X[i], b = X[i + h], c = X[i + 2 * h], d = X[i + 3 * h];
+        const float2 w1 = TW[pos << (LOGN - s)];                       // stage s: pairs (a,b), (c,d), same pos
+        butterfly(a, b, w1);
+        butterfly(c, d, w1);
+        butterfly(a, c, TW[pos << (LOGN - s - 1)]);                    // stage s+1 (half = 2h): position pos
+        butterfly(b, d, TW[(pos + h) << (LOGN - s - 1)]);              //                        position pos + h
+        X[i] = a; X[i + h] = b; X[i + 2 * h] = c; X[i + 3 * h] = d;
+      }
+      __syncthreads();
+    }
+    if (s <= LOGN) {                                           // odd LOGN: one last single stage
+      const int h = 1 << (s - 1);
+      for (int j = t; j < N / 2; j += 256) {
+        const int pos = j & (h - 1), i = ((j >> (s - 1)) << s) + pos;
+        float2 a = X[i], b = X[i + h];
+        butterfly(a, b, TW[pos << (LOGN - s)]);
+        X[i] = a; X[i + h] = b;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+      const int k = t + 256 * q;
+      if (k < N) { const float2 v = X[k]; S[q] = S[q] + __builtin_fmaf(v.x, v.x, v.y * v.y); }
+    }
+    __syncthreads();                                           // X is rewritten by the next frame
+  }
+#pragma unroll
+  for (int q = 0; q < PPT; ++q) {
+    const int k = t + 256 * q;
+    if (k < N) p.power[(size_t)stream * p.power_stride + (size_t)((k + N / 2) & (N - 1))] = S[q] * p.inv_frames;
+  }
+}
+
+typedef void (*spec_kernel_t)(SParams);
+spec_kernel_t pick_kernel(uint32_t logn) {
+  switch (logn) {
+    case 6: return k_spectrum<6>;
+    case 7: return k_spectrum<7>;
+    case 8: return k_spectrum<8>;
+    case 9: return k_spectrum<9>;
+    case 10: return k_spectrum<10>;
+    case 11: return k_spectrum<11>;
+    case 12: return k_spectrum<12>;
+    default: return nullptr;
+  }
+}
+
+}  // namespace
+
+struct sdrfm_spectrum {
+  sdrfm_spectrum_config cfg;
+  int device;
+  uint32_t logn, max_bytes;
+  hipStream_t own_stream, stream;
+  float2* d_tw;
+  float* d_win;
+  uint8_t* d_iq; size_t d_iq_stride;
+  float* d_power;
+  spec_kernel_t kernel;
+};
+
+#define STRY(expr, code)                                                                                     \
+  do {                                                                                                       \
+    hipError_t e__ = (expr);                                                                                 \
+    if (e__ != hipSuccess) {                                                                                 \
+      fprintf(stderr, "[sdrfm_spectrum] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+      return (code);                                                                                         \
+    }                                                                                                        \
+  } while (0)
+
+static void sfree(sdrfm_spectrum* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  void* ptrs[] = {h->d_tw, h->d_win, h->d_iq, h->d_power};
+  for (void* q : ptrs) if (q) (void)hipFree(q);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+}
+
+extern "C" {
+
+int sdrfm_spectrum_create(const sdrfm_spectrum_config* cfg, sdrfm_spectrum_t** out) {
+  if (!out) return SDRFM_EINVAL;
+  *out = nullptr;
+  if (!cfg || cfg->struct_size != sizeof(sdrfm_spectrum_config) || cfg->flags || !cfg->n_streams) return SDRFM_EINVAL;
+  uint32_t logn = 0;
+  while ((1u << logn) < cfg->nfft) ++logn;
+  if ((1u << logn) != cfg->nfft || logn < 6 || logn > 12) return SDRFM_EINVAL;
+  if (cfg->window) for (uint32_t n = 0; n < cfg->nfft; ++n) if (!std::isfinite(cfg->window[n])) return SDRFM_EINVAL;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) return SDRFM_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0) return SDRFM_NO_DEVICE;
+  sdrfm_spectrum* h = new sdrfm_spectrum();
+  memset(h, 0, sizeof(*h));
+  h->cfg = *cfg; h->cfg.window = nullptr;
+  h->device = cfg->device; h->logn = logn;
+  h->max_bytes = cfg->max_bytes_per_call ? cfg->max_bytes_per_call : (1u << 20);
+  h->kernel = pick_kernel(logn);
+#define CR(expr) do { if ((expr) != hipSuccess) { sfree(h); return SDRFM_ENOMEM; } } while (0)
+  CR(hipSetDevice(h->device));
+  CR(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+  h->stream = h->own_stream;
+  const uint32_t N = cfg->nfft;
+  float2* tw = (float2*)malloc(sizeof(float2) * (N / 2));
+  float* win = (float*)malloc(sizeof(float) * N);
+  const double two_pi = 6.283185307179586476925286766559;
+  for (uint32_t t = 0; t < N / 2; ++t) tw[t] = make_float2((float)cos(two_pi * (double)t / (double)N), (float)(-sin(two_pi * (double)t / (double)N)));
+  for (uint32_t n = 0; n < N; ++n) win[n] = cfg->window ? cfg->window[n] : (float)(0.5 - 0.5 * cos(two_pi * (double)n / (double)N));
+  hipError_t e = hipMalloc(&h->d_tw, sizeof(float2) * (N / 2));
+  if (e == hipSuccess) e = hipMalloc(&h->d_win, sizeof(float) * N);
+  if (e == hipSuccess) e = hipMemcpy(h->d_tw, tw, sizeof(float2) * (N / 2), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(h->d_win, win, sizeof(float) * N, hipMemcpyHostToDevice);
+  free(tw); free(win);
+  CR(e);
+#undef CR
+  *out = h;
+  return SDRFM_OK;
+}
+
+void sdrfm_spectrum_destroy(sdrfm_spectrum_t* h) { sfree(h); }
+
+int sdrfm_spectrum_set_stream(sdrfm_spectrum_t* h, void* hip_stream) {
+  if (!h) return SDRFM_EINVAL;
+  h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+  return SDRFM_OK;
+}
+
+int sdrfm_spectrum_synchronize(sdrfm_spectrum_t* h) {
+  if (!h) return SDRFM_EINVAL;
+  STRY(hipSetDevice(h->device), SDRFM_FAIL);
+  STRY(hipStreamSynchronize(h->stream), SDRFM_FAIL);
+  return SDRFM_OK;
+}
+
+static int senqueue(sdrfm_spectrum* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nbytes, float* d_power, size_t power_stride,
+                    uint32_t F) {
+  const uint32_t ns = h->cfg.n_streams, N = h->cfg.nfft;
+  if (F == 0) {                                               // nothing to view: all zeros
+    STRY(hipMemset2DAsync(d_power, power_stride * sizeof(float), 0, N * sizeof(float), ns, h->stream), SDRFM_FAIL);
+    return SDRFM_OK;
+  }
+  const uint64_t span = (uint64_t)(ns - 1) * iq_stride + 2ull * F * N;
+  if (span >= (1ull << 32)) return SDRFM_ECAPACITY;           // one buffer descriptor spans the batch
+  (void)nbytes;
+  SParams p;
+  p.iq = d_iq; p.iq_stride = iq_stride; p.iq_span = (uint32_t)span; p.power = d_power; p.power_stride = power_stride;
+  p.tw = h->d_tw; p.win = h->d_win; p.F = F; p.inv_frames = 1.0f / (float)F;
+  hipLaunchKernelGGL(h->kernel, dim3(ns), dim3(256), 0, h->stream, p);
+  STRY(hipGetLastError(), SDRFM_FAIL);
+  return SDRFM_OK;
+}
+
+int sdrfm_spectrum_process_batch(sdrfm_spectrum_t* h, const uint8_t* iq, size_t iq_stride, uint32_t nbytes, float* power,
+                                 size_t power_stride, uint32_t* n_frames, uint32_t flags) {
+  if (!h || !n_frames || !power) return SDRFM_EINVAL;
+  if (flags & ~SDRFM_F_DEVICE_PTRS) return SDRFM_EINVAL;
+  if (nbytes & 1u) return SDRFM_EODD;
+  if (nbytes && !iq) return SDRFM_EINVAL;
+  if (nbytes > h->max_bytes) return SDRFM_ECAPACITY;
+  const uint32_t ns = h->cfg.n_streams, N = h->cfg.nfft;
+  if (ns > 1 && iq_stride < nbytes) return SDRFM_ECAPACITY;
+  if (power_stride < N) return SDRFM_ECAPACITY;
+  const uint32_t F = (nbytes / 2) / N;
+  *n_frames = F;
+  STRY(hipSetDevice(h->device), SDRFM_FAIL);
+  if (flags & SDRFM_F_DEVICE_PTRS) return senqueue(h, iq, iq_stride, nbytes, power, power_stride, F);
+  if (!h->d_iq) {
+    h->d_iq_stride = ((size_t)h->max_bytes + 255) & ~(size_t)255;
+    STRY(hipMalloc(&h->d_iq, ns * h->d_iq_stride), SDRFM_ENOMEM);
+    STRY(hipMalloc(&h->d_power, sizeof(float) * ns * N), SDRFM_ENOMEM);
+  }
+  if (nbytes)
+    STRY(hipMemcpy2DAsync(h->d_iq, h->d_iq_stride, iq, ns > 1 ? iq_stride : nbytes, nbytes, ns, hipMemcpyHostToDevice, h->stream), SDRFM_FAIL);
+  const int rc = senqueue(h, h->d_iq, h->d_iq_stride, nbytes, h->d_power, N, F);
+  if (rc != SDRFM_OK) return rc;
+  STRY(hipMemcpy2DAsync(power, power_stride * sizeof(float), h->d_power, N * sizeof(float), N * sizeof(float), ns, hipMemcpyDeviceToHost, h->stream), SDRFM_FAIL);
+  STRY(hipStreamSynchronize(h->stream), SDRFM_FAIL);
+  return SDRFM_OK;
+}
+
+}  // extern "C"

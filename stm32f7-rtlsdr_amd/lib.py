@@ -18,6 +18,8 @@ ABI_SYMBOLS = [
     "sdrfm_host_atan2f", "sdrfm_host_discriminate", "sdrfm_debug_phase_cycles", "sdrfm_debug_discriminate", "sdrfm_debug_raw",
     "sdrfm_wbfm_create", "sdrfm_wbfm_destroy", "sdrfm_wbfm_reset", "sdrfm_wbfm_audio_count", "sdrfm_wbfm_process_batch",
     "sdrfm_wbfm_set_stream", "sdrfm_wbfm_synchronize", "sdrfm_wbfm_kernel_name", "sdrfm_rtl_pack_fir", "sdrfm_rtl_resampler", "sdrfm_e4k_pll_params",
+    "sdrfm_spectrum_create", "sdrfm_spectrum_destroy", "sdrfm_spectrum_process_batch", "sdrfm_spectrum_set_stream",
+    "sdrfm_spectrum_synchronize",
     "sdrfm_pcm_deemph_s16", "sdrfm_pcm_alpha",
     "sdrfm_ring_create", "sdrfm_ring_destroy", "sdrfm_ring_submit", "sdrfm_ring_collect",
 ]
@@ -50,6 +52,13 @@ class WbfmConfig(C.Structure):
         ("proto_coeffs", C.POINTER(C.c_float)), ("resamp_taps", C.c_uint32), ("resamp_up", C.c_uint32),
         ("resamp_down", C.c_uint32), ("resamp_coeffs", C.POINTER(C.c_float)), ("max_bytes_per_call", C.c_uint32),
         ("device", C.c_int32), ("flags", C.c_uint32),
+    ]
+
+
+class SpectrumConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("n_streams", C.c_uint32), ("nfft", C.c_uint32), ("window", C.POINTER(C.c_float)),
+        ("max_bytes_per_call", C.c_uint32), ("device", C.c_int32), ("flags", C.c_uint32),
     ]
 
 
@@ -120,6 +129,16 @@ def load_library():
     lib.sdrfm_wbfm_synchronize.restype = C.c_int
     lib.sdrfm_wbfm_kernel_name.argtypes = [vp]
     lib.sdrfm_wbfm_kernel_name.restype = C.c_char_p
+    lib.sdrfm_spectrum_create.argtypes = [C.POINTER(SpectrumConfig), C.POINTER(vp)]
+    lib.sdrfm_spectrum_create.restype = C.c_int
+    lib.sdrfm_spectrum_destroy.argtypes = [vp]
+    lib.sdrfm_spectrum_destroy.restype = None
+    lib.sdrfm_spectrum_process_batch.argtypes = [vp, vp, C.c_size_t, u32, vp, C.c_size_t, u32p, u32]
+    lib.sdrfm_spectrum_process_batch.restype = C.c_int
+    lib.sdrfm_spectrum_set_stream.argtypes = [vp, vp]
+    lib.sdrfm_spectrum_set_stream.restype = C.c_int
+    lib.sdrfm_spectrum_synchronize.argtypes = [vp]
+    lib.sdrfm_spectrum_synchronize.restype = C.c_int
     lib.sdrfm_rtl_pack_fir.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_uint8)]
     lib.sdrfm_rtl_pack_fir.restype = C.c_int
     lib.sdrfm_rtl_resampler.argtypes = [u32, u32, u32p, u32p, C.POINTER(C.c_double)]
