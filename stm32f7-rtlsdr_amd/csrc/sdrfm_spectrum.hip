@@ -5,10 +5,13 @@
 // lo = A+T, hi = A-T), P = fmaf(re,re,im*im), S += P in frame order, out = fftshift(S) * (1/F).  Every operation is the
 // oracle's, in an order the graph allows, so the result is bit-identical.
 //
-// Kernel: one 256-thread workgroup per stream walks the stream's frames in order (the spec's sum over frames is
-// sequential) with the running sums in registers.  A frame lives in LDS as float2[N]; samples arrive through typed
-// buffer loads (u8 pair -> 2 floats in the texture unit), one frame ahead of the FFT; the DIT stages are applied two at a
-// time (a thread takes the 4 points that two consecutive stages couple, so each pass reads and writes a point once).
+// Kernel: one workgroup per stream walks the stream's frames in rounds of NWF = 8 (N <= 1024) frames, ONE WAVE PER FRAME:
+// a frame lives in that wave's own LDS region as float2[N] and its FFT needs no workgroup barrier (a wave's LDS
+// operations execute in order).  Samples arrive through typed buffer loads (u8 pair -> 2 floats in the texture unit), one
+// round ahead of the FFT; the DIT stages are applied two at a time (a lane takes the 4 points that two consecutive stages
+// couple, so each pass reads and writes a point once).  After a round the frames' powers are added to the running sums
+// (registers, N/threads bins per thread) in frame order — the spec's sum over frames is sequential — which costs two
+// workgroup barriers per round instead of ~7 per frame.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -47,79 +50,148 @@ __device__ __forceinline__ void butterfly(float2& a, float2& b, float2 w) {   //
   b = make_float2(A.x - tr, A.y - ti);
 }
 
+// frames in flight per workgroup (one wave each): 8, or 4 for 4096 points (LDS: 160 KiB per CU)
+constexpr int spec_nwf(int logn) { return logn <= 11 ? 8 : 4; }
+// LDS index padding: a DIT pass touches points at power-of-two strides (and the bit-reversed scatter at stride N/64), which
+// without padding put all 64 lanes into 4 of the 16 float2 bank slots; one pad slot per 16 and per 256 elements makes every
+// access pattern of every pass conflict-free (checked exhaustively for N = 256..4096, tools/fft_lds_padding.py)
+__host__ __device__ constexpr int spad(int i) { return i + (i >> 4) + (i >> 8); }
+
+__device__ __forceinline__ void wave_sync() {                  // LDS written by this wave is visible to all of its lanes
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
 template <int LOGN>
-__global__ void __launch_bounds__(256) k_spectrum(SParams p) {
-  constexpr int N = 1 << LOGN, PPT = (N + 255) / 256;          // points per thread
-  __shared__ float2 X[N];
-  __shared__ float2 TW[N / 2];
-  const int t = (int)threadIdx.x;
+__global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
+  constexpr int N = 1 << LOGN, NWF = spec_nwf(LOGN), NT = 64 * NWF;
+  constexpr int PPL = (N + 63) / 64;                           // points per lane of a frame's wave
+  constexpr int PPT = (N + NT - 1) / NT;                       // bins per thread of the running sum
+  extern __shared__ __attribute__((aligned(16))) unsigned char spec_smem[];
+  constexpr int NPT = spad(N / 2 - 1) + 1, NPX = spad(N - 1) + 1;   // padded sizes of the twiddle table and of a frame
+  float2* TW = reinterpret_cast<float2*>(spec_smem);           // N/2 twiddles at TW[spad(t)]
+  const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  float2* X = reinterpret_cast<float2*>(spec_smem) + NPT + wv * NPX;   // this wave's frame: point i at X[spad(i)]
+  const float* PW = reinterpret_cast<const float*>(reinterpret_cast<float2*>(spec_smem) + NPT);   // wave w's powers at PW[2 NPX w + k]
   const uint32_t stream = blockIdx.x;
-  for (int i = t; i < N / 2; i += 256) TW[i] = p.tw[i];
-  float wv[PPT], S[PPT];
+  for (int i = tid; i < N / 2; i += NT) TW[spad(i)] = p.tw[i];
+  // up to 1024 points the lane keeps its window values and the next round's samples in registers; longer frames would
+  // need > 256 VGPRs for that, so they read the window through the cache and load their samples when they need them
+  constexpr bool REGS = (LOGN <= 10);
+  constexpr int PR = REGS ? PPL : 1;
+  float wv_win[PR], S[PPT];
+  if constexpr (REGS) {
 #pragma unroll
-  for (int q = 0; q < PPT; ++q) {
-    const int n = t + 256 * q;
-    wv[q] = n < N ? p.win[n] : 0.0f;
-    S[q] = 0.0f;
+    for (int q = 0; q < PPL; ++q) { const int n = lane + 64 * q; wv_win[q] = n < N ? p.win[n] : 0.0f; }
   }
+#pragma unroll
+  for (int q = 0; q < PPT; ++q) S[q] = 0.0f;
   const unsigned long long ga = (unsigned long long)p.iq;
   const si4_t rsrc = {(int)(unsigned)ga, (int)(unsigned)(ga >> 32), (int)p.iq_span, SDRFM_SPEC_RSRC_U8X2};
   const uint32_t sbase = stream * (uint32_t)p.iq_stride;
-  sf2_t cur[PPT];
+  sf2_t cur[PR];
+  auto fetch = [&](uint32_t f) {                               // frame f of this stream -> cur (out-of-range reads return 0)
+    if constexpr (REGS) {
 #pragma unroll
-  for (int q = 0; q < PPT; ++q) cur[q] = spec_typed_load_xy(rsrc, (int)(sbase + 2u * (uint32_t)(t + 256 * q)), 0, 0);
-  __syncthreads();                                             // TW visible
-  for (uint32_t f = 0; f < p.F; ++f) {
-#pragma unroll
-    for (int q = 0; q < PPT; ++q) {
-      const int n = t + 256 * q;
-      if (n < N) {
-        const uint32_t u = __brev((uint32_t)n) >> (32 - LOGN);
-        X[u] = make_float2((cur[q].x - 127.5f) * wv[q], (cur[q].y - 127.5f) * wv[q]);
-      }
+      for (int q = 0; q < PPL; ++q)
+        cur[q] = spec_typed_load_xy(rsrc, (int)(sbase + 2u * (f * (uint32_t)N + (uint32_t)(lane + 64 * q))), 0, 0);
     }
-    if (f + 1 < p.F) {                                         // next frame's bytes: in flight during this frame's FFT
+  };
+  if ((uint32_t)wv < p.F) fetch((uint32_t)wv);
+  __syncthreads();                                             // TW visible
+  for (uint32_t f0 = 0; f0 < p.F; f0 += NWF) {                 // a round: frames f0 .. f0+NWF-1, one per wave
+    const uint32_t f = f0 + (uint32_t)wv;
+    if (f < p.F) {                                             // (wave-uniform)
+      if constexpr (REGS) {
 #pragma unroll
-      for (int q = 0; q < PPT; ++q)
-        cur[q] = spec_typed_load_xy(rsrc, (int)(sbase + 2u * ((f + 1) * (uint32_t)N + (uint32_t)(t + 256 * q))), 0, 0);
+        for (int q = 0; q < PPL; ++q) {
+          const int n = lane + 64 * q;
+          if (n < N) {
+            const uint32_t u = __brev((uint32_t)n) >> (32 - LOGN);
+            X[spad((int)u)] = make_float2((cur[q].x - 127.5f) * wv_win[q], (cur[q].y - 127.5f) * wv_win[q]);
+          }
+        }
+      } else {
+#pragma unroll 8
+        for (int q = 0; q < PPL; ++q) {
+          const int n = lane + 64 * q;
+          const sf2_t c = spec_typed_load_xy(rsrc, (int)(sbase + 2u * (f * (uint32_t)N + (uint32_t)n)), 0, 0);
+          const float wn = p.win[n];
+          X[spad((int)(__brev((uint32_t)n) >> (32 - LOGN)))] = make_float2((c.x - 127.5f) * wn, (c.y - 127.5f) * wn);
+        }
+      }
+      if (f + NWF < p.F) fetch(f + NWF);                       // next round's bytes: in flight during this frame's FFT
+      wave_sync();
+      // stages s and s+1 together: the 4 points {i, i+h, i+2h, i+3h} (h = 2^(s-1)) are closed under both stages
+      int s = 1;
+#pragma unroll
+      for (; s + 1 <= LOGN; s += 2) {
+        const int h = 1 << (s - 1);
+#pragma unroll 4
+        for (int g0 = 0; g0 < N / 4; g0 += 64) {
+          const int g = g0 + lane;
+          if (N / 4 >= 64 || g < N / 4) {
+            const int pos = g & (h - 1), i = ((g >> (s - 1)) << (s + 1)) + pos;
+            const int ia = spad(i), ib = spad(i + h), ic = spad(i + 2 * h), id = spad(i + 3 * h);
+            float2 a = X[ia], b = X[ib], c = X[ic], d = X[id];
+            const float2 w1 = TW[spad(pos << (LOGN - s))];             // stage s: pairs (a,b), (c,d), same position
+            butterfly(a, b, w1);
+            butterfly(c, d, w1);
+            butterfly(a, c, TW[spad(pos << (LOGN - s - 1))]);          // stage s+1 (half = 2h): position pos
+            butterfly(b, d, TW[spad((pos + h) << (LOGN - s - 1))]);    //                        position pos + h
+            X[ia] = a; X[ib] = b; X[ic] = c; X[id] = d;
+          }
+        }
+        wave_sync();
+      }
+      if (s <= LOGN) {                                         // odd LOGN: one last single stage
+        const int h = 1 << (s - 1);
+#pragma unroll 4
+        for (int j0 = 0; j0 < N / 2; j0 += 64) {
+          const int j = j0 + lane;
+          if (N / 2 >= 64 || j < N / 2) {
+            const int pos = j & (h - 1), i = ((j >> (s - 1)) << s) + pos;
+            float2 a = X[spad(i)], b = X[spad(i + h)];
+            butterfly(a, b, TW[spad(pos << (LOGN - s))]);
+            X[spad(i)] = a; X[spad(i + h)] = b;
+          }
+        }
+        wave_sync();
+      }
+      // powers of this frame, written over the start of its own region (PW[2 NPX wv + k]) in blocks of 16 points per lane:
+      // block b overwrites float slots [1024 b, 1024 b + 1024), i.e. float2 slots below 512 (b + 1) — points already consumed
+      // (a point's padded slot is never below its index)
+      constexpr int PB = PPL < 16 ? PPL : 16;
+      for (int q0 = 0; q0 < PPL; q0 += PB) {
+        float pw[PB];
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+          const int k = lane + 64 * (q0 + q);
+          if (k < N) { const float2 v = X[spad(k)]; pw[q] = __builtin_fmaf(v.x, v.x, v.y * v.y); }
+        }
+        wave_sync();
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+          const int k = lane + 64 * (q0 + q);
+          if (k < N) reinterpret_cast<float*>(X)[k] = pw[q];
+        }
+        wave_sync();
+      }
     }
     __syncthreads();
-    // stages s and s+1 together: group g of 4 points {i, i+h, i+2h, i+3h} (h = 2^(s-1)) is closed under both stages
-    int s = 1;
-    for (; s + 1 <= LOGN; s += 2) {
-      const int h = 1 << (s - 1);
-      for (int g = t; g < N / 4; g += 256) {
-        const int pos = g & (h - 1), i = ((g >> (s - 1)) << (s + 1)) + pos;
-        float2 a = X[i], b = X[i + h], c = X[i + 2 * h], d = X[i + 3 * h];
-        const float2 w1 = TW[pos << (LOGN - s)];                       // stage s: pairs (a,b), (c,d), same pos
-        butterfly(a, b, w1);
-        butterfly(c, d, w1);
-        butterfly(a, c, TW[pos << (LOGN - s - 1)]);                    // stage s+1 (half = 2h): position pos
-        butterfly(b, d, TW[(pos + h) << (LOGN - s - 1)]);              //                        position pos + h
-        X[i] = a; X[i + h] = b; X[i + 2 * h] = c; X[i + 3 * h] = d;
-      }
-      __syncthreads();
-    }
-    if (s <= LOGN) {                                           // odd LOGN: one last single stage
-      const int h = 1 << (s - 1);
-      for (int j = t; j < N / 2; j += 256) {
-        const int pos = j & (h - 1), i = ((j >> (s - 1)) << s) + pos;
-        float2 a = X[i], b = X[i + h];
-        butterfly(a, b, TW[pos << (LOGN - s)]);
-        X[i] = a; X[i + h] = b;
-      }
-      __syncthreads();
-    }
+    // the spec's sum over frames is sequential: add this round's frames in frame order
+    const uint32_t nfr = (p.F - f0) < (uint32_t)NWF ? (p.F - f0) : (uint32_t)NWF;
 #pragma unroll
     for (int q = 0; q < PPT; ++q) {
-      const int k = t + 256 * q;
-      if (k < N) { const float2 v = X[k]; S[q] = S[q] + __builtin_fmaf(v.x, v.x, v.y * v.y); }
+      const int k = tid + NT * q;
+      if (k < N)
+        for (uint32_t w = 0; w < nfr; ++w) S[q] = S[q] + PW[2 * NPX * w + k];
     }
-    __syncthreads();                                           // X is rewritten by the next frame
+    __syncthreads();                                           // the frames are rewritten by the next round
   }
 #pragma unroll
   for (int q = 0; q < PPT; ++q) {
-    const int k = t + 256 * q;
+    const int k = tid + NT * q;
     if (k < N) p.power[(size_t)stream * p.power_stride + (size_t)((k + N / 2) & (N - 1))] = S[q] * p.inv_frames;
   }
 }
@@ -150,6 +222,7 @@ struct sdrfm_spectrum {
   uint8_t* d_iq; size_t d_iq_stride;
   float* d_power;
   spec_kernel_t kernel;
+  size_t lds_bytes;
 };
 
 #define STRY(expr, code)                                                                                     \
@@ -190,8 +263,14 @@ int sdrfm_spectrum_create(const sdrfm_spectrum_config* cfg, sdrfm_spectrum_t** o
   h->device = cfg->device; h->logn = logn;
   h->max_bytes = cfg->max_bytes_per_call ? cfg->max_bytes_per_call : (1u << 20);
   h->kernel = pick_kernel(logn);
+  h->lds_bytes = ((size_t)(spad((int)cfg->nfft / 2 - 1) + 1) + (size_t)spec_nwf((int)logn) * (size_t)(spad((int)cfg->nfft - 1) + 1)) * sizeof(float2);
 #define CR(expr) do { if ((expr) != hipSuccess) { sfree(h); return SDRFM_ENOMEM; } } while (0)
   CR(hipSetDevice(h->device));
+  if (h->lds_bytes > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(h->kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) {
+    sfree(h);
+    return SDRFM_NOT_SUPPORTED;
+  }
   CR(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
   h->stream = h->own_stream;
   const uint32_t N = cfg->nfft;
@@ -239,7 +318,7 @@ static int senqueue(sdrfm_spectrum* h, const uint8_t* d_iq, size_t iq_stride, ui
   SParams p;
   p.iq = d_iq; p.iq_stride = iq_stride; p.iq_span = (uint32_t)span; p.power = d_power; p.power_stride = power_stride;
   p.tw = h->d_tw; p.win = h->d_win; p.F = F; p.inv_frames = 1.0f / (float)F;
-  hipLaunchKernelGGL(h->kernel, dim3(ns), dim3(256), 0, h->stream, p);
+  hipLaunchKernelGGL(h->kernel, dim3(ns), dim3(64 * spec_nwf((int)h->logn)), h->lds_bytes, h->stream, p);
   STRY(hipGetLastError(), SDRFM_FAIL);
   return SDRFM_OK;
 }
