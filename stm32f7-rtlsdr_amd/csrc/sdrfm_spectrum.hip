@@ -50,17 +50,58 @@ __device__ __forceinline__ void butterfly(float2& a, float2& b, float2 w) {   //
   b = make_float2(A.x - tr, A.y - ti);
 }
 
-// frames in flight per workgroup (one wave each): 8, or 4 for 4096 points (LDS: 160 KiB per CU)
-constexpr int spec_nwf(int logn) { return logn <= 11 ? 8 : 4; }
+__device__ __forceinline__ void wave_sync() {                  // LDS written by this wave is visible to all of its lanes
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
 // LDS index padding: a DIT pass touches points at power-of-two strides (and the bit-reversed scatter at stride N/64), which
 // without padding put all 64 lanes into 4 of the 16 float2 bank slots; one pad slot per 16 and per 256 elements makes every
 // access pattern of every pass conflict-free (checked exhaustively for N = 256..4096, tools/fft_lds_padding.py)
 __host__ __device__ constexpr int spad(int i) { return i + (i >> 4) + (i >> 8); }
 
-__device__ __forceinline__ void wave_sync() {                  // LDS written by this wave is visible to all of its lanes
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  __builtin_amdgcn_wave_barrier();
+// Stages S .. S+K-1 of the radix-2 DIT graph in ONE pass over LDS: the 2^K points {base + c h}, h = 2^(S-1), are closed under
+// these K stages, so a lane loads them, applies the K layers of butterflies in registers and stores them — one LDS round
+// trip per K stages instead of one per stage.  Every butterfly is the spec's (same operands, same twiddle
+// tw[position_in_stage * N/m]); only the order of independent butterflies differs from the oracle's loops.
+template <int LOGN, int S, int K>
+__device__ __forceinline__ void fft_pass(float2* X, const float2* TW, int lane) {
+  constexpr int N = 1 << LOGN, H = 1 << (S - 1), G = 1 << K, NG = N >> K;
+#pragma unroll
+  for (int g0 = 0; g0 < NG; g0 += 64) {
+    const int g = g0 + lane;
+    if (NG >= 64 || g < NG) {
+      const int pos = g & (H - 1), base = ((g >> (S - 1)) << (S - 1 + K)) + pos;
+      float2 v[G];
+#pragma unroll
+      for (int c = 0; c < G; ++c) v[c] = X[spad(base + c * H)];
+#pragma unroll
+      for (int t = 0; t < K; ++t) {                            // stage S + t: half = H 2^t, partner c ^ 2^t
+#pragma unroll
+        for (int c = 0; c < G; ++c) {
+          if ((c >> t) & 1) continue;
+          const int pos_t = pos + (c & ((1 << t) - 1)) * H;    // position of the pair within its stage-(S+t) block
+          butterfly(v[c], v[c + (1 << t)], TW[spad(pos_t << (LOGN - S - t))]);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < G; ++c) X[spad(base + c * H)] = v[c];
+    }
+  }
+  wave_sync();
 }
+template <int LOGN, int S>
+__device__ __forceinline__ void fft_passes(float2* X, const float2* TW, int lane) {
+  if constexpr (S <= LOGN) {
+    // up to 4 stages per pass, but no more than leaves a group (2^K points) for each of the 64 lanes
+    constexpr int KMAX = (LOGN - 6) >= 4 ? 4 : ((LOGN - 6) >= 2 ? (LOGN - 6) : 2);
+    constexpr int K = (LOGN - S + 1) >= KMAX ? KMAX : (LOGN - S + 1);
+    fft_pass<LOGN, S, K>(X, TW, lane);
+    fft_passes<LOGN, S + K>(X, TW, lane);
+  }
+}
+
+// frames in flight per workgroup (one wave each): 8, or 4 for 4096 points (LDS: 160 KiB per CU)
+constexpr int spec_nwf(int logn) { return logn <= 11 ? 8 : 4; }
 
 template <int LOGN>
 __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
@@ -122,42 +163,8 @@ __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
       }
       if (f + NWF < p.F) fetch(f + NWF);                       // next round's bytes: in flight during this frame's FFT
       wave_sync();
-      // stages s and s+1 together: the 4 points {i, i+h, i+2h, i+3h} (h = 2^(s-1)) are closed under both stages
-      int s = 1;
-#pragma unroll
-      for (; s + 1 <= LOGN; s += 2) {
-        const int h = 1 << (s - 1);
-#pragma unroll 4
-        for (int g0 = 0; g0 < N / 4; g0 += 64) {
-          const int g = g0 + lane;
-          if (N / 4 >= 64 || g < N / 4) {
-            const int pos = g & (h - 1), i = ((g >> (s - 1)) << (s + 1)) + pos;
-            const int ia = spad(i), ib = spad(i + h), ic = spad(i + 2 * h), id = spad(i + 3 * h);
-            float2 a = X[ia], b = X[ib], c = X[ic], d = X[id];
-            const float2 w1 = TW[spad(pos << (LOGN - s))];             // stage s: pairs (a,b), (c,d), same position
-            butterfly(a, b, w1);
-            butterfly(c, d, w1);
-            butterfly(a, c, TW[spad(pos << (LOGN - s - 1))]);          // stage s+1 (half = 2h): position pos
-            butterfly(b, d, TW[spad((pos + h) << (LOGN - s - 1))]);    //                        position pos + h
-            X[ia] = a; X[ib] = b; X[ic] = c; X[id] = d;
-          }
-        }
-        wave_sync();
-      }
-      if (s <= LOGN) {                                         // odd LOGN: one last single stage
-        const int h = 1 << (s - 1);
-#pragma unroll 4
-        for (int j0 = 0; j0 < N / 2; j0 += 64) {
-          const int j = j0 + lane;
-          if (N / 2 >= 64 || j < N / 2) {
-            const int pos = j & (h - 1), i = ((j >> (s - 1)) << s) + pos;
-            float2 a = X[spad(i)], b = X[spad(i + h)];
-            butterfly(a, b, TW[spad(pos << (LOGN - s))]);
-            X[spad(i)] = a; X[spad(i + h)] = b;
-          }
-        }
-        wave_sync();
-      }
+      // DIT stages in passes of up to 4 stages, each pass entirely in registers (see fft_pass)
+      fft_passes<LOGN, 1>(X, TW, lane);
       // powers of this frame, written over the start of its own region (PW[2 NPX wv + k]) in blocks of 16 points per lane:
       // block b overwrites float slots [1024 b, 1024 b + 1024), i.e. float2 slots below 512 (b + 1) — points already consumed
       // (a point's padded slot is never below its index)
