@@ -966,6 +966,8 @@ struct sdrfm {
   size_t d_iq_stride;
   float* d_audio;
   size_t d_audio_stride;
+  // small single-stream calls (URB-sized hand-offs): host-mapped pinned buffers the kernel reads / writes directly
+  uint8_t* zc_iq; float* zc_audio; uint8_t* zc_iq_dev; float* zc_audio_dev; uint32_t zc_audio_cap; bool zc_off;
   uint32_t max_bytes;
   // generic kernel geometry
   uint32_t NA;
@@ -1015,6 +1017,8 @@ static void free_handle(sdrfm* h) {
     if (h->d_hist_b[i]) (void)hipFree(h->d_hist_b[i]);
   }
   if (h->d_iq) (void)hipFree(h->d_iq);
+  if (h->zc_iq) (void)hipHostFree(h->zc_iq);
+  if (h->zc_audio) (void)hipHostFree(h->zc_audio);
   if (h->d_audio) (void)hipFree(h->d_audio);
   if (h->d_dbg) (void)hipFree(h->d_dbg);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -1030,6 +1034,20 @@ static int ensure_staging(sdrfm* h) {
   h->d_audio_stride = (max_audio_for(h->cfg, h->max_bytes) + 63) & ~(size_t)63;
   HIP_TRY(hipMalloc(&h->d_iq, ns * h->d_iq_stride), SDRFM_ENOMEM);
   HIP_TRY(hipMalloc(&h->d_audio, ns * h->d_audio_stride * sizeof(float)), SDRFM_ENOMEM);
+  return SDRFM_OK;
+}
+
+// URB-sized synchronous calls spend most of their time in two tiny DMA transfers.  Up to SDRFM_ZC_MAX bytes the bytes are
+// instead copied by the CPU into a pinned, device-mapped buffer that the kernel reads over PCIe, and the kernel writes its
+// audio straight into mapped host memory: one launch and one stream wait per call.
+#define SDRFM_ZC_MAX 65536u
+static int ensure_zero_copy(sdrfm* h) {
+  if (h->zc_iq) return SDRFM_OK;
+  h->zc_audio_cap = (uint32_t)((max_audio_for(h->cfg, SDRFM_ZC_MAX) + 63) & ~(size_t)63);
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->zc_iq), SDRFM_ZC_MAX + 256, hipHostMallocMapped), SDRFM_ENOMEM);
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->zc_audio), sizeof(float) * h->zc_audio_cap, hipHostMallocMapped), SDRFM_ENOMEM);
+  HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->zc_iq_dev), h->zc_iq, 0), SDRFM_FAIL);
+  HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->zc_audio_dev), h->zc_audio, 0), SDRFM_FAIL);
   return SDRFM_OK;
 }
 
@@ -1084,6 +1102,7 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
   h->cfg = *cfg;
   h->device = cfg->device;
   h->max_bytes = cfg->max_bytes_per_call ? cfg->max_bytes_per_call : (1u << 20);
+  h->zc_off = getenv("SDRFM_NO_ZEROCOPY") != nullptr;
   h->max_bytes &= ~1u;
   float* hc = (float*)malloc(sizeof(float) * cfg->fir_taps);
   float* gc = (float*)malloc(sizeof(float) * cfg->audio_taps);
@@ -1326,6 +1345,16 @@ int sdrfm_process_batch(sdrfm_t* h, const uint8_t* iq, size_t iq_stride, uint32_
   // host buffers: stage -> kernels -> copy back, synchronous (the caller may re-arm `iq` as soon as we return,
   // like the reference FSM does with CommItf.buff)
   if (nbytes > h->max_bytes) return SDRFM_ECAPACITY;
+  if (ns == 1 && nbytes <= SDRFM_ZC_MAX && !h->zc_off) {
+    int zrc = ensure_zero_copy(h);
+    if (zrc != SDRFM_OK) return zrc;
+    memcpy(h->zc_iq, iq, nbytes);
+    zrc = enqueue(h, h->zc_iq_dev, SDRFM_ZC_MAX + 256, nbytes, h->zc_audio_dev, h->zc_audio_cap, n_audio);
+    if (zrc != SDRFM_OK) return zrc;
+    HIP_TRY(hipStreamSynchronize(h->stream), SDRFM_FAIL);
+    if (A) memcpy(audio, h->zc_audio, sizeof(float) * A);
+    return SDRFM_OK;
+  }
   int rc = ensure_staging(h);
   if (rc != SDRFM_OK) return rc;
   HIP_TRY(hipMemcpy2DAsync(h->d_iq, h->d_iq_stride, iq, ns > 1 ? iq_stride : nbytes, nbytes, ns, hipMemcpyHostToDevice,

@@ -269,3 +269,26 @@ def test_device_discriminator_arithmetic(pkg):
     for got in (o1, o2):
         assert np.max(np.abs(got.astype(np.float64) - want)) <= 1.0e-6
     assert np.array_equal(o1.view(np.uint32), o2.view(np.uint32)), "scalar and packed K3 disagree"
+
+
+def test_zero_copy_small_calls_bitwise_equal_staged_path(pkg, monkeypatch):
+    """URB-sized synchronous calls go through host-mapped buffers (no DMA); the bytes and the kernels are the same, so the
+    audio must equal the staged path's bit for bit — across the 65 536-byte switch-over as well."""
+    h, g = pkg.default_config(64)
+    iq = pkg.make_iq(1, 150000, mode="fm", first_id=77)[0]
+    sizes = [512, 512, 1024, 65536, 65538, 4096, 70000, 2, 0, 512]
+    outs = []
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("SDRFM_NO_ZEROCOPY", env)
+        else:
+            monkeypatch.delenv("SDRFM_NO_ZEROCOPY", raising=False)
+        dm = pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, max_bytes_per_call=1 << 18))
+        parts, pos = [], 0
+        for n in sizes:
+            parts.append(dm.process(iq[pos:pos + n]))
+            pos += n
+        outs.append(np.concatenate(parts))
+        dm.close()
+    assert outs[0].size > 2000
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
