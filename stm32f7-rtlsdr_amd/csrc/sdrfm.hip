@@ -934,12 +934,19 @@ struct FastVariant {
   uint32_t xbytes;
 };
 #define SDRFM_FAST(T_, D_, R_) { 'a', T_, D_, R_, 0, 0, {k_fast<T_, D_, R_, 0>, k_fast<T_, D_, R_, 1>, k_fast<T_, D_, R_, 2>, k_fast<T_, D_, R_, 3>, k_fast<T_, D_, R_, 4>, k_fast<T_, D_, R_, 5>, k_fast<T_, D_, R_, 6>, k_fast<T_, D_, R_, 7>}, (uint32_t)fast_xbytes(T_, D_, R_) }
-#define SDRFM_FASTB(T_, D_, R_) { 'b', T_, D_, R_, 32, 5, {k_fastb<T_, D_, R_, 32, 5, 0>, k_fastb<T_, D_, R_, 32, 5, 1>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, (uint32_t)fastb_xbytes(T_, D_, R_) }
+#define SDRFM_FAST_LITE(T_, D_, R_) { 'a', T_, D_, R_, 0, 0, {k_fast<T_, D_, R_, 0>, k_fast<T_, D_, R_, 1>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, (uint32_t)fast_xbytes(T_, D_, R_) }
+#define SDRFM_FASTB2(T_, D_, R_, TA_, DA_) { 'b', T_, D_, R_, TA_, DA_, {k_fastb<T_, D_, R_, TA_, DA_, 0>, k_fastb<T_, D_, R_, TA_, DA_, 1>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, (uint32_t)fastb_xbytes(T_, D_, R_) }
+#define SDRFM_FASTB(T_, D_, R_) SDRFM_FASTB2(T_, D_, R_, 32, 5)
 const FastVariant kFastVariants[] = {
+    // 2.4 MS/s -> 240 kS/s -> 48 kHz: the rate the firmware programs (usbh_rtlsdr.c:898) and the BASELINE configs
     SDRFM_FASTB(64, 10, 12), SDRFM_FASTB(64, 10, 8), SDRFM_FASTB(16, 10, 12), SDRFM_FASTB(16, 10, 8), SDRFM_FASTB(32, 10, 12), SDRFM_FASTB(32, 10, 8),
-    SDRFM_FAST(64, 10, 2), SDRFM_FAST(64, 10, 3), SDRFM_FAST(64, 10, 4),
-    SDRFM_FAST(16, 10, 2), SDRFM_FAST(16, 10, 4),
-    SDRFM_FAST(32, 10, 2), SDRFM_FAST(32, 10, 4),
+    // the other rates RTLSDR_set_sample_rate accepts and a dongle is commonly run at:
+    // 2.048 MS/s -> 256 kS/s -> 32 kHz, 1.024 MS/s -> 256 kS/s -> 32 kHz, 3.2 MS/s -> 200 kS/s -> 40 kHz
+    SDRFM_FASTB2(64, 8, 12, 32, 8), SDRFM_FASTB2(16, 8, 12, 32, 8), SDRFM_FASTB2(64, 4, 12, 32, 8), SDRFM_FASTB2(64, 16, 8, 32, 5),
+    // design A (float tile): kept as the measured alternative; ablation modes only on the documented shape
+    SDRFM_FAST(64, 10, 3), SDRFM_FAST_LITE(64, 10, 2), SDRFM_FAST_LITE(64, 10, 4),
+    SDRFM_FAST_LITE(16, 10, 2), SDRFM_FAST_LITE(16, 10, 4),
+    SDRFM_FAST_LITE(32, 10, 2), SDRFM_FAST_LITE(32, 10, 4),
 };
 
 }  // namespace

@@ -233,6 +233,22 @@ def test_specialised_kernels_equal_generic_kernel_bitwise(pkg, oracle_mod, monke
     fast.close(); gen.close()
 
 
+@pytest.mark.parametrize("T,D,Da,fs", [(64, 8, 8, 2.048e6), (16, 8, 8, 2.048e6), (64, 4, 8, 1.024e6), (64, 16, 5, 3.2e6)])
+def test_other_dongle_rates_have_specialised_kernels(pkg, oracle_mod, T, D, Da, fs):
+    """2.048 / 1.024 / 3.2 MS/s front ends (rates RTLSDR_set_sample_rate accepts) get a design-B kernel too; it must equal
+    the generic kernel bit for bit and the oracle within tolerance."""
+    h, g = pkg.default_config(T, fir_decim=D, audio_taps=32, audio_decim=Da)
+    iq = pkg.make_iq(1, 150000, mode="fm", fs=fs, first_id=91)[0]
+    cuts = [2 * 4000, 2 * 4000 + 2 * 70000]
+    kw = dict(fir_coeffs=h, audio_coeffs=g, fir_decim=D, audio_decim=Da, max_bytes_per_call=400000)
+    fast, gen = pkg.FmDemod(pkg.FmConfig(**kw)), pkg.FmDemod(pkg.FmConfig(force_generic=True, **kw))
+    a_fast, a_gen = _run_chunks(fast, iq, cuts), _run_chunks(gen, iq, cuts)
+    assert fast.kernel_name.startswith("fast-b"), fast.kernel_name
+    assert np.array_equal(a_fast.view(np.uint32), a_gen.view(np.uint32))
+    assert scaled_err(a_fast, oracle_mod.Oracle(h, g, D, Da).process(iq)) <= TOL
+    fast.close(); gen.close()
+
+
 def test_odd_sample_counts_fall_back_and_recover(pkg, oracle_mod):
     """A chunk with an odd number of IQ samples makes the decimator phase odd: the next calls use the generic kernel
     until the phase is even again; the audio is unaffected."""
