@@ -936,17 +936,17 @@ struct FastVariant {
 #define SDRFM_FAST(T_, D_, R_) { 'a', T_, D_, R_, 0, 0, {k_fast<T_, D_, R_, 0>, k_fast<T_, D_, R_, 1>, k_fast<T_, D_, R_, 2>, k_fast<T_, D_, R_, 3>, k_fast<T_, D_, R_, 4>, k_fast<T_, D_, R_, 5>, k_fast<T_, D_, R_, 6>, k_fast<T_, D_, R_, 7>}, (uint32_t)fast_xbytes(T_, D_, R_) }
 #define SDRFM_FAST_LITE(T_, D_, R_) { 'a', T_, D_, R_, 0, 0, {k_fast<T_, D_, R_, 0>, k_fast<T_, D_, R_, 1>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, (uint32_t)fast_xbytes(T_, D_, R_) }
 #define SDRFM_FASTB2(T_, D_, R_, TA_, DA_) { 'b', T_, D_, R_, TA_, DA_, {k_fastb<T_, D_, R_, TA_, DA_, 0>, k_fastb<T_, D_, R_, TA_, DA_, 1>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, (uint32_t)fastb_xbytes(T_, D_, R_) }
+#define SDRFM_FASTB2_LITE(T_, D_, R_, TA_, DA_) { 'b', T_, D_, R_, TA_, DA_, {k_fastb<T_, D_, R_, TA_, DA_, 0>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, (uint32_t)fastb_xbytes(T_, D_, R_) }
 #define SDRFM_FASTB(T_, D_, R_) SDRFM_FASTB2(T_, D_, R_, 32, 5)
 const FastVariant kFastVariants[] = {
     // 2.4 MS/s -> 240 kS/s -> 48 kHz: the rate the firmware programs (usbh_rtlsdr.c:898) and the BASELINE configs
-    SDRFM_FASTB(64, 10, 12), SDRFM_FASTB(64, 10, 8), SDRFM_FASTB(16, 10, 12), SDRFM_FASTB(16, 10, 8), SDRFM_FASTB(32, 10, 12), SDRFM_FASTB(32, 10, 8),
+    // (the instrumented twin, kernel[1], exists for the two BASELINE filter lengths only)
+    SDRFM_FASTB(64, 10, 12), SDRFM_FASTB2_LITE(64, 10, 8, 32, 5), SDRFM_FASTB(16, 10, 12), SDRFM_FASTB2_LITE(32, 10, 12, 32, 5),
     // the other rates RTLSDR_set_sample_rate accepts and a dongle is commonly run at:
     // 2.048 MS/s -> 256 kS/s -> 32 kHz, 1.024 MS/s -> 256 kS/s -> 32 kHz, 3.2 MS/s -> 200 kS/s -> 40 kHz
-    SDRFM_FASTB2(64, 8, 12, 32, 8), SDRFM_FASTB2(16, 8, 12, 32, 8), SDRFM_FASTB2(64, 4, 12, 32, 8), SDRFM_FASTB2(64, 16, 8, 32, 5),
+    SDRFM_FASTB2_LITE(64, 8, 12, 32, 8), SDRFM_FASTB2_LITE(16, 8, 12, 32, 8), SDRFM_FASTB2_LITE(64, 4, 12, 32, 8), SDRFM_FASTB2_LITE(64, 16, 8, 32, 5),
     // design A (float tile): kept as the measured alternative; ablation modes only on the documented shape
-    SDRFM_FAST(64, 10, 3), SDRFM_FAST_LITE(64, 10, 2), SDRFM_FAST_LITE(64, 10, 4),
-    SDRFM_FAST_LITE(16, 10, 2), SDRFM_FAST_LITE(16, 10, 4),
-    SDRFM_FAST_LITE(32, 10, 2), SDRFM_FAST_LITE(32, 10, 4),
+    SDRFM_FAST(64, 10, 3), SDRFM_FAST_LITE(16, 10, 2), SDRFM_FAST_LITE(32, 10, 2),
 };
 
 }  // namespace
@@ -1181,7 +1181,7 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
       h->warm_ahead = 0;
       if (const char* e = getenv("SDRFM_WARM_AHEAD")) h->warm_ahead = (uint32_t)atoi(e);
       if (const char* e = getenv("SDRFM_ABLATE")) { const int m = atoi(e); if (m >= 2 && m <= 7 && v.kernel[m]) h->fast_mode = m; }
-      if (getenv("SDRFM_PHASE_PROFILE") && !h->d_dbg) {
+      if (getenv("SDRFM_PHASE_PROFILE") && !h->d_dbg && v.kernel[1]) {
         if (hipMalloc(&h->d_dbg, 560 * sizeof(unsigned long long)) != hipSuccess) h->d_dbg = nullptr;
         else { (void)hipMemset(h->d_dbg, 0, 560 * sizeof(unsigned long long)); for (int x = 0; x < 8; ++x) { (void)hipMemset(h->d_dbg + 520 + 4 * x, 0xff, 8); (void)hipMemset(h->d_dbg + 522 + 4 * x, 0xff, 8); } h->fast_mode = 1; }
       }
