@@ -18,7 +18,8 @@ def pytest_configure(config):
 def _built():
     """Build native pieces once per session if they are missing (no-op when the .so files travelled with the repo)."""
     need = [os.path.join(ROOT, "stm32f7-rtlsdr_amd", "csrc", "libsdrfm.so"),
-            os.path.join(ROOT, "tools", "siggen", "libsiggen.so"), os.path.join(ROOT, "oracle", "libsdrfm_oracle.so")]
+            os.path.join(ROOT, "tools", "siggen", "libsiggen.so"), os.path.join(ROOT, "oracle", "libsdrfm_oracle.so"),
+            os.path.join(ROOT, "oracle", "libsdrfm_wbfm_oracle.so"), os.path.join(ROOT, "oracle", "libsdrfm_spectrum_oracle.so")]
     if not all(os.path.exists(p) for p in need):
         import __graft_entry__ as g
         g.build()
