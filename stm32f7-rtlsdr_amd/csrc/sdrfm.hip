@@ -1285,8 +1285,14 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
   p.prio_balance = getenv("SDRFM_NO_PRIO") ? 0u : 1u;
   p.dbg_tag = (h->d_dbg && ++h->dbg_launches == 16) ? 1u : 0u;
   p.warm_ahead = h->warm_ahead;
+  // Design B cannot express the zero history at the start of a stream in bytes: until T-1 real samples have been seen its
+  // first y_aff outputs are wrong and the generic kernel recomputes the audio that depends on them (below).  The STATE it
+  // hands over (last Ta-1 discriminator outputs, y[M-1]) must not contain any of those outputs either, so a first call that
+  // short runs on the generic kernel entirely.
+  const uint32_t y_aff = (c.fir_taps + c.fir_decim - 1) / c.fir_decim + 1;            // outputs touching never-seen samples
+  const bool short_first = h->fast && h->fast->kind == 'b' && h->n_seen + 1 < c.fir_taps && M < y_aff + c.audio_taps;
   const bool fast_ok = h->fast && A > 0 && (h->phase_x % 2 == 0) && ((uintptr_t)d_iq % 4 == 0) && (iq_stride % 4 == 0) &&
-                       N < (1u << 30);
+                       N < (1u << 30) && !short_first;
   if (fast_ok) {
     // split every stream into segments so that ~waves_target waves are resident; each segment >= min_subtiles sub-tiles
     const uint32_t NYT = 64 * h->fast->R;
@@ -1312,7 +1318,6 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
     if (h->fast->kind == 'b' && h->n_seen + 1 < c.fir_taps) {
       // Design B reads its halo as bytes, which cannot express the zero history at the start of a stream: the few audio
       // outputs that depend on inputs before the first real sample are recomputed by the generic kernel (tile 0..k only).
-      const uint32_t y_aff = (c.fir_taps + c.fir_decim - 1) / c.fir_decim + 1;            // outputs touching n < 0
       const uint32_t a_aff = (y_aff + c.audio_taps + c.audio_decim - 1) / c.audio_decim;  // audio outputs touching them
       CallParams q = p;
       q.NA = h->NA;

@@ -249,6 +249,27 @@ def test_other_dongle_rates_have_specialised_kernels(pkg, oracle_mod, T, D, Da, 
     fast.close(); gen.close()
 
 
+@pytest.mark.parametrize("T", [16, 32, 64])
+def test_short_first_calls_then_long_ones(pkg, oracle_mod, T):
+    """Found by tools/fuzz_parity.py: a stream that starts with a few tiny calls reaches the raw-byte kernel with a partial
+    history; if that call is itself short, the discriminator history it hands over must not contain outputs computed from
+    the (inexpressible) zero history."""
+    rng = np.random.default_rng(T)
+    h = (rng.standard_normal(T) / T).astype(np.float32)
+    g = (rng.standard_normal(32) / 32).astype(np.float32)
+    for chunks in ([10, 0, 2, 660, 8190, 100218], [40, 700, 20000], [2, 2, 2, 400, 400, 30000], [620, 640, 50000]):
+        iq = pkg.make_iq(2, sum(chunks) // 2, mode="fm", first_id=T)
+        dm = pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=2, max_bytes_per_call=1 << 18))
+        outs, pos = [], 0
+        for c in chunks:
+            outs.append(dm.process_batch(iq[:, pos:pos + c]))
+            pos += c
+        got = np.concatenate(outs, axis=1)
+        for s in range(2):
+            assert scaled_err(got[s], oracle_mod.Oracle(h, g).process(iq[s])) <= TOL, (chunks, s)
+        dm.close()
+
+
 def test_odd_sample_counts_fall_back_and_recover(pkg, oracle_mod):
     """A chunk with an odd number of IQ samples makes the decimator phase odd: the next calls use the generic kernel
     until the phase is even again; the audio is unaffected."""

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Randomised parity soak (GPU box): random geometry, stream count, input class and chunking through the C-ABI against the
+oracle; prints one line per failure and a summary.   python tools/fuzz_parity.py [seconds] [seed]"""
+import importlib, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+pkg = importlib.import_module("stm32f7-rtlsdr_amd")
+from oracle import oracle as om  # the checker
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+GEOMS = [(64, 10, 32, 5), (16, 10, 32, 5), (32, 10, 32, 5), (64, 8, 32, 8), (64, 16, 32, 5), (64, 4, 32, 8), (7, 3, 5, 4), (128, 16, 64, 6), (2, 2, 2, 2)]
+t_end, cases, fails, worst = time.time() + budget, 0, 0, 0.0
+while time.time() < t_end:
+    T, D, Ta, Da = GEOMS[rng.integers(len(GEOMS))]
+    if (T, D) in ((64, 10), (16, 10)):
+        h, g = pkg.default_config(T, audio_taps=Ta)
+    else:
+        h = (rng.standard_normal(T) / T).astype(np.float32); g = (rng.standard_normal(Ta) / Ta).astype(np.float32)
+    ns = int(rng.choice([1, 1, 2, 3, 8, 17]))
+    nsamp = int(rng.integers(1, 60000))
+    mode = str(rng.choice(["fm", "random", "const", "counter"]))
+    iq = pkg.make_iq(ns, nsamp, mode=mode, first_id=int(rng.integers(1 << 20)))
+    dm = pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, fir_decim=D, audio_decim=Da, n_streams=ns, max_bytes_per_call=1 << 18))
+    outs, pos, chunks = [], 0, []
+    while pos < 2 * nsamp:
+        c = 2 * int(rng.choice([0, 1, 5, 256, 4095, 20000, 65536])) if rng.random() < 0.7 else 2 * int(rng.integers(0, 30000))
+        c = min(c, 2 * nsamp - pos)
+        chunks.append(c)
+        outs.append(dm.process_batch(iq[:, pos:pos + c]) if ns > 1 else dm.process(iq[0, pos:pos + c])[None, :])
+        pos += c if c else 0
+        if c == 0 and rng.random() < 0.5:
+            outs.append(dm.process_batch(iq[:, pos:pos + 2]) if ns > 1 else dm.process(iq[0, pos:pos + 2])[None, :]); pos += 2; chunks.append(2)
+    got = np.concatenate(outs, axis=1)
+    for s in range(ns):
+        want = om.Oracle(h, g, D, Da).process(iq[s])
+        ok = got[s].size == want.size
+        err = float(np.max(np.abs(got[s] - want) / np.maximum(np.abs(want), 1.0))) if ok and want.size else 0.0
+        worst = max(worst, err)
+        if not ok or err > 1e-5:
+            fails += 1
+            print("FAIL", dict(T=T, D=D, Ta=Ta, Da=Da, ns=ns, nsamp=nsamp, mode=mode, stream=s, err=err, sizes=(got[s].size, want.size), kernel=dm.kernel_name, chunks=chunks[:40], first_bad=int(np.argmax(np.abs(got[s] - want) / np.maximum(np.abs(want), 1.0) > 1e-5)) if ok else -1))
+    dm.close(); cases += 1
+print("fm: cases %d  failures %d  worst scaled error %.3g" % (cases, fails, worst))
+# ---- WBFM: random chunking must equal the one-shot result bit for bit, and the occupied band must match the oracle ----
+pw = pkg.lowpass_taps(128, 0.5 / 16 * 0.8); gw = pkg.lowpass_taps(60, 0.5 / 25 * 0.8) * 6.0
+t_end, wcases, wfails = time.time() + budget / 3, 0, 0
+while time.time() < t_end:
+    ns = int(rng.choice([1, 2, 4, 5])); nsamp = int(rng.integers(16, 40000))
+    iq = pkg.make_iq(ns, nsamp, mode="fm", fs=3.2e6, first_id=int(rng.integers(1 << 20)))
+    one = pkg.WbfmDemod(pkg.WbfmConfig(proto_coeffs=pw, resamp_coeffs=gw, n_streams=ns, max_bytes_per_call=1 << 18))
+    ref = one.process_batch(iq); one.close()
+    dm = pkg.WbfmDemod(pkg.WbfmConfig(proto_coeffs=pw, resamp_coeffs=gw, n_streams=ns, max_bytes_per_call=1 << 18))
+    outs, pos = [], 0
+    while pos < 2 * nsamp:
+        c = min(2 * int(rng.choice([0, 1, 15, 16, 17, 1023, 2048, 9999, 30000])), 2 * nsamp - pos)
+        outs.append(dm.process_batch(iq[:, pos:pos + c])); pos += c
+        if c == 0:
+            outs.append(dm.process_batch(iq[:, pos:pos + 2])); pos += 2
+    dm.close()
+    got = np.concatenate(outs, axis=2)
+    want0 = om.WbfmOracle(pw, gw).process(iq[0])
+    e = float(np.max(np.abs(got[0, 0] - want0[0]) / np.maximum(np.abs(want0[0]), 1.0))) if want0.shape[1] else 0.0
+    if got.shape != ref.shape or not np.array_equal(got.view(np.uint32), ref.view(np.uint32)) or e > 1e-5:
+        wfails += 1; print("WBFM FAIL", dict(ns=ns, nsamp=nsamp, shapes=(got.shape, ref.shape), err=e))
+    wcases += 1
+print("wbfm: cases %d  failures %d" % (wcases, wfails))
+fails += wfails
+sys.exit(1 if fails else 0)
