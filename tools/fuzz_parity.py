@@ -66,4 +66,51 @@ while time.time() < t_end:
     wcases += 1
 print("wbfm: cases %d  failures %d" % (wcases, wfails))
 fails += wfails
+# ---- device-resident batch path: odd row strides / unaligned chunk starts, resets in mid-stream ---------------------------
+import torch
+t_end, dcases, dfails = time.time() + budget / 3, 0, 0
+while time.time() < t_end:
+    T = int(rng.choice([16, 64])); h, g = pkg.default_config(T)
+    ns = int(rng.choice([1, 3, 16])); nsamp = int(rng.integers(2000, 80000))
+    iq_host = pkg.make_iq(ns, nsamp, mode=str(rng.choice(["fm", "random"])), first_id=int(rng.integers(1 << 20)))
+    stride = 2 * nsamp + int(rng.choice([0, 2, 4, 6, 64]))
+    dev = torch.zeros((ns, stride), dtype=torch.uint8, device="cuda"); dev[:, :2 * nsamp] = torch.from_numpy(iq_host).cuda()
+    dm = pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=ns, max_bytes_per_call=1 << 18))
+    oracles = [om.Oracle(h, g) for _ in range(ns)]
+    pos, bad = 0, 0.0
+    while pos < 2 * nsamp:
+        if rng.random() < 0.1:
+            dm.reset(); oracles = [om.Oracle(h, g) for _ in range(ns)]
+        c = min(2 * int(rng.choice([1, 3, 100, 511, 4096, 12345, 60000])), 2 * nsamp - pos)
+        cap = dm.audio_count(c) + int(rng.integers(0, 5))
+        audio = torch.full((ns, max(cap, 1)), 7.0, dtype=torch.float32, device="cuda")
+        n = dm.process_batch_device(dev[:, pos:], audio, nbytes=c)
+        dm.synchronize()
+        got = audio[:, :n].cpu().numpy()
+        for s_ in range(ns):
+            want = oracles[s_].process(iq_host[s_, pos:pos + c])
+            if want.size != n: bad = 1.0
+            elif n: bad = max(bad, float(np.max(np.abs(got[s_] - want) / np.maximum(np.abs(want), 1.0))))
+        pos += c
+    dm.close(); dcases += 1
+    if bad > 1e-5:
+        dfails += 1; print("DEVICE FAIL", dict(T=T, ns=ns, nsamp=nsamp, stride=stride, err=bad))
+print("device path: cases %d  failures %d" % (dcases, dfails))
+fails += dfails
+# ---- spectrum view: bit-identical to its oracle for random sizes / windows ---------------------------------------------------
+t_end, scases, sfails = time.time() + budget / 4, 0, 0
+while time.time() < t_end:
+    nfft = int(rng.choice([64, 128, 256, 512, 1024, 2048, 4096])); ns = int(rng.choice([1, 2, 5]))
+    nsamp = int(rng.integers(0, 12 * nfft))
+    win = None if rng.random() < 0.5 else rng.random(nfft).astype(np.float32)
+    iq = pkg.make_iq(ns, max(nsamp, 1), mode=str(rng.choice(["fm", "random", "counter"])), first_id=int(rng.integers(1 << 20)))[:, :2 * nsamp]
+    sv = pkg.SpectrumView(pkg.SpectrumConfig(nfft=nfft, window=win, n_streams=ns, max_bytes_per_call=1 << 18))
+    got, frames = sv.process_batch(iq); sv.close()
+    for s_ in range(ns):
+        want, wf = om.SpectrumOracle(nfft, win).process(iq[s_])
+        if wf != frames or not np.array_equal(got[s_].view(np.uint32), want.view(np.uint32)):
+            sfails += 1; print("SPECTRUM FAIL", dict(nfft=nfft, ns=ns, nsamp=nsamp, stream=s_, frames=(frames, wf)))
+    scases += 1
+print("spectrum: cases %d  failures %d" % (scases, sfails))
+fails += sfails
 sys.exit(1 if fails else 0)
