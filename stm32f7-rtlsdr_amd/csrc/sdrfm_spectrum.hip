@@ -63,14 +63,16 @@ __host__ __device__ constexpr int spad(int i) { return i + (i >> 4) + (i >> 8); 
 // these K stages, so a lane loads them, applies the K layers of butterflies in registers and stores them — one LDS round
 // trip per K stages instead of one per stage.  Every butterfly is the spec's (same operands, same twiddle
 // tw[position_in_stage * N/m]); only the order of independent butterflies differs from the oracle's loops.
-template <int LOGN, int S, int K>
+// LOGB >= LOGN: the wave's block holds 2^(LOGB-LOGN) independent frames side by side; stages <= LOGN never couple points of
+// different frames, so the same pass transforms all of them at once (index arithmetic over the block, twiddles of N).
+template <int LOGB, int LOGN, int S, int K>
 __device__ __forceinline__ void fft_pass(float2* X, const float2* TW, int lane) {
-  constexpr int N = 1 << LOGN, H = 1 << (S - 1), G = 1 << K, NG = N >> K;
+  constexpr int H = 1 << (S - 1), G = 1 << K, NG = (1 << LOGB) >> K;
 #pragma unroll
   for (int g0 = 0; g0 < NG; g0 += 64) {
     const int g = g0 + lane;
     if (NG >= 64 || g < NG) {
-      const int pos = g & (H - 1), base = ((g >> (S - 1)) << (S - 1 + K)) + pos;
+      const int pos = g & (H - 1), base = ((g >> (S - 1)) << (S - 1 + K)) + pos;   // (pos: position within the stage-S block)
       float2 v[G];
 #pragma unroll
       for (int c = 0; c < G; ++c) v[c] = X[spad(base + c * H)];
@@ -89,41 +91,44 @@ __device__ __forceinline__ void fft_pass(float2* X, const float2* TW, int lane) 
   }
   wave_sync();
 }
-template <int LOGN, int S>
+template <int LOGB, int LOGN, int S>
 __device__ __forceinline__ void fft_passes(float2* X, const float2* TW, int lane) {
   if constexpr (S <= LOGN) {
     // up to 4 stages per pass, but no more than leaves a group (2^K points) for each of the 64 lanes
-    constexpr int KMAX = (LOGN - 6) >= 4 ? 4 : ((LOGN - 6) >= 2 ? (LOGN - 6) : 2);
+    constexpr int KMAX = (LOGB - 6) >= 4 ? 4 : ((LOGB - 6) >= 2 ? (LOGB - 6) : 2);
     constexpr int K = (LOGN - S + 1) >= KMAX ? KMAX : (LOGN - S + 1);
-    fft_pass<LOGN, S, K>(X, TW, lane);
-    fft_passes<LOGN, S + K>(X, TW, lane);
+    fft_pass<LOGB, LOGN, S, K>(X, TW, lane);
+    fft_passes<LOGB, LOGN, S + K>(X, TW, lane);
   }
 }
 
-// frames in flight per workgroup (one wave each): 8, or 4 for 4096 points (LDS: 160 KiB per CU)
+// waves per workgroup, one block of frames each: 8, or 4 for 4096 points (LDS: 160 KiB per CU)
 constexpr int spec_nwf(int logn) { return logn <= 11 ? 8 : 4; }
+// points per wave and round: a frame, or for N < 1024 as many whole frames as make 1024 points (all 64 lanes stay busy)
+constexpr int spec_logb(int logn) { return logn < 10 ? 10 : logn; }
 
 template <int LOGN>
 __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
   constexpr int N = 1 << LOGN, NWF = spec_nwf(LOGN), NT = 64 * NWF;
-  constexpr int PPL = (N + 63) / 64;                           // points per lane of a frame's wave
+  constexpr int LOGB = spec_logb(LOGN), B = 1 << LOGB, FPW = B / N, FPR = FPW * NWF;   // block, frames per wave / per round
+  constexpr int PPL = B / 64;                                  // points per lane of a wave's block
   constexpr int PPT = (N + NT - 1) / NT;                       // bins per thread of the running sum
   extern __shared__ __attribute__((aligned(16))) unsigned char spec_smem[];
-  constexpr int NPT = spad(N / 2 - 1) + 1, NPX = spad(N - 1) + 1;   // padded sizes of the twiddle table and of a frame
+  constexpr int NPT = spad(N / 2 - 1) + 1, NPX = spad(B - 1) + 1;   // padded sizes of the twiddle table and of a block
   float2* TW = reinterpret_cast<float2*>(spec_smem);           // N/2 twiddles at TW[spad(t)]
   const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  float2* X = reinterpret_cast<float2*>(spec_smem) + NPT + wv * NPX;   // this wave's frame: point i at X[spad(i)]
-  const float* PW = reinterpret_cast<const float*>(reinterpret_cast<float2*>(spec_smem) + NPT);   // wave w's powers at PW[2 NPX w + k]
+  float2* X = reinterpret_cast<float2*>(spec_smem) + NPT + wv * NPX;   // this wave's block: point i at X[spad(i)]
+  const float* PW = reinterpret_cast<const float*>(reinterpret_cast<float2*>(spec_smem) + NPT);   // wave w's powers at PW[2 NPX w + i]
   const uint32_t stream = blockIdx.x;
   for (int i = tid; i < N / 2; i += NT) TW[spad(i)] = p.tw[i];
   // up to 1024 points the lane keeps its window values and the next round's samples in registers; longer frames would
   // need > 256 VGPRs for that, so they read the window through the cache and load their samples when they need them
-  constexpr bool REGS = (LOGN <= 10);
+  constexpr bool REGS = (LOGB <= 10);
   constexpr int PR = REGS ? PPL : 1;
   float wv_win[PR], S[PPT];
   if constexpr (REGS) {
 #pragma unroll
-    for (int q = 0; q < PPL; ++q) { const int n = lane + 64 * q; wv_win[q] = n < N ? p.win[n] : 0.0f; }
+    for (int q = 0; q < PPL; ++q) wv_win[q] = p.win[(lane + 64 * q) & (N - 1)];
   }
 #pragma unroll
   for (int q = 0; q < PPT; ++q) S[q] = 0.0f;
@@ -131,26 +136,24 @@ __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
   const si4_t rsrc = {(int)(unsigned)ga, (int)(unsigned)(ga >> 32), (int)p.iq_span, SDRFM_SPEC_RSRC_U8X2};
   const uint32_t sbase = stream * (uint32_t)p.iq_stride;
   sf2_t cur[PR];
-  auto fetch = [&](uint32_t f) {                               // frame f of this stream -> cur (out-of-range reads return 0)
+  auto fetch = [&](uint32_t f) {                               // the block starting at frame f -> cur (out-of-range reads return 0)
     if constexpr (REGS) {
 #pragma unroll
       for (int q = 0; q < PPL; ++q)
         cur[q] = spec_typed_load_xy(rsrc, (int)(sbase + 2u * (f * (uint32_t)N + (uint32_t)(lane + 64 * q))), 0, 0);
     }
   };
-  if ((uint32_t)wv < p.F) fetch((uint32_t)wv);
+  if ((uint32_t)(wv * FPW) < p.F) fetch((uint32_t)(wv * FPW));
   __syncthreads();                                             // TW visible
-  for (uint32_t f0 = 0; f0 < p.F; f0 += NWF) {                 // a round: frames f0 .. f0+NWF-1, one per wave
-    const uint32_t f = f0 + (uint32_t)wv;
-    if (f < p.F) {                                             // (wave-uniform)
+  for (uint32_t f0 = 0; f0 < p.F; f0 += FPR) {                 // a round: frames f0 .. f0+FPR-1, FPW consecutive ones per wave
+    const uint32_t f = f0 + (uint32_t)(wv * FPW);
+    if (f < p.F) {                                             // (wave-uniform; frames past F in the block are computed, not summed)
       if constexpr (REGS) {
 #pragma unroll
         for (int q = 0; q < PPL; ++q) {
-          const int n = lane + 64 * q;
-          if (n < N) {
-            const uint32_t u = __brev((uint32_t)n) >> (32 - LOGN);
-            X[spad((int)u)] = make_float2((cur[q].x - 127.5f) * wv_win[q], (cur[q].y - 127.5f) * wv_win[q]);
-          }
+          const int n = lane + 64 * q;                         // sample n of the block = sample n mod N of frame n / N
+          const uint32_t u = (uint32_t)(n & ~(N - 1)) | (__brev((uint32_t)(n & (N - 1))) >> (32 - LOGN));
+          X[spad((int)u)] = make_float2((cur[q].x - 127.5f) * wv_win[q], (cur[q].y - 127.5f) * wv_win[q]);
         }
       } else {
 #pragma unroll 8
@@ -161,11 +164,11 @@ __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
           X[spad((int)(__brev((uint32_t)n) >> (32 - LOGN)))] = make_float2((c.x - 127.5f) * wn, (c.y - 127.5f) * wn);
         }
       }
-      if (f + NWF < p.F) fetch(f + NWF);                       // next round's bytes: in flight during this frame's FFT
+      if (f + FPR < p.F) fetch(f + FPR);                       // next round's bytes: in flight during this block's FFTs
       wave_sync();
       // DIT stages in passes of up to 4 stages, each pass entirely in registers (see fft_pass)
-      fft_passes<LOGN, 1>(X, TW, lane);
-      // powers of this frame, written over the start of its own region (PW[2 NPX wv + k]) in blocks of 16 points per lane:
+      fft_passes<LOGB, LOGN, 1>(X, TW, lane);
+      // powers of this block, written over the start of its own region (PW[2 NPX wv + i]) in blocks of 16 points per lane:
       // block b overwrites float slots [1024 b, 1024 b + 1024), i.e. float2 slots below 512 (b + 1) — points already consumed
       // (a point's padded slot is never below its index)
       constexpr int PB = PPL < 16 ? PPL : 16;
@@ -173,28 +176,26 @@ __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
         float pw[PB];
 #pragma unroll
         for (int q = 0; q < PB; ++q) {
-          const int k = lane + 64 * (q0 + q);
-          if (k < N) { const float2 v = X[spad(k)]; pw[q] = __builtin_fmaf(v.x, v.x, v.y * v.y); }
+          const float2 v = X[spad(lane + 64 * (q0 + q))];
+          pw[q] = __builtin_fmaf(v.x, v.x, v.y * v.y);
         }
         wave_sync();
 #pragma unroll
-        for (int q = 0; q < PB; ++q) {
-          const int k = lane + 64 * (q0 + q);
-          if (k < N) reinterpret_cast<float*>(X)[k] = pw[q];
-        }
+        for (int q = 0; q < PB; ++q) reinterpret_cast<float*>(X)[lane + 64 * (q0 + q)] = pw[q];
         wave_sync();
       }
     }
     __syncthreads();
-    // the spec's sum over frames is sequential: add this round's frames in frame order
-    const uint32_t nfr = (p.F - f0) < (uint32_t)NWF ? (p.F - f0) : (uint32_t)NWF;
+    // the spec's sum over frames is sequential: add this round's frames in frame order (frame o of the round = frame
+    // o mod FPW of wave o / FPW)
+    const uint32_t nfr = (p.F - f0) < (uint32_t)FPR ? (p.F - f0) : (uint32_t)FPR;
 #pragma unroll
     for (int q = 0; q < PPT; ++q) {
       const int k = tid + NT * q;
       if (k < N)
-        for (uint32_t w = 0; w < nfr; ++w) S[q] = S[q] + PW[2 * NPX * w + k];
+        for (uint32_t o = 0; o < nfr; ++o) S[q] = S[q] + PW[2 * NPX * (o / FPW) + (o % FPW) * N + k];
     }
-    __syncthreads();                                           // the frames are rewritten by the next round
+    __syncthreads();                                           // the blocks are rewritten by the next round
   }
 #pragma unroll
   for (int q = 0; q < PPT; ++q) {
@@ -270,7 +271,7 @@ int sdrfm_spectrum_create(const sdrfm_spectrum_config* cfg, sdrfm_spectrum_t** o
   h->device = cfg->device; h->logn = logn;
   h->max_bytes = cfg->max_bytes_per_call ? cfg->max_bytes_per_call : (1u << 20);
   h->kernel = pick_kernel(logn);
-  h->lds_bytes = ((size_t)(spad((int)cfg->nfft / 2 - 1) + 1) + (size_t)spec_nwf((int)logn) * (size_t)(spad((int)cfg->nfft - 1) + 1)) * sizeof(float2);
+  h->lds_bytes = ((size_t)(spad((int)cfg->nfft / 2 - 1) + 1) + (size_t)spec_nwf((int)logn) * (size_t)(spad((1 << spec_logb((int)logn)) - 1) + 1)) * sizeof(float2);
 #define CR(expr) do { if ((expr) != hipSuccess) { sfree(h); return SDRFM_ENOMEM; } } while (0)
   CR(hipSetDevice(h->device));
   if (h->lds_bytes > 64 * 1024 &&

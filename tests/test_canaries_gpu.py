@@ -19,6 +19,7 @@ def test_fm_batch_writes_only_its_audio(pkg, oracle_mod):
     pad, stride = 64, n_expected + 37
     big = torch.full((pad + ns * stride + pad,), SENT, dtype=torch.float32, device="cuda")
     audio = big[pad:pad + ns * stride].view(ns, stride)
+    torch.cuda.synchronize()                                         # fills ran on torch's stream, the library uses its own
     for rep in range(3):                                             # first call (fix-up launch) and steady state
         n = dm.process_batch_device(iq, audio)
         dm.synchronize()
@@ -42,6 +43,7 @@ def test_wbfm_batch_writes_only_its_audio(pkg):
     pad, stride = 64, n_expected + 21
     big = torch.full((pad + ns * 16 * stride + pad,), SENT, dtype=torch.float32, device="cuda")
     audio = big[pad:pad + ns * 16 * stride].view(ns, 16, stride)
+    torch.cuda.synchronize()
     for _ in range(2):
         n = dm.process_batch_device(iq, audio)
         dm.synchronize()

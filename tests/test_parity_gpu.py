@@ -159,6 +159,7 @@ def test_device_resident_batch_full_size_config3(pkg, oracle_mod):
     iq_host = np.tile(distinct, (ns // 16, 1))
     iq = torch.from_numpy(iq_host).cuda()
     audio = torch.zeros((ns, 4800), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()    # allocations / fills ran on torch's stream; the library uses its own
     n = dm.process_batch_device(iq, audio)
     dm.synchronize()
     assert n == 4800
@@ -172,6 +173,7 @@ def test_device_resident_batch_full_size_config3(pkg, oracle_mod):
     dm.reset()
     a1 = torch.zeros((ns, 2400), dtype=torch.float32, device="cuda")
     a2 = torch.zeros((ns, 2400), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()    # allocations / fills ran on torch's stream; the library uses its own
     half = nsamp  # bytes
     assert dm.process_batch_device(iq[:, :half], a1, nbytes=half) == 2400
     assert dm.process_batch_device(iq[:, half:], a2, nbytes=half) == 2400

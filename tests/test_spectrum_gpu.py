@@ -46,6 +46,7 @@ def test_golden_vectors_custom_window_and_device_buffers(pkg):
         assert np.array_equal(got[0].view(np.uint32), z["power"].view(np.uint32)), fn
         iq = torch.from_numpy(z["iq"][None, :].copy()).cuda()
         power = torch.full((1, nfft + 8), -1.0, dtype=torch.float32, device="cuda")     # padded rows: stride > nfft
+        torch.cuda.synchronize()    # allocations / fills ran on torch's stream; the library uses its own
         assert sv.process_batch_device(iq, power) == frames
         sv.synchronize()
         assert np.array_equal(power[0, :nfft].cpu().numpy().view(np.uint32), z["power"].view(np.uint32))

@@ -83,6 +83,7 @@ def test_device_buffers_and_errors(pkg, oracle_mod):
     iq_host = pkg.make_iq(4, 32000, mode="fm", fs=3.2e6, first_id=50)
     iq = torch.from_numpy(iq_host).cuda()
     audio = torch.zeros((4, 16, 500), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()    # allocations / fills ran on torch's stream; the library uses its own
     n = dm.process_batch_device(iq, audio)
     dm.synchronize()
     assert n == 480

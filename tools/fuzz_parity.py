@@ -8,9 +8,15 @@ pkg = importlib.import_module("stm32f7-rtlsdr_amd")
 from oracle import oracle as om  # the checker
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+only = sys.argv[3] if len(sys.argv) > 3 else ""          # "fm", "wbfm", "device", "spectrum" or empty = all
+rng = np.random.default_rng(seed)
+if only and only != "fm":
+    budget_fm = 0.0
+else:
+    budget_fm = budget
 GEOMS = [(64, 10, 32, 5), (16, 10, 32, 5), (32, 10, 32, 5), (64, 8, 32, 8), (64, 16, 32, 5), (64, 4, 32, 8), (7, 3, 5, 4), (128, 16, 64, 6), (2, 2, 2, 2)]
-t_end, cases, fails, worst = time.time() + budget, 0, 0, 0.0
+t_end, cases, fails, worst = time.time() + budget_fm, 0, 0, 0.0
 while time.time() < t_end:
     T, D, Ta, Da = GEOMS[rng.integers(len(GEOMS))]
     if (T, D) in ((64, 10), (16, 10)):
@@ -44,7 +50,8 @@ while time.time() < t_end:
 print("fm: cases %d  failures %d  worst scaled error %.3g" % (cases, fails, worst))
 # ---- WBFM: random chunking must equal the one-shot result bit for bit, and the occupied band must match the oracle ----
 pw = pkg.lowpass_taps(128, 0.5 / 16 * 0.8); gw = pkg.lowpass_taps(60, 0.5 / 25 * 0.8) * 6.0
-t_end, wcases, wfails = time.time() + budget / 3, 0, 0
+rng = np.random.default_rng(seed + 1)
+t_end, wcases, wfails = time.time() + (budget / 3 if only in ("", "wbfm") else 0.0), 0, 0
 while time.time() < t_end:
     ns = int(rng.choice([1, 2, 4, 5])); nsamp = int(rng.integers(16, 40000))
     iq = pkg.make_iq(ns, nsamp, mode="fm", fs=3.2e6, first_id=int(rng.integers(1 << 20)))
@@ -68,37 +75,46 @@ print("wbfm: cases %d  failures %d" % (wcases, wfails))
 fails += wfails
 # ---- device-resident batch path: odd row strides / unaligned chunk starts, resets in mid-stream ---------------------------
 import torch
-t_end, dcases, dfails = time.time() + budget / 3, 0, 0
+rng = np.random.default_rng(seed + 2)
+t_end, dcases, dfails = time.time() + (budget / 3 if only in ("", "device") else 0.0), 0, 0
 while time.time() < t_end:
     T = int(rng.choice([16, 64])); h, g = pkg.default_config(T)
     ns = int(rng.choice([1, 3, 16])); nsamp = int(rng.integers(2000, 80000))
     iq_host = pkg.make_iq(ns, nsamp, mode=str(rng.choice(["fm", "random"])), first_id=int(rng.integers(1 << 20)))
     stride = 2 * nsamp + int(rng.choice([0, 2, 4, 6, 64]))
     dev = torch.zeros((ns, stride), dtype=torch.uint8, device="cuda"); dev[:, :2 * nsamp] = torch.from_numpy(iq_host).cuda()
+    torch.cuda.synchronize()
     dm = pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=ns, max_bytes_per_call=1 << 18))
     oracles = [om.Oracle(h, g) for _ in range(ns)]
-    pos, bad = 0, 0.0
+    pos, bad, where, log = 0, 0.0, None, []
     while pos < 2 * nsamp:
         if rng.random() < 0.1:
             dm.reset(); oracles = [om.Oracle(h, g) for _ in range(ns)]
         c = min(2 * int(rng.choice([1, 3, 100, 511, 4096, 12345, 60000])), 2 * nsamp - pos)
         cap = dm.audio_count(c) + int(rng.integers(0, 5))
         audio = torch.full((ns, max(cap, 1)), 7.0, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()                               # the fill runs on torch's stream, the library on its own
         n = dm.process_batch_device(dev[:, pos:], audio, nbytes=c)
         dm.synchronize()
         got = audio[:, :n].cpu().numpy()
+        log.append((pos, c, n, dm.kernel_name.split()[0]))
         for s_ in range(ns):
             want = oracles[s_].process(iq_host[s_, pos:pos + c])
             if want.size != n: bad = 1.0
-            elif n: bad = max(bad, float(np.max(np.abs(got[s_] - want) / np.maximum(np.abs(want), 1.0))))
+            elif n:
+                e = np.abs(got[s_] - want) / np.maximum(np.abs(want), 1.0)
+                if e.max() > 1e-5 and where is None:
+                    where = dict(call=len(log) - 1, stream=s_, index=int(np.argmax(e)), n=n, got=float(got[s_][int(np.argmax(e))]), nbad=int((e > 1e-5).sum()))
+                bad = max(bad, float(e.max()))
         pos += c
     dm.close(); dcases += 1
     if bad > 1e-5:
-        dfails += 1; print("DEVICE FAIL", dict(T=T, ns=ns, nsamp=nsamp, stride=stride, err=bad))
+        dfails += 1; print("DEVICE FAIL", dict(T=T, ns=ns, nsamp=nsamp, stride=stride, err=bad, where=where, calls=log[:where["call"] + 1][-6:] if where else log[-6:]))
 print("device path: cases %d  failures %d" % (dcases, dfails))
 fails += dfails
 # ---- spectrum view: bit-identical to its oracle for random sizes / windows ---------------------------------------------------
-t_end, scases, sfails = time.time() + budget / 4, 0, 0
+rng = np.random.default_rng(seed + 3)
+t_end, scases, sfails = time.time() + (budget / 4 if only in ("", "spectrum") else 0.0), 0, 0
 while time.time() < t_end:
     nfft = int(rng.choice([64, 128, 256, 512, 1024, 2048, 4096])); ns = int(rng.choice([1, 2, 5]))
     nsamp = int(rng.integers(0, 12 * nfft))
