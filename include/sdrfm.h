@@ -62,7 +62,10 @@ enum {
 
 /* flags for sdrfm_process_batch */
 #define SDRFM_F_DEVICE_PTRS 1u    /* iq and audio are device pointers on cfg.device; call is enqueued on the
-                                     handle's stream and returns without synchronising */
+                                     handle's stream and returns without synchronising.  The handle's own stream is
+                                     created non-blocking: it does NOT order itself against the null stream or any
+                                     other stream, so work that produces iq or touches audio elsewhere must be
+                                     synchronised by the caller, or the caller's stream given via sdrfm_set_stream */
 
 typedef struct sdrfm_config {
   uint32_t struct_size;           /* = sizeof(sdrfm_config) */
