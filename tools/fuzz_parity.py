@@ -9,7 +9,7 @@ from oracle import oracle as om  # the checker
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-only = sys.argv[3] if len(sys.argv) > 3 else ""          # "fm", "wbfm", "device", "spectrum" or empty = all
+only = sys.argv[3] if len(sys.argv) > 3 else ""          # "fm", "wbfm", "device", "spectrum", "ring" or empty = all
 rng = np.random.default_rng(seed)
 if only and only != "fm":
     budget_fm = 0.0
@@ -129,4 +129,46 @@ while time.time() < t_end:
     scases += 1
 print("spectrum: cases %d  failures %d" % (scases, sfails))
 fails += sfails
+# ---- pinned ring (sdrfm_ring_*): random slot geometry and chunk sizes, non-blocking submit / collect, audio in order ----------
+import ctypes as C
+rng = np.random.default_rng(seed + 4)
+lib = pkg.load_library()
+t_end, rcases, rfails = time.time() + (budget / 4 if only in ("", "ring") else 0.0), 0, 0
+while time.time() < t_end:
+    T = int(rng.choice([16, 64])); h, g = pkg.default_config(T)
+    slots = int(rng.integers(2, 9)); slot_bytes = 2 * int(rng.choice([256, 1000, 4096, 32768, 131072]))
+    nsamp = int(rng.integers(1, 40 * slot_bytes // 2 + 2)) if slot_bytes <= 8192 else int(rng.integers(1, 400000))
+    iq = pkg.make_iq(1, nsamp, mode=str(rng.choice(["fm", "random"])), first_id=int(rng.integers(1 << 20)))[0]
+    dm = pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, max_bytes_per_call=262144))
+    ring = C.c_void_p()
+    assert lib.sdrfm_ring_create(dm._h, slots, slot_bytes, C.byref(ring)) == 0
+    buf = np.empty(slot_bytes // 2 // 10 // 5 + 8, np.float32); n = C.c_uint32()
+    out, pos, guard = [], 0, 0
+    while True:
+        guard += 1
+        if guard > 10 ** 6: break
+        if pos < iq.size and rng.random() < 0.7:
+            m = min(2 * int(rng.integers(0, slot_bytes // 2 + 1)), iq.size - pos)
+            chunk = np.ascontiguousarray(iq[pos:pos + m]) if m else np.zeros(2, np.uint8)
+            st = lib.sdrfm_ring_submit(ring, chunk.ctypes.data, m)
+            if st == 0: pos += m
+            elif st != 1: rfails += 1; print("RING submit status", st); break
+            continue
+        st = lib.sdrfm_ring_collect(ring, buf.ctypes.data, buf.size, C.byref(n), int(rng.random() < 0.5))
+        if st == 0: out.append(buf[: n.value].copy())
+        elif st == 1:
+            if pos >= iq.size:
+                st2 = lib.sdrfm_ring_collect(ring, buf.ctypes.data, buf.size, C.byref(n), 1)
+                if st2 == 0: out.append(buf[: n.value].copy())
+                else: break
+        else: rfails += 1; print("RING collect status", st); break
+    lib.sdrfm_ring_destroy(ring); dm.close()
+    got = np.concatenate(out) if out else np.zeros(0, np.float32)
+    want = om.Oracle(h, g).process(iq)
+    e = float(np.max(np.abs(got - want) / np.maximum(np.abs(want), 1.0))) if got.size == want.size and want.size else 0.0
+    if got.size != want.size or e > 1e-5:
+        rfails += 1; print("RING FAIL", dict(T=T, slots=slots, slot_bytes=slot_bytes, nsamp=nsamp, sizes=(got.size, want.size), err=e))
+    rcases += 1
+print("ring: cases %d  failures %d" % (rcases, rfails))
+fails += rfails
 sys.exit(1 if fails else 0)
