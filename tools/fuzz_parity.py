@@ -55,9 +55,15 @@ t_end, wcases, wfails = time.time() + (budget / 3 if only in ("", "wbfm") else 0
 while time.time() < t_end:
     ns = int(rng.choice([1, 2, 4, 5])); nsamp = int(rng.integers(16, 40000))
     iq = pkg.make_iq(ns, nsamp, mode="fm", fs=3.2e6, first_id=int(rng.integers(1 << 20)))
-    one = pkg.WbfmDemod(pkg.WbfmConfig(proto_coeffs=pw, resamp_coeffs=gw, n_streams=ns, max_bytes_per_call=1 << 18))
+    if rng.random() < 0.5:
+        pwc, gwc, L, M = pw, gw, 6, 25                              # the BASELINE shape (fused kernel)
+    else:                                                          # other prototypes / ratios (generic kernels, or fused when P = 128)
+        P = int(rng.choice([16, 64, 128, 256])); L, M = [(6, 25), (1, 4), (3, 10), (2, 5), (1, 1)][int(rng.integers(5))]
+        pwc = pkg.lowpass_taps(P, 0.5 / 16 * 0.8); gwc = (pkg.lowpass_taps(int(rng.integers(L, 12 * L + 1)), 0.4 / max(L, M)) * L).astype(np.float32)
+    wkw = dict(proto_coeffs=pwc, resamp_coeffs=gwc, resamp_up=L, resamp_down=M, n_streams=ns, max_bytes_per_call=1 << 18)
+    one = pkg.WbfmDemod(pkg.WbfmConfig(**wkw))
     ref = one.process_batch(iq); one.close()
-    dm = pkg.WbfmDemod(pkg.WbfmConfig(proto_coeffs=pw, resamp_coeffs=gw, n_streams=ns, max_bytes_per_call=1 << 18))
+    dm = pkg.WbfmDemod(pkg.WbfmConfig(**wkw))
     outs, pos = [], 0
     while pos < 2 * nsamp:
         c = min(2 * int(rng.choice([0, 1, 15, 16, 17, 1023, 2048, 9999, 30000])), 2 * nsamp - pos)
@@ -66,10 +72,10 @@ while time.time() < t_end:
             outs.append(dm.process_batch(iq[:, pos:pos + 2])); pos += 2
     dm.close()
     got = np.concatenate(outs, axis=2)
-    want0 = om.WbfmOracle(pw, gw).process(iq[0])
+    want0 = om.WbfmOracle(pwc, gwc, L, M).process(iq[0])
     e = float(np.max(np.abs(got[0, 0] - want0[0]) / np.maximum(np.abs(want0[0]), 1.0))) if want0.shape[1] else 0.0
     if got.shape != ref.shape or not np.array_equal(got.view(np.uint32), ref.view(np.uint32)) or e > 1e-5:
-        wfails += 1; print("WBFM FAIL", dict(ns=ns, nsamp=nsamp, shapes=(got.shape, ref.shape), err=e))
+        wfails += 1; print("WBFM FAIL", dict(ns=ns, nsamp=nsamp, P=pwc.size, Tg=gwc.size, L=L, M=M, shapes=(got.shape, ref.shape), err=e))
     wcases += 1
 print("wbfm: cases %d  failures %d" % (wcases, wfails))
 fails += wfails
