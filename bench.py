@@ -26,8 +26,8 @@ HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI3
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--streams-per-gpu", type=int, default=256)
     ap.add_argument("--seconds", type=float, default=0.1, help="capture length per stream per step")
     ap.add_argument("--fir-taps", type=int, default=64)
