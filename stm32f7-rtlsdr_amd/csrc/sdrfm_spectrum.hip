@@ -68,7 +68,8 @@ __host__ __device__ constexpr int spad(int i) { return i + (i >> 4) + (i >> 8); 
 template <int LOGB, int LOGN, int S, int K>
 __device__ __forceinline__ void fft_pass(float2* X, const float2* TW, int lane) {
   constexpr int H = 1 << (S - 1), G = 1 << K, NG = (1 << LOGB) >> K;
-#pragma unroll
+  constexpr int UNR = LOGB >= 12 ? 1 : 4;                      // (4096 points: 16 points x 4 groups unrolled would not fit in VGPRs)
+#pragma unroll UNR
   for (int g0 = 0; g0 < NG; g0 += 64) {
     const int g = g0 + lane;
     if (NG >= 64 || g < NG) {
