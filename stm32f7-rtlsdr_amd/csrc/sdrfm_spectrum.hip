@@ -103,8 +103,9 @@ __device__ __forceinline__ void fft_passes(float2* X, const float2* TW, int lane
   }
 }
 
-// waves per workgroup, one block of frames each: 8, or 4 for 4096 points (LDS: 160 KiB per CU)
-constexpr int spec_nwf(int logn) { return logn <= 11 ? 8 : 4; }
+// waves per workgroup, one block of frames each: 8, or 4 for 4096 points (LDS: 160 KiB per CU); the short-frame kernels fit
+// 128 VGPRs without the prefetch registers and run 16 waves, which hide the load latency instead
+constexpr int spec_nwf(int logn) { return logn <= 8 ? 16 : (logn <= 11 ? 8 : 4); }
 // points per wave and round: a frame, or for N < 1024 as many whole frames as make 1024 points (all 64 lanes stay busy)
 constexpr int spec_logb(int logn) { return logn < 10 ? 10 : logn; }
 
@@ -124,7 +125,7 @@ __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
   for (int i = tid; i < N / 2; i += NT) TW[spad(i)] = p.tw[i];
   // up to 1024 points the lane keeps its window values and the next round's samples in registers; longer frames would
   // need > 256 VGPRs for that, so they read the window through the cache and load their samples when they need them
-  constexpr bool REGS = (LOGB <= 10);
+  constexpr bool REGS = (LOGB <= 10) && (NWF <= 8);
   constexpr int PR = REGS ? PPL : 1;
   float wv_win[PR], S[PPT];
   if constexpr (REGS) {
@@ -161,8 +162,8 @@ __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
         for (int q = 0; q < PPL; ++q) {
           const int n = lane + 64 * q;
           const sf2_t c = spec_typed_load_xy(rsrc, (int)(sbase + 2u * (f * (uint32_t)N + (uint32_t)n)), 0, 0);
-          const float wn = p.win[n];
-          X[spad((int)(__brev((uint32_t)n) >> (32 - LOGN)))] = make_float2((c.x - 127.5f) * wn, (c.y - 127.5f) * wn);
+          const float wn = p.win[n & (N - 1)];
+          X[spad((int)((uint32_t)(n & ~(N - 1)) | (__brev((uint32_t)(n & (N - 1))) >> (32 - LOGN))))] = make_float2((c.x - 127.5f) * wn, (c.y - 127.5f) * wn);
         }
       }
       if (f + FPR < p.F) fetch(f + FPR);                       // next round's bytes: in flight during this block's FFTs
