@@ -291,7 +291,8 @@ def main_wbfm(args, pkg, world, rank, local_rank):
                                       "channelizer + per-band FM demod + 6/25 resampler -> 16 x 48 kHz" % (ns, args.seconds),
                           "streams_per_gpu": ns, "bytes_per_stream": 2 * nsamp, "kernel": kname},
                "roofline": {"bound": "hbm", "achieved": round(alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                            "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None, "kernel_ms_avg": round(ms, 4),
+                            "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                            "traffic": (latest_traffic(kname) or {}).get("hbm_bytes_per_launch"), "kernel_ms_avg": round(ms, 4),
                             "algorithmic_bytes_per_launch": alg}}
         print(json.dumps(res), flush=True)
     dm.set_stream(None)
@@ -350,8 +351,9 @@ def main_spectrum(args, pkg, world, rank, local_rank):
                                       "%d-point Hann FFT, %d frames averaged per stream" % (ns, args.seconds, nfft, frames),
                           "streams_per_gpu": ns, "bytes_per_stream": 2 * nsamp, "kernel": "k_spectrum<%d>" % int(np.log2(nfft))},
                "roofline": {"bound": "hbm", "achieved": round(alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                            "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None, "kernel_ms_avg": round(ms, 4),
-                            "algorithmic_bytes_per_launch": alg}}
+                            "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                            "traffic": (latest_traffic("k_spectrum<%d>" % int(np.log2(nfft))) or {}).get("hbm_bytes_per_launch"),
+                            "kernel_ms_avg": round(ms, 4), "algorithmic_bytes_per_launch": alg}}
         print(json.dumps(res), flush=True)
     sv.set_stream(None)
     sv.close()
