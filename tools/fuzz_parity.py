@@ -15,7 +15,8 @@ if only and only != "fm":
     budget_fm = 0.0
 else:
     budget_fm = budget
-GEOMS = [(64, 10, 32, 5), (16, 10, 32, 5), (32, 10, 32, 5), (64, 8, 32, 8), (64, 16, 32, 5), (64, 4, 32, 8), (7, 3, 5, 4), (128, 16, 64, 6), (2, 2, 2, 2)]
+GEOMS = [(64, 10, 32, 5), (16, 10, 32, 5), (32, 10, 32, 5), (64, 8, 32, 8), (64, 16, 32, 5), (64, 4, 32, 8), (7, 3, 5, 4), (128, 16, 64, 6), (2, 2, 2, 2),
+         (1, 1, 1, 1), (4, 10, 3, 7), (256, 10, 256, 5), (256, 64, 256, 64), (5, 1, 9, 1), (33, 64, 2, 3)]
 t_end, cases, fails, worst = time.time() + budget_fm, 0, 0, 0.0
 while time.time() < t_end:
     T, D, Ta, Da = GEOMS[rng.integers(len(GEOMS))]
