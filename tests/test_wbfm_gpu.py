@@ -145,3 +145,15 @@ def test_degenerate_inputs_match_oracle_exactly_in_sign(pkg, oracle_mod, monkeyp
         for s in range(3):
             want = oracle_mod.WbfmOracle(p, g).process(iq[s])
             assert scaled_err(got[s], want) <= TOL, (env, s)
+
+
+def test_golden_vector_on_gpu(pkg):
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wbfm_three_carriers.npz"))
+    dm = pkg.WbfmDemod(pkg.WbfmConfig(proto_coeffs=z["p"], resamp_coeffs=z["g"], resamp_up=int(z["L"]), resamp_down=int(z["M"])))
+    got = dm.process_batch(z["iq"])[0]
+    assert got.shape == z["audio"].shape
+    for b in z["bands"]:                                               # the three occupied bands: every sample within tolerance
+        assert scaled_err(got[int(b)], z["audio"][int(b)]) <= TOL, int(b)
+    assert np.mean(_err(got, z["audio"]) <= TOL) > 0.995               # noise-only bands: branch-cut flips are rare
+    dm.close()

@@ -79,3 +79,11 @@ def test_channelizer_matches_direct_dft_definition(pkg, oracle_mod):
     # fp32 path vs float64 definition: the +-pi wrap of a noisy empty band can flip, so compare the occupied band only
     occ = int(np.argmax(np.mean(np.abs(c), axis=1)))
     assert np.max(np.abs(a[occ] - want[occ])) < 2e-4
+
+
+def test_golden_vector(oracle_mod):
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wbfm_three_carriers.npz"))
+    got = oracle_mod.WbfmOracle(z["p"], z["g"], int(z["L"]), int(z["M"])).process(z["iq"])
+    assert got.shape == z["audio"].shape
+    assert np.array_equal(got.view(np.uint32), z["audio"].view(np.uint32))
