@@ -37,7 +37,10 @@ def stats(got, want):
         hist[label] = int(np.count_nonzero((u >= lo) & (u < hi)))
     return {"n": int(got.size), "max_abs": float(d.max(initial=0.0)),
             "max_scaled": float((d / np.maximum(np.abs(want), 1.0)).max(initial=0.0)),
-            "bit_equal_fraction": float(np.mean(u == 0)) if got.size else 1.0, "ulp_histogram": hist}
+            "bit_equal_fraction": float(np.mean(u == 0)) if got.size else 1.0,
+            "max_ulp": int(u.max(initial=0)),
+            "fraction_within_pure_relative_1e-5": float(np.mean(d <= 1e-5 * np.abs(want.astype(np.float64)))) if got.size else 1.0,
+            "ulp_histogram": hist}
 
 
 def main(out):
