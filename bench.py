@@ -39,6 +39,9 @@ def parse():
                     help="fm = BASELINE configs[2] (default, the headline); wbfm = configs[4] channelizer path, 128 streams/GPU; "
                          "spectrum = FFT view (SURVEY 8f-3) of the configs[2] buffers")
     ap.add_argument("--nfft", type=int, default=1024, help="spectrum workload: FFT length")
+    ap.add_argument("--end-to-end", action="store_true",
+                    help="fm workload: every step also scatters the IQ batch from rank 0 to all ranks and gathers the audio back "
+                         "over RCCL (SURVEY 8e C1/C2); reported separately from the compute-only default")
     return ap.parse_args()
 
 
@@ -140,8 +143,26 @@ def main():
         audio = torch.zeros((ns, n_audio_max), dtype=torch.float32, device="cuda")
     stream.synchronize()
 
+    e2e = None
+    if args.end_to_end:
+        # rank 0 owns the whole batch; each step = C1 scatter -> local hot path -> C2 gather, all on `stream`
+        if not dist.is_initialized():
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1,
+                                    device_id=torch.device("cuda", local_rank))
+        fan = pkg.fanout
+        with torch.cuda.stream(stream):
+            iq_all = torch.from_numpy(np.tile(iq_host, (world, 1))).cuda() if rank == 0 else None
+        stream.synchronize()
+        e2e = {"iq_all": iq_all, "total": world * ns}
+
     def step():
-        return dm.process_batch_device(iq, audio)
+        if e2e is None:
+            return dm.process_batch_device(iq, audio)
+        with torch.cuda.stream(stream):
+            local = pkg.fanout.scatter_streams(e2e["iq_all"], e2e["total"], nbytes, iq.device)
+            n = dm.process_batch_device(local, audio)
+            pkg.fanout.gather_audio(audio[:, :n], e2e["total"])
+        return n
 
     def fence():
         torch.cuda.synchronize()
@@ -200,6 +221,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "mode": "end-to-end (RCCL scatter of IQ from rank 0 + gather of audio every step)" if args.end_to_end else "compute-only (IQ resident per GPU)",
             "config": {"workload": "BASELINE configs[2]: %d concurrent 2.4 MS/s uint8 IQ streams per GPU x %.1f s (%d B each), "
                                    "%d-tap FIR /%d + FM discriminator + %d-tap /%d -> 48 kHz; device-resident, streams sharded "
                                    "across GPUs with no collective" % (ns, args.seconds, nbytes, args.fir_taps, D, len(g), Da),
@@ -222,7 +244,7 @@ def main():
         print(json.dumps(res), flush=True)
     dm.set_stream(None)
     dm.close()
-    if use_dist:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
