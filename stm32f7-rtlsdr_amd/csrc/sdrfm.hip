@@ -776,7 +776,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 3)))
         constexpr int j = j8 * 8 + s;                         // window position; output r uses positions OFF+r*D .. +T-1
         if constexpr (j >= OFF && j < OFF + NW) {
           const unsigned w = (s / 2 == 0) ? cur.x : (s / 2 == 1) ? cur.y : (s / 2 == 2) ? cur.z : cur.w;
-          const f2_t x = cvt_iq<(s & 1)>(w);
+          f2_t x;
+          if constexpr (MODE == 2 && j < OFF + HALO) { x = f2_t{__uint_as_float(w), __uint_as_float(w)}; }   // ablation: halo not converted
+          else if constexpr (MODE == 3) { x = f2_t{__uint_as_float(w), __uint_as_float(w)}; }                 // ablation: nothing converted
+          else x = cvt_iq<(s & 1)>(w);
           static_for<0, R>([&](auto RR) {
             constexpr int r = decltype(RR)::value;
             constexpr int p0 = j - OFF - r * D;               // 0 = oldest sample of output r
@@ -936,12 +939,14 @@ struct FastVariant {
 #define SDRFM_FAST(T_, D_, R_) { 'a', T_, D_, R_, 0, 0, {k_fast<T_, D_, R_, 0>, k_fast<T_, D_, R_, 1>, k_fast<T_, D_, R_, 2>, k_fast<T_, D_, R_, 3>, k_fast<T_, D_, R_, 4>, k_fast<T_, D_, R_, 5>, k_fast<T_, D_, R_, 6>, k_fast<T_, D_, R_, 7>}, (uint32_t)fast_xbytes(T_, D_, R_) }
 #define SDRFM_FAST_LITE(T_, D_, R_) { 'a', T_, D_, R_, 0, 0, {k_fast<T_, D_, R_, 0>, k_fast<T_, D_, R_, 1>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, (uint32_t)fast_xbytes(T_, D_, R_) }
 #define SDRFM_FASTB2(T_, D_, R_, TA_, DA_) { 'b', T_, D_, R_, TA_, DA_, {k_fastb<T_, D_, R_, TA_, DA_, 0>, k_fastb<T_, D_, R_, TA_, DA_, 1>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, (uint32_t)fastb_xbytes(T_, D_, R_) }
+// headline shape only: [2] = halo samples not converted, [3] = no sample converted (timing ablations, wrong results; SDRFM_ABLATE=2|3)
+#define SDRFM_FASTB2_ABL(T_, D_, R_, TA_, DA_) { 'b', T_, D_, R_, TA_, DA_, {k_fastb<T_, D_, R_, TA_, DA_, 0>, k_fastb<T_, D_, R_, TA_, DA_, 1>, k_fastb<T_, D_, R_, TA_, DA_, 2>, k_fastb<T_, D_, R_, TA_, DA_, 3>, nullptr, nullptr, nullptr, nullptr}, (uint32_t)fastb_xbytes(T_, D_, R_) }
 #define SDRFM_FASTB2_LITE(T_, D_, R_, TA_, DA_) { 'b', T_, D_, R_, TA_, DA_, {k_fastb<T_, D_, R_, TA_, DA_, 0>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, (uint32_t)fastb_xbytes(T_, D_, R_) }
 #define SDRFM_FASTB(T_, D_, R_) SDRFM_FASTB2(T_, D_, R_, 32, 5)
 const FastVariant kFastVariants[] = {
     // 2.4 MS/s -> 240 kS/s -> 48 kHz: the rate the firmware programs (usbh_rtlsdr.c:898) and the BASELINE configs
     // (the instrumented twin, kernel[1], exists for the two BASELINE filter lengths only)
-    SDRFM_FASTB(64, 10, 12), SDRFM_FASTB2_LITE(64, 10, 8, 32, 5), SDRFM_FASTB(16, 10, 12), SDRFM_FASTB2_LITE(32, 10, 12, 32, 5),
+    SDRFM_FASTB2_ABL(64, 10, 12, 32, 5), SDRFM_FASTB2_LITE(64, 10, 8, 32, 5), SDRFM_FASTB(16, 10, 12), SDRFM_FASTB2_LITE(32, 10, 12, 32, 5),
     // the other rates RTLSDR_set_sample_rate accepts and a dongle is commonly run at:
     // 2.048 MS/s -> 256 kS/s -> 32 kHz, 1.024 MS/s -> 256 kS/s -> 32 kHz, 3.2 MS/s -> 200 kS/s -> 40 kHz
     SDRFM_FASTB2_LITE(64, 8, 12, 32, 8), SDRFM_FASTB2_LITE(16, 8, 12, 32, 8), SDRFM_FASTB2_LITE(64, 4, 12, 32, 8), SDRFM_FASTB2_LITE(64, 16, 8, 32, 5),
