@@ -778,12 +778,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 3)))
           const unsigned w = (s / 2 == 0) ? cur.x : (s / 2 == 1) ? cur.y : (s / 2 == 2) ? cur.z : cur.w;
           f2_t x;
           if constexpr (MODE == 2 && j < OFF + HALO) { x = f2_t{__uint_as_float(w), __uint_as_float(w)}; }   // ablation: halo not converted
-          else if constexpr (MODE == 3) { x = f2_t{__uint_as_float(w), __uint_as_float(w)}; }                 // ablation: nothing converted
+          else if constexpr (MODE == 3 || MODE == 5) { x = f2_t{__uint_as_float(w), __uint_as_float(w)}; }    // ablation: nothing converted
           else x = cvt_iq<(s & 1)>(w);
           static_for<0, R>([&](auto RR) {
             constexpr int r = decltype(RR)::value;
             constexpr int p0 = j - OFF - r * D;               // 0 = oldest sample of output r
-            if constexpr (p0 >= 0 && p0 < T) {
+            if constexpr (MODE == 5) { if constexpr (p0 == 0) acc[r] = x; }   // ablation: no FIR (one use per output)
+            else if constexpr (p0 >= 0 && p0 < T) {
               constexpr int k = T - 1 - p0;
               if constexpr (k / 2 < NVT) {
                 if constexpr (k & 1) pk_fma_bcast_v<1>(acc[r], hp[k / 2], x); else pk_fma_bcast_v<0>(acc[r], hp[k / 2], x);
@@ -809,7 +810,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 3)))
     float dv[R];
 #pragma unroll
     for (int r = 0; r + 1 < R; r += 2) {
-      const f2_t d2 = discriminate_pair(acc[r], r == 0 ? prev : acc[r - 1], acc[r + 1]);
+      f2_t d2;
+      if constexpr (MODE == 4 || MODE == 5) d2 = f2_t{acc[r].x + prev.x, acc[r + 1].y};     // ablation: no discriminator
+      else d2 = discriminate_pair(acc[r], r == 0 ? prev : acc[r - 1], acc[r + 1]);
       dv[r] = d2.x;
       dv[r + 1] = d2.y;
     }
@@ -939,8 +942,9 @@ struct FastVariant {
 #define SDRFM_FAST(T_, D_, R_) { 'a', T_, D_, R_, 0, 0, {k_fast<T_, D_, R_, 0>, k_fast<T_, D_, R_, 1>, k_fast<T_, D_, R_, 2>, k_fast<T_, D_, R_, 3>, k_fast<T_, D_, R_, 4>, k_fast<T_, D_, R_, 5>, k_fast<T_, D_, R_, 6>, k_fast<T_, D_, R_, 7>}, (uint32_t)fast_xbytes(T_, D_, R_) }
 #define SDRFM_FAST_LITE(T_, D_, R_) { 'a', T_, D_, R_, 0, 0, {k_fast<T_, D_, R_, 0>, k_fast<T_, D_, R_, 1>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, (uint32_t)fast_xbytes(T_, D_, R_) }
 #define SDRFM_FASTB2(T_, D_, R_, TA_, DA_) { 'b', T_, D_, R_, TA_, DA_, {k_fastb<T_, D_, R_, TA_, DA_, 0>, k_fastb<T_, D_, R_, TA_, DA_, 1>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, (uint32_t)fastb_xbytes(T_, D_, R_) }
-// headline shape only: [2] = halo samples not converted, [3] = no sample converted (timing ablations, wrong results; SDRFM_ABLATE=2|3)
-#define SDRFM_FASTB2_ABL(T_, D_, R_, TA_, DA_) { 'b', T_, D_, R_, TA_, DA_, {k_fastb<T_, D_, R_, TA_, DA_, 0>, k_fastb<T_, D_, R_, TA_, DA_, 1>, k_fastb<T_, D_, R_, TA_, DA_, 2>, k_fastb<T_, D_, R_, TA_, DA_, 3>, nullptr, nullptr, nullptr, nullptr}, (uint32_t)fastb_xbytes(T_, D_, R_) }
+// headline shape only, timing ablations with wrong results (SDRFM_ABLATE=2..5): [2] halo samples not converted, [3] no sample
+// converted, [4] no discriminator, [5] no conversion, no FIR, no discriminator (staging, LDS window reads and audio stage remain)
+#define SDRFM_FASTB2_ABL(T_, D_, R_, TA_, DA_) { 'b', T_, D_, R_, TA_, DA_, {k_fastb<T_, D_, R_, TA_, DA_, 0>, k_fastb<T_, D_, R_, TA_, DA_, 1>, k_fastb<T_, D_, R_, TA_, DA_, 2>, k_fastb<T_, D_, R_, TA_, DA_, 3>, k_fastb<T_, D_, R_, TA_, DA_, 4>, k_fastb<T_, D_, R_, TA_, DA_, 5>, nullptr, nullptr}, (uint32_t)fastb_xbytes(T_, D_, R_) }
 #define SDRFM_FASTB2_LITE(T_, D_, R_, TA_, DA_) { 'b', T_, D_, R_, TA_, DA_, {k_fastb<T_, D_, R_, TA_, DA_, 0>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, (uint32_t)fastb_xbytes(T_, D_, R_) }
 #define SDRFM_FASTB(T_, D_, R_) SDRFM_FASTB2(T_, D_, R_, 32, 5)
 const FastVariant kFastVariants[] = {
