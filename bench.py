@@ -2,9 +2,18 @@
 """bench.py — IQ MSamples/s through FIR + FM-demod + resample on MI355X (BASELINE.json metric).
 
 A "step" is one pass of the hot path (sdrfm_process_batch on device-resident buffers: one fused kernel launch) over one
-batch of synthetic IQ: by default BASELINE configs[2] — 256 concurrent 2.4 MS/s streams x 0.1 s (480 000 B each),
-64-tap FIR /10, FM discriminator, 32-tap /5 audio resampler.  With --gpus N (launched by torch.distributed.run) every
-rank owns its own 256 streams on its own GPU (streams are independent: no data-path collective, weak scaling).
+batch of synthetic IQ:
+  N = 1   BASELINE configs[2] — 256 concurrent 2.4 MS/s streams x 0.1 s (480 000 B each), 64-tap FIR /10, FM discriminator,
+          32-tap /5 audio resampler;
+  N > 1   BASELINE configs[3]'s share per GPU — 512 streams each (4096 streams on 8 GPUs); streams are independent, so every
+          rank owns its own streams on its own GPU: no data-path collective, weak scaling.
+`python3 bench.py --gpus N` works as typed: with N > 1 and no torch.distributed environment it starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process (before anything touches the GPU),
+forwards its JSON line and exits with its return code.
+
+Cold inputs: the timed loop rotates over enough distinct input batches (>= 3, > 256 MiB in total, i.e. more than the
+Infinity Cache holds) that every step reads its bytes from HBM; that is `value`.  The figure with ONE resident 123 MB
+batch (which the 256 MiB L3 can keep) is reported beside it as `resident_input`, never as `value`.
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).  The GPU legs never touch oracle/; only the
 `cpu_baseline` leg (rank 0, N=1) times the scalar-C oracle on a bounded sample of the same workload.
@@ -14,6 +23,8 @@ import glob
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+L3_BYTES = 256 << 20            # Infinity Cache (same guide): the rotated inputs must exceed it
 
 
 def parse():
@@ -28,21 +40,46 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--streams-per-gpu", type=int, default=256)
+    ap.add_argument("--streams-per-gpu", type=int, default=0, help="0 = 256 at one GPU (configs[2]), 512 at several (configs[3] share)")
     ap.add_argument("--seconds", type=float, default=0.1, help="capture length per stream per step")
     ap.add_argument("--fir-taps", type=int, default=64)
-    ap.add_argument("--distinct", type=int, default=0, help="distinct synthetic streams (0 = all)")
+    ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic streams generated on the host per rank; the other "
+                    "rows and the other rotated batches are byte-rotations of them made on the device (0 = generate every row)")
+    ap.add_argument("--batches", type=int, default=0, help="input batches the timed loop rotates over (0 = as many as exceed the L3, >= 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--check", action="store_true", help="also verify a few streams against the oracle (not timed)")
     ap.add_argument("--workload", choices=["fm", "wbfm", "spectrum"], default="fm",
-                    help="fm = BASELINE configs[2] (default, the headline); wbfm = configs[4] channelizer path, 128 streams/GPU; "
+                    help="fm = BASELINE configs[2]/[3] (default, the headline); wbfm = configs[4] channelizer path, 128 streams/GPU; "
                          "spectrum = FFT view (SURVEY 8f-3) of the configs[2] buffers")
     ap.add_argument("--nfft", type=int, default=1024, help="spectrum workload: FFT length")
     ap.add_argument("--end-to-end", action="store_true",
                     help="fm workload: every step also scatters the IQ batch from rank 0 to all ranks and gathers the audio back "
                          "over RCCL (SURVEY 8e C1/C2); reported separately from the compute-only default")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`bench.py --gpus N` typed directly: run the N ranks as a child job and relay its one JSON line.  Called before torch (or
+    anything else) has touched the GPU; this process never does."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line:
+        print(line, flush=True)
+    sys.exit(proc.returncode if proc.returncode else (0 if line else 1))
 
 
 def latest_traffic(kernel_name):
@@ -53,7 +90,7 @@ def latest_traffic(kernel_name):
             with open(fn) as f:
                 t = json.load(f)
             if t.get("kernel_name") == kernel_name:
-                best = t
+                best = dict(t, file=os.path.basename(fn))
         except Exception:
             pass
     return best
@@ -94,8 +131,74 @@ def cpu_baseline(pkg, h, g, iq_host, seconds, threads):
     return out
 
 
+def make_batches(torch, pkg, stream, ns, nsamp, fs, rank, distinct, nbatches):
+    """nbatches device-resident input batches [ns, 2*nsamp] u8.  `distinct` rows come from the host generator (FM test signal,
+    own PRNG stream per (rank, row)); every other row of every batch is one of them rotated by a different whole number of I/Q
+    pairs on the device: the same signal statistics at different bytes, so no two rows (or batches) share a cache line."""
+    import numpy as np
+    distinct = ns if distinct <= 0 else min(distinct, ns)
+    t0 = time.perf_counter()
+    base_host = pkg.make_iq(distinct, nsamp, mode="fm", fs=fs, first_id=rank * ns)
+    t_gen = time.perf_counter() - t0
+    batches = []
+    with torch.cuda.stream(stream):
+        base = torch.from_numpy(base_host).cuda()
+        for b in range(nbatches):
+            rows = []
+            for r0 in range(0, ns, distinct):
+                k = b * ((ns + distinct - 1) // distinct) + r0 // distinct
+                rows.append(base if k == 0 else torch.roll(base, shifts=2 * (7919 * k % nsamp), dims=1))
+            batches.append(torch.cat(rows)[:ns].contiguous())
+    stream.synchronize()
+    first_host = batches[0][: min(ns, 64)].cpu().numpy() if distinct < min(ns, 64) else base_host[: min(ns, 64)]
+    return batches, np.ascontiguousarray(first_host), t_gen
+
+
+def pick_batches(args, bytes_per_batch):
+    if args.batches > 0:
+        return args.batches
+    return max(3, -(-int(1.5 * L3_BYTES) // int(bytes_per_batch)) + 1)   # (nb - 1) batches between two uses of one > 1.5 x L3
+
+
+def timed(torch, dist, use_dist, stream, step, steps):
+    """K back-to-back steps between ONE pair of HIP events on the launch stream, bracketed by barrier + synchronize on both
+    sides; returns (max-over-ranks wall seconds, event span / K in ms)."""
+    def fence():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for i in range(steps):
+        step(i)
+    ev1.record(stream)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, ev0.elapsed_time(ev1) / steps
+
+
+def per_launch_events(torch, stream, step, n):
+    """Untimed pass: one HIP event pair around each of n launches on the launch stream -> list of ms."""
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for i, (a, b) in enumerate(evs):
+        a.record(stream)
+        step(i)
+        b.record(stream)
+    torch.cuda.synchronize()
+    return [a.elapsed_time(b) for a, b in evs]
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)                                         # never returns
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -103,10 +206,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -114,32 +214,28 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    rccl_world = dist.get_world_size() if dist.is_initialized() else 1
 
     pkg = importlib.import_module("stm32f7-rtlsdr_amd")
     if args.workload == "wbfm":
-        return main_wbfm(args, pkg, world, rank, local_rank)
+        return main_wbfm(args, pkg, world, rank, local_rank, use_dist, rccl_world)
     if args.workload == "spectrum":
-        return main_spectrum(args, pkg, world, rank, local_rank)
+        return main_spectrum(args, pkg, world, rank, local_rank, use_dist, rccl_world)
     fs = 2.4e6
-    ns = args.streams_per_gpu
+    ns = args.streams_per_gpu if args.streams_per_gpu > 0 else (256 if world == 1 else 512)
+    cfg_name = "configs[2]" if ns == 256 else ("configs[3] share (4096 streams / 8 GPUs)" if ns == 512 else "configs[2]-shaped")
     nsamp = int(round(args.seconds * fs))
     nbytes = 2 * nsamp
     h, g = pkg.default_config(args.fir_taps, fs=fs)
     D, Da = 10, 5
 
-    # synthetic input: FM test signal, distinct PRNG stream per (rank, stream)
-    distinct = args.distinct if args.distinct > 0 else ns
-    t_gen = time.perf_counter()
-    base = pkg.make_iq(distinct, nsamp, mode="fm", fs=fs, first_id=rank * ns)
-    iq_host = base if distinct == ns else np.tile(base, ((ns + distinct - 1) // distinct, 1))[:ns]
-    t_gen = time.perf_counter() - t_gen
-
     dm = pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, fir_decim=D, audio_decim=Da, n_streams=ns, device=local_rank))
     stream = torch.cuda.Stream()
     dm.set_stream(stream.cuda_stream)
+    nb = pick_batches(args, ns * nbytes)
+    batches, iq_host, t_gen = make_batches(torch, pkg, stream, ns, nsamp, fs, rank, args.distinct, nb)
     n_audio_max = nsamp // D // Da + 1
     with torch.cuda.stream(stream):
-        iq = torch.from_numpy(iq_host).cuda()
         audio = torch.zeros((ns, n_audio_max), dtype=torch.float32, device="cuda")
     stream.synchronize()
 
@@ -149,60 +245,48 @@ def main():
         if not dist.is_initialized():
             dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1,
                                     device_id=torch.device("cuda", local_rank))
-        fan = pkg.fanout
         with torch.cuda.stream(stream):
-            iq_all = torch.from_numpy(np.tile(iq_host, (world, 1))).cuda() if rank == 0 else None
+            iq_all = batches[0].repeat(world, 1) if rank == 0 else None
         stream.synchronize()
         e2e = {"iq_all": iq_all, "total": world * ns}
 
-    def step():
+    last = {"n": 0}
+
+    def step_rot(i):
         if e2e is None:
-            return dm.process_batch_device(iq, audio)
+            last["n"] = dm.process_batch_device(batches[i % nb], audio)
+            return
         with torch.cuda.stream(stream):
-            local = pkg.fanout.scatter_streams(e2e["iq_all"], e2e["total"], nbytes, iq.device)
-            n = dm.process_batch_device(local, audio)
-            pkg.fanout.gather_audio(audio[:, :n], e2e["total"])
-        return n
+            local = pkg.fanout.scatter_streams(e2e["iq_all"], e2e["total"], nbytes, batches[0].device)
+            last["n"] = dm.process_batch_device(local, audio)
+            pkg.fanout.gather_audio(audio[:, :last["n"]], e2e["total"])
 
-    def fence():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def step_res(i):
+        last["n"] = dm.process_batch_device(batches[0], audio)
 
-    for _ in range(args.warmup):
-        step()
-    fence()
+    for i in range(args.warmup):
+        step_rot(i)
     # Timed region: K back-to-back launches between ONE pair of HIP events on the launch stream (an event pair around every
-    # launch costs ~6 us of idle GPU per step, 14 % of this kernel).  kernel_ms_avg = event span / K is therefore the average
-    # launch duration INCLUDING any inter-launch gap; per-launch event timings come from a short untimed pass afterwards.
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    n_audio = 0
-    ev0.record(stream)
-    for _ in range(args.steps):
-        n_audio = step()
-    ev1.record(stream)
-    fence()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kernel_ms_avg = ev0.elapsed_time(ev1) / args.steps
-    kernel_ms = per_launch_events(torch, stream, step, min(args.steps, 20))
-    fence()
+    # launch costs ~6 us of idle GPU per step).  kernel_ms_avg = event span / K is therefore the average launch duration
+    # INCLUDING any inter-launch gap; per-launch event timings come from a short untimed pass afterwards.
+    elapsed, kernel_ms_avg = timed(torch, dist, use_dist, stream, step_rot, args.steps)
+    n_audio = last["n"]
+    kernel_ms = per_launch_events(torch, stream, step_rot, min(args.steps, 20))
+    # second, labelled figure: ONE resident input batch (fits the 256 MiB Infinity Cache) — what round 1 reported as `value`
+    res_steps = min(args.steps, 100)
+    for i in range(min(args.warmup, 10)):
+        step_res(i)
+    elapsed_res, kernel_ms_res = timed(torch, dist, use_dist, stream, step_res, res_steps) if e2e is None else (None, None)
 
     ok = None
     if args.check and rank == 0:
         from oracle.oracle import Oracle
         dm.reset()
-        step()
+        step_res(0)
         dm.synchronize()
         got = audio[:, :n_audio].cpu().numpy()
         ok = True
-        for s in (0, ns // 2, ns - 1):
+        for s in (0, min(ns, iq_host.shape[0]) // 2, min(ns, iq_host.shape[0]) - 1):
             want = Oracle(h, g).process(iq_host[s])
             err = np.max(np.abs(got[s] - want) / np.maximum(np.abs(want), 1.0))
             ok = ok and bool(err <= 1e-5)
@@ -217,30 +301,38 @@ def main():
         res = {
             "metric": "IQ MSamples/s through FIR+FM-demod+resample",
             "value": round(value, 1), "unit": "MSamples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "rccl_world": rccl_world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "mode": "end-to-end (RCCL scatter of IQ from rank 0 + gather of audio every step)" if args.end_to_end else "compute-only (IQ resident per GPU)",
-            "config": {"workload": "BASELINE configs[2]: %d concurrent 2.4 MS/s uint8 IQ streams per GPU x %.1f s (%d B each), "
+            "config": {"workload": "BASELINE %s: %d concurrent 2.4 MS/s uint8 IQ streams per GPU x %.1f s (%d B each), "
                                    "%d-tap FIR /%d + FM discriminator + %d-tap /%d -> 48 kHz; device-resident, streams sharded "
-                                   "across GPUs with no collective" % (ns, args.seconds, nbytes, args.fir_taps, D, len(g), Da),
+                                   "across GPUs with no collective; timed loop rotates over %d input batches = %.0f MB per GPU (> 256 MiB "
+                                   "L3: cold HBM reads)" % (cfg_name, ns, args.seconds, nbytes, args.fir_taps, D, len(g), Da, nb, nb * ns * nbytes / 1e6),
                        "streams_per_gpu": ns, "bytes_per_stream": nbytes, "fir_taps": args.fir_taps, "kernel": dm.kernel_name,
+                       "input_batches_rotated": nb, "input_bytes_rotated_per_gpu": nb * ns * nbytes,
                        "bytes_per_sample_algorithmic": round(alg_bytes / samples_per_launch, 4),
                        "GB_per_s_input": round(value * 2e6 / 1e9, 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
+                         "traffic_source": ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at commit %s)" % (traffic["file"], traffic.get("commit", "?"))) if traffic else None,
                          "kernel": dm.kernel_name, "kernel_ms_avg": round(kernel_ms_avg, 4),
                          "kernel_ms_isolated_avg": round(float(np.mean(kernel_ms)), 4),
                          "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
                          "algorithmic_bytes_per_launch": alg_bytes},
             "gen_seconds": round(t_gen, 2),
         }
+        if elapsed_res is not None:
+            res["resident_input"] = {"value": round(float(world) * ns * nsamp * res_steps / elapsed_res / 1e6, 1), "unit": "MSamples/s",
+                                     "kernel_ms_avg": round(kernel_ms_res, 4), "steps": res_steps,
+                                     "frac_of_hbm_peak": round(alg_bytes / (kernel_ms_res * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                     "note": "same kernel re-reading ONE %.0f MB batch, which the 256 MiB Infinity Cache can hold; not the headline" % (ns * nbytes / 1e6)}
         if ok is not None:
             res["parity_ok"] = ok
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(pkg, h, g, iq_host[: min(ns, 64)], args.cpu_seconds, os.cpu_count() or 1)
+            res["cpu_baseline"] = cpu_baseline(pkg, h, g, iq_host, args.cpu_seconds, os.cpu_count() or 1)
         print(json.dumps(res), flush=True)
     dm.set_stream(None)
     dm.close()
@@ -249,137 +341,98 @@ def main():
         dist.destroy_process_group()
 
 
-def per_launch_events(torch, stream, step, n):
-    """Untimed pass: one HIP event pair around each of n launches on the launch stream -> list of ms."""
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
-    for a, b in evs:
-        a.record(stream)
-        step()
-        b.record(stream)
-    torch.cuda.synchronize()
-    return [a.elapsed_time(b) for a, b in evs]
-
-
-def main_wbfm(args, pkg, world, rank, local_rank):
+def main_wbfm(args, pkg, world, rank, local_rank, use_dist, rccl_world):
     """BASELINE configs[4]: 3.2 MS/s IQ, 128-tap prototype, 16 bands, per-band FM demod, 6/25 resampler; 128 streams/GPU."""
-    import numpy as np
     import torch
     import torch.distributed as dist
-    fs, ns = 3.2e6, (args.streams_per_gpu if args.streams_per_gpu != 256 else 128)
+    fs, ns = 3.2e6, (args.streams_per_gpu if args.streams_per_gpu > 0 else 128)
     nsamp = int(round(args.seconds * fs))
     p = pkg.lowpass_taps(128, 0.5 / 16 * 0.8)
     g = pkg.lowpass_taps(60, 0.5 / 25 * 0.8) * 6.0
-    iq_host = pkg.make_iq(ns, nsamp, mode="fm", fs=fs, first_id=rank * ns)
     dm = pkg.WbfmDemod(pkg.WbfmConfig(proto_coeffs=p, resamp_coeffs=g, n_streams=ns, device=local_rank, max_bytes_per_call=2 * nsamp))
     kname = dm.kernel_name
     stream = torch.cuda.Stream()
     dm.set_stream(stream.cuda_stream)
+    nb = pick_batches(args, ns * 2 * nsamp)
+    batches, _, _ = make_batches(torch, pkg, stream, ns, nsamp, fs, rank, args.distinct, nb)
     cap = dm.audio_count(2 * nsamp) + 8
     with torch.cuda.stream(stream):
-        iq = torch.from_numpy(iq_host).cuda()
         audio = torch.zeros((ns, 16, cap), dtype=torch.float32, device="cuda")
     stream.synchronize()
+    last = {"n": 0}
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def step(i):
+        last["n"] = dm.process_batch_device(batches[i % nb], audio)
 
-    for _ in range(args.warmup):
-        dm.process_batch_device(iq, audio)
-    fence()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    n_audio = 0
-    ev0.record(stream)
-    for _ in range(args.steps):
-        n_audio = dm.process_batch_device(iq, audio)
-    ev1.record(stream)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms = ev0.elapsed_time(ev1) / args.steps                      # launch duration incl. inter-launch gap (see main())
+    for i in range(args.warmup):
+        step(i)
+    elapsed, ms = timed(torch, dist, use_dist, stream, step, args.steps)   # ms = launch duration incl. inter-launch gap (see main())
+    n_audio = last["n"]
     if rank == 0:
         alg = ns * nsamp * 2.0 + ns * 16 * n_audio * 4.0
+        tr = latest_traffic(kname)
         res = {"metric": "IQ MSamples/s through FIR+FM-demod+resample", "value": round(world * ns * nsamp * args.steps / elapsed / 1e6, 1),
-               "unit": "MSamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "unit": "MSamples/s", "n_gpus": world, "rccl_world": rccl_world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": "BASELINE configs[4]: %d x 3.2 MS/s uint8 IQ streams per GPU x %.1f s, 128-tap prototype, 16-band polyphase "
-                                      "channelizer + per-band FM demod + 6/25 resampler -> 16 x 48 kHz" % (ns, args.seconds),
-                          "streams_per_gpu": ns, "bytes_per_stream": 2 * nsamp, "kernel": kname},
+                                      "channelizer + per-band FM demod + 6/25 resampler -> 16 x 48 kHz; %d input batches rotated (%.0f MB, cold HBM reads)"
+                                      % (ns, args.seconds, nb, nb * ns * 2 * nsamp / 1e6),
+                          "streams_per_gpu": ns, "bytes_per_stream": 2 * nsamp, "kernel": kname, "input_batches_rotated": nb},
                "roofline": {"bound": "hbm", "achieved": round(alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                             "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                            "traffic": (latest_traffic(kname) or {}).get("hbm_bytes_per_launch"), "kernel_ms_avg": round(ms, 4),
+                            "traffic": (tr or {}).get("hbm_bytes_per_launch"), "kernel_ms_avg": round(ms, 4),
                             "algorithmic_bytes_per_launch": alg}}
         print(json.dumps(res), flush=True)
     dm.set_stream(None)
     dm.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
 
-def main_spectrum(args, pkg, world, rank, local_rank):
+def main_spectrum(args, pkg, world, rank, local_rank, use_dist, rccl_world):
     """FFT view of the BASELINE configs[2] buffers: 256 x 0.1 s of 2.4 MS/s IQ per GPU -> averaged power spectra."""
     import numpy as np
     import torch
     import torch.distributed as dist
-    fs, ns, nfft = 2.4e6, args.streams_per_gpu, args.nfft
+    fs, ns, nfft = 2.4e6, (args.streams_per_gpu if args.streams_per_gpu > 0 else 256), args.nfft
     nsamp = int(round(args.seconds * fs))
-    iq_host = pkg.make_iq(ns, nsamp, mode="fm", fs=fs, first_id=rank * ns)
     sv = pkg.SpectrumView(pkg.SpectrumConfig(nfft=nfft, n_streams=ns, device=local_rank, max_bytes_per_call=2 * nsamp))
     stream = torch.cuda.Stream()
     sv.set_stream(stream.cuda_stream)
+    nb = pick_batches(args, ns * 2 * nsamp)
+    batches, _, _ = make_batches(torch, pkg, stream, ns, nsamp, fs, rank, args.distinct, nb)
     with torch.cuda.stream(stream):
-        iq = torch.from_numpy(iq_host).cuda()
         power = torch.zeros((ns, nfft), dtype=torch.float32, device="cuda")
     stream.synchronize()
+    last = {"n": 0}
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def step(i):
+        last["n"] = sv.process_batch_device(batches[i % nb], power)
 
-    for _ in range(args.warmup):
-        sv.process_batch_device(iq, power)
-    fence()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    frames = 0
-    ev0.record(stream)
-    for _ in range(args.steps):
-        frames = sv.process_batch_device(iq, power)
-    ev1.record(stream)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms = ev0.elapsed_time(ev1) / args.steps                      # launch duration incl. inter-launch gap (see main())
+    for i in range(args.warmup):
+        step(i)
+    elapsed, ms = timed(torch, dist, use_dist, stream, step, args.steps)
+    frames = last["n"]
     if rank == 0:
         alg = ns * frames * nfft * 2.0 + ns * nfft * 4.0
+        kname = "k_spectrum<%d>" % int(np.log2(nfft))
         res = {"metric": "IQ MSamples/s through the windowed-FFT spectrum view", "value": round(world * ns * frames * nfft * args.steps / elapsed / 1e6, 1),
-               "unit": "MSamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "unit": "MSamples/s", "n_gpus": world, "rccl_world": rccl_world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": "spectrum view (SURVEY 8f-3) of BASELINE configs[2] buffers: %d x 2.4 MS/s uint8 IQ streams per GPU x %.1f s, "
-                                      "%d-point Hann FFT, %d frames averaged per stream" % (ns, args.seconds, nfft, frames),
-                          "streams_per_gpu": ns, "bytes_per_stream": 2 * nsamp, "kernel": "k_spectrum<%d>" % int(np.log2(nfft))},
+                                      "%d-point Hann FFT, %d frames averaged per stream; %d input batches rotated (cold HBM reads)" % (ns, args.seconds, nfft, frames, nb),
+                          "streams_per_gpu": ns, "bytes_per_stream": 2 * nsamp, "kernel": kname, "input_batches_rotated": nb},
                "roofline": {"bound": "hbm", "achieved": round(alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                             "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                            "traffic": (latest_traffic("k_spectrum<%d>" % int(np.log2(nfft))) or {}).get("hbm_bytes_per_launch"),
+                            "traffic": (latest_traffic(kname) or {}).get("hbm_bytes_per_launch"),
                             "kernel_ms_avg": round(ms, 4), "algorithmic_bytes_per_launch": alg}}
         print(json.dumps(res), flush=True)
     sv.set_stream(None)
     sv.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

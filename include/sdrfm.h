@@ -59,6 +59,7 @@ enum {
 
 /* flags for sdrfm_config.flags */
 #define SDRFM_CFG_FORCE_GENERIC 1u  /* never select a (T,D)-specialised kernel: run the generic kernel (tests) */
+#define SDRFM_CFG_NO_ZEROCOPY   2u  /* URB-sized host calls use the staged H2D/D2H path instead of mapped host memory (tests) */
 
 /* flags for sdrfm_process_batch */
 #define SDRFM_F_DEVICE_PTRS 1u    /* iq and audio are device pointers on cfg.device; call is enqueued on the
@@ -126,9 +127,10 @@ const char* sdrfm_strerror(int status);
 float sdrfm_host_atan2f(float y, float x);
 float sdrfm_host_discriminate(float yr, float yi, float pr, float pi);
 
-/* Profiling aid: with SDRFM_PHASE_PROFILE=1 in the environment at create time the (T,D)-specialised kernel runs an
- * instrumented build; this returns cumulative shader cycles per phase summed over waves: out[0..4] = stage, FIR,
- * discriminator, audio, carry; out[5] = sub-tiles; out[6] = waves; and resets them. SDRFM_NOT_SUPPORTED otherwise. */
+/* Profiling aid of the development build (libsdrfm_dev.so, built with -DSDRFM_DEV; SDRFM_PHASE_PROFILE=1 at create time):
+ * cumulative shader cycles per phase summed over waves: out[0..4] = stage, FIR, discriminator, audio, carry; out[5] =
+ * sub-tiles; out[6] = waves; and resets them.  The product library holds no instrumented kernel and no environment
+ * knob: it always answers SDRFM_NOT_SUPPORTED. */
 int sdrfm_debug_phase_cycles(sdrfm_t* h, unsigned long long* out8);
 
 /* Profiling aid: raw dump of the 560 debug words of the instrumented build. */
@@ -162,6 +164,9 @@ int  sdrfm_ring_collect(sdrfm_ring_t* r, float* audio, uint32_t audio_cap, uint3
  * audio layout: audio[(stream * 16 + band) * band_stride + j].
  * ------------------------------------------------------------------------------------------------------------------ */
 #define SDRFM_WBFM_BANDS 16
+/* flags for sdrfm_wbfm_config.flags (both are test hooks; results do not depend on them) */
+#define SDRFM_WBFM_CFG_FORCE_GENERIC 1u        /* never run the fused kernel */
+#define SDRFM_WBFM_CFG_RUN_STEPS_SHIFT 8       /* flags >> 8 = fixed run length (steps) of the fused kernel, 0 = chosen per call */
 
 typedef struct sdrfm_wbfm_config {
   uint32_t struct_size;           /* = sizeof(sdrfm_wbfm_config) */
@@ -174,7 +179,7 @@ typedef struct sdrfm_wbfm_config {
   const float* resamp_coeffs;
   uint32_t max_bytes_per_call;    /* per stream; 0 = 1 MiB */
   int32_t  device;
-  uint32_t flags;                 /* must be 0 */
+  uint32_t flags;                 /* SDRFM_WBFM_CFG_* */
 } sdrfm_wbfm_config;
 
 typedef struct sdrfm_wbfm sdrfm_wbfm_t;
@@ -243,6 +248,21 @@ int sdrfm_e4k_pll_params(uint32_t fosc_hz, uint32_t intended_flo_hz, sdrfm_e4k_p
  * (Utilities/STM32746G-Discovery/stm32746g_discovery_audio.c:224).  pcm_stereo receives 2*n samples. */
 int   sdrfm_pcm_deemph_s16(const float* audio, uint32_t n, float alpha, float gain, float* state, int16_t* pcm_stereo);
 float sdrfm_pcm_alpha(float fs_hz, float tau_s);   /* 1 - exp(-1/(fs*tau)); tau = 75e-6 (US) / 50e-6 (EU) */
+
+/* The same sink ON THE DEVICE for the batched path: audio[stream * audio_stride + i] (f32, as sdrfm_process_batch leaves it) ->
+ * pcm[stream * pcm_stride + 2*i + {0,1}] (int16, L = R), de-emphasis state carried per stream in the handle.  Bit-identical
+ * to sdrfm_pcm_deemph_s16 run per stream (same operations in the same order; csrc/sdrfm_sink.hip).  pcm_stride is in int16
+ * elements, even, >= 2*n.  With SDRFM_F_DEVICE_PTRS both buffers are device memory (pcm 4-byte aligned) and the call only
+ * enqueues on the sink's stream; give it the demodulator's stream (or synchronise) so that it runs after the audio exists. */
+typedef struct sdrfm_pcm_sink sdrfm_pcm_sink_t;
+int  sdrfm_pcm_sink_create(uint32_t n_streams, float alpha, float gain, int32_t device, sdrfm_pcm_sink_t** out);
+void sdrfm_pcm_sink_destroy(sdrfm_pcm_sink_t* k);
+int  sdrfm_pcm_sink_reset(sdrfm_pcm_sink_t* k);
+int  sdrfm_pcm_sink_process_batch(sdrfm_pcm_sink_t* k, const float* audio, size_t audio_stride, uint32_t n,
+                                  int16_t* pcm, size_t pcm_stride, uint32_t flags);
+int  sdrfm_pcm_sink_set_stream(sdrfm_pcm_sink_t* k, void* hip_stream);
+int  sdrfm_pcm_sink_synchronize(sdrfm_pcm_sink_t* k);
+int  sdrfm_pcm_sink_get_state(sdrfm_pcm_sink_t* k, float* state_out /* n_streams floats */);
 
 #ifdef __cplusplus
 }

@@ -12,12 +12,13 @@ from .lib import SdrfmError, load_library, library_path, STATUS, ABI_SYMBOLS
 from .demod import FmDemod, FmConfig
 from .wbfm import WbfmDemod, WbfmConfig
 from .spectrum import SpectrumView, SpectrumConfig, power_db
+from .sink import PcmSink, pcm_deemph_s16_host
 from .taps import RTLSDR_FIR, rtlsdr_fir16, lowpass_taps, default_config
 from .siggen import make_iq, MODES
 from .frontend import ReplayFrontEnd, XferState
 from . import fanout
 
 __all__ = [
-    "SdrfmError", "load_library", "library_path", "STATUS", "ABI_SYMBOLS", "FmDemod", "FmConfig", "WbfmDemod", "WbfmConfig", "SpectrumView", "SpectrumConfig", "power_db", "RTLSDR_FIR",
+    "SdrfmError", "load_library", "library_path", "STATUS", "ABI_SYMBOLS", "FmDemod", "FmConfig", "WbfmDemod", "WbfmConfig", "SpectrumView", "SpectrumConfig", "power_db", "PcmSink", "pcm_deemph_s16_host", "RTLSDR_FIR",
     "rtlsdr_fir16", "lowpass_taps", "default_config", "make_iq", "MODES", "ReplayFrontEnd", "XferState", "fanout",
 ]

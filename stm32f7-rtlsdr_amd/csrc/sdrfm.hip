@@ -302,6 +302,7 @@ __device__ __forceinline__ f2_t discriminate_pair(f2_t y0, f2_t p0, f2_t y1) {
   return f2_t{(re.x == 0.0f && im.x == 0.0f) ? 0.0f : a.x, (re.y == 0.0f && im.y == 0.0f) ? 0.0f : a.y};
 }
 
+#ifdef SDRFM_DEV   // design A and every MODE != 0 instantiation exist only in libsdrfm_dev.so
 // MODE 0 = product kernel.  Other modes exist for timing experiments only and are reachable only through the
 // SDRFM_PHASE_PROFILE / SDRFM_ABLATE environment variables: 1 = per-phase cycle counters; 2 = no LDS staging writes;
 // 3 = no FIR arithmetic; 4 = no discriminator/audio; 5 = no LDS staging writes and no FIR LDS reads; 6 = staging only;
@@ -573,6 +574,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   }
 #undef SDRFM_TICK
 }
+
+#endif  // SDRFM_DEV
 
 typedef unsigned u4_t __attribute__((ext_vector_type(4)));
 // =================================================================================================================
@@ -939,23 +942,29 @@ struct FastVariant {
   void (*kernel[8])(CallParams);   // [0] product; [1..7] timing experiments (profile / ablations)
   uint32_t xbytes;
 };
+#ifdef SDRFM_DEV
 #define SDRFM_FAST(T_, D_, R_) { 'a', T_, D_, R_, 0, 0, {k_fast<T_, D_, R_, 0>, k_fast<T_, D_, R_, 1>, k_fast<T_, D_, R_, 2>, k_fast<T_, D_, R_, 3>, k_fast<T_, D_, R_, 4>, k_fast<T_, D_, R_, 5>, k_fast<T_, D_, R_, 6>, k_fast<T_, D_, R_, 7>}, (uint32_t)fast_xbytes(T_, D_, R_) }
 #define SDRFM_FAST_LITE(T_, D_, R_) { 'a', T_, D_, R_, 0, 0, {k_fast<T_, D_, R_, 0>, k_fast<T_, D_, R_, 1>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, (uint32_t)fast_xbytes(T_, D_, R_) }
 #define SDRFM_FASTB2(T_, D_, R_, TA_, DA_) { 'b', T_, D_, R_, TA_, DA_, {k_fastb<T_, D_, R_, TA_, DA_, 0>, k_fastb<T_, D_, R_, TA_, DA_, 1>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, (uint32_t)fastb_xbytes(T_, D_, R_) }
 // headline shape only, timing ablations with wrong results (SDRFM_ABLATE=2..5): [2] halo samples not converted, [3] no sample
 // converted, [4] no discriminator, [5] no conversion, no FIR, no discriminator (staging, LDS window reads and audio stage remain)
 #define SDRFM_FASTB2_ABL(T_, D_, R_, TA_, DA_) { 'b', T_, D_, R_, TA_, DA_, {k_fastb<T_, D_, R_, TA_, DA_, 0>, k_fastb<T_, D_, R_, TA_, DA_, 1>, k_fastb<T_, D_, R_, TA_, DA_, 2>, k_fastb<T_, D_, R_, TA_, DA_, 3>, k_fastb<T_, D_, R_, TA_, DA_, 4>, k_fastb<T_, D_, R_, TA_, DA_, 5>, nullptr, nullptr}, (uint32_t)fastb_xbytes(T_, D_, R_) }
+#else   // product library: the result-correct kernel of every shape and nothing else
+#define SDRFM_FASTB2(T_, D_, R_, TA_, DA_) SDRFM_FASTB2_LITE(T_, D_, R_, TA_, DA_)
+#define SDRFM_FASTB2_ABL(T_, D_, R_, TA_, DA_) SDRFM_FASTB2_LITE(T_, D_, R_, TA_, DA_)
+#endif
 #define SDRFM_FASTB2_LITE(T_, D_, R_, TA_, DA_) { 'b', T_, D_, R_, TA_, DA_, {k_fastb<T_, D_, R_, TA_, DA_, 0>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, (uint32_t)fastb_xbytes(T_, D_, R_) }
 #define SDRFM_FASTB(T_, D_, R_) SDRFM_FASTB2(T_, D_, R_, 32, 5)
 const FastVariant kFastVariants[] = {
     // 2.4 MS/s -> 240 kS/s -> 48 kHz: the rate the firmware programs (usbh_rtlsdr.c:898) and the BASELINE configs
-    // (the instrumented twin, kernel[1], exists for the two BASELINE filter lengths only)
     SDRFM_FASTB2_ABL(64, 10, 12, 32, 5), SDRFM_FASTB2_LITE(64, 10, 8, 32, 5), SDRFM_FASTB(16, 10, 12), SDRFM_FASTB2_LITE(32, 10, 12, 32, 5),
     // the other rates RTLSDR_set_sample_rate accepts and a dongle is commonly run at:
     // 2.048 MS/s -> 256 kS/s -> 32 kHz, 1.024 MS/s -> 256 kS/s -> 32 kHz, 3.2 MS/s -> 200 kS/s -> 40 kHz
     SDRFM_FASTB2_LITE(64, 8, 12, 32, 8), SDRFM_FASTB2_LITE(16, 8, 12, 32, 8), SDRFM_FASTB2_LITE(64, 4, 12, 32, 8), SDRFM_FASTB2_LITE(64, 16, 8, 32, 5),
+#ifdef SDRFM_DEV
     // design A (float tile): kept as the measured alternative; ablation modes only on the documented shape
     SDRFM_FAST(64, 10, 3), SDRFM_FAST_LITE(16, 10, 2), SDRFM_FAST_LITE(32, 10, 2),
+#endif
 };
 
 }  // namespace
@@ -997,7 +1006,8 @@ struct sdrfm {
   unsigned long long* d_dbg;  // phase profile accumulators (only with SDRFM_PHASE_PROFILE=1)
   uint32_t warm_ahead;        // L2 warm-up distance (sub-tiles)
   uint32_t dbg_launches;      // launches since the debug counters were last reset
-  int fast_mode;              // 0 product; 1..5 timing experiments selected by environment variables
+  int fast_mode;              // 0 product; 1..7 timing experiments (libsdrfm_dev.so only)
+  uint32_t prio_balance, fold_state_ok;   // design B knobs, fixed at create
   char kernel_name[64];
   char generic_name[64];
   char fast_name[64];
@@ -1091,7 +1101,7 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
   if (!out) return SDRFM_EINVAL;
   *out = nullptr;
   if (!cfg || cfg->struct_size != sizeof(sdrfm_config)) return SDRFM_EINVAL;
-  if (!cfg->n_streams || !cfg->fir_coeffs || !cfg->audio_coeffs || (cfg->flags & ~SDRFM_CFG_FORCE_GENERIC)) return SDRFM_EINVAL;
+  if (!cfg->n_streams || !cfg->fir_coeffs || !cfg->audio_coeffs || (cfg->flags & ~(SDRFM_CFG_FORCE_GENERIC | SDRFM_CFG_NO_ZEROCOPY))) return SDRFM_EINVAL;
   if (!cfg->fir_taps || cfg->fir_taps > SDRFM_MAX_TAPS || !cfg->audio_taps || cfg->audio_taps > SDRFM_MAX_TAPS)
     return SDRFM_EINVAL;
   if (!cfg->fir_decim || cfg->fir_decim > SDRFM_MAX_DECIM || !cfg->audio_decim || cfg->audio_decim > SDRFM_MAX_DECIM)
@@ -1118,7 +1128,8 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
   h->cfg = *cfg;
   h->device = cfg->device;
   h->max_bytes = cfg->max_bytes_per_call ? cfg->max_bytes_per_call : (1u << 20);
-  h->zc_off = getenv("SDRFM_NO_ZEROCOPY") != nullptr;
+  h->zc_off = (cfg->flags & SDRFM_CFG_NO_ZEROCOPY) != 0;
+  h->prio_balance = 1; h->fold_state_ok = 1;
   h->max_bytes &= ~1u;
   float* hc = (float*)malloc(sizeof(float) * cfg->fir_taps);
   float* gc = (float*)malloc(sizeof(float) * cfg->audio_taps);
@@ -1164,11 +1175,15 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
   snprintf(h->kernel_name, sizeof(h->kernel_name), "%s", h->generic_name);
   if (!(cfg->flags & SDRFM_CFG_FORCE_GENERIC)) {
     char want_kind = 'b';
+    uint32_t want_r = 12, ab_env = 0;
+#ifdef SDRFM_DEV   // every environment knob is a development aid: read once, here, and only in libsdrfm_dev.so
     if (const char* e = getenv("SDRFM_FAST_KIND")) want_kind = e[0];
-    uint32_t want_r = (want_kind == 'b') ? 12 : 3;
+    want_r = (want_kind == 'b') ? 12 : 3;
     if (const char* e = getenv("SDRFM_FAST_R")) want_r = (uint32_t)atoi(e);
-    uint32_t ab_env = 0;
     if (const char* e = getenv("SDRFM_AUDIO_BATCH")) ab_env = (uint32_t)atoi(e);
+    if (getenv("SDRFM_NO_PRIO")) h->prio_balance = 0;
+    if (getenv("SDRFM_NO_FOLD")) h->fold_state_ok = 0;
+#endif
     for (int pass = 0; pass < 3 && !h->fast; ++pass)
     for (const FastVariant& v : kFastVariants) {
       if (v.T != cfg->fir_taps || v.D != cfg->fir_decim) continue;
@@ -1188,20 +1203,26 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
         continue;
       h->AB = AB;
       h->warm_ahead = 0;
+#ifdef SDRFM_DEV
       if (const char* e = getenv("SDRFM_WARM_AHEAD")) h->warm_ahead = (uint32_t)atoi(e);
       if (const char* e = getenv("SDRFM_ABLATE")) { const int m = atoi(e); if (m >= 2 && m <= 7 && v.kernel[m]) h->fast_mode = m; }
       if (getenv("SDRFM_PHASE_PROFILE") && !h->d_dbg && v.kernel[1]) {
         if (hipMalloc(&h->d_dbg, 560 * sizeof(unsigned long long)) != hipSuccess) h->d_dbg = nullptr;
         else { (void)hipMemset(h->d_dbg, 0, 560 * sizeof(unsigned long long)); for (int x = 0; x < 8; ++x) { (void)hipMemset(h->d_dbg + 520 + 4 * x, 0xff, 8); (void)hipMemset(h->d_dbg + 522 + 4 * x, 0xff, 8); } h->fast_mode = 1; }
       }
+#endif
       h->fast = &v;
       h->fast_lds = lds;
       uint32_t per_cu = (uint32_t)((160 * 1024) / lds);
       if (per_cu > 16) per_cu = 16;
+#ifdef SDRFM_DEV
       if (const char* e = getenv("SDRFM_WAVES_PER_CU")) per_cu = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : per_cu;
+#endif
       h->waves_target = (uint32_t)prop.multiProcessorCount * per_cu;
       h->min_subtiles = 4;
+#ifdef SDRFM_DEV
       if (const char* e = getenv("SDRFM_MIN_SUBTILES")) h->min_subtiles = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : 4;
+#endif
       snprintf(h->fast_name, sizeof(h->fast_name), "fast-%c T%u D%u R%u Ta%u Da%u AB%u", v.kind, v.T, v.D, v.R,
                cfg->audio_taps, cfg->audio_decim, AB);
       snprintf(h->kernel_name, sizeof(h->kernel_name), "%s", h->fast_name);
@@ -1291,7 +1312,7 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
   p.phase_x = h->phase_x;
   p.AB = h->AB;
   p.dbg = h->d_dbg;
-  p.prio_balance = getenv("SDRFM_NO_PRIO") ? 0u : 1u;
+  p.prio_balance = h->prio_balance;
   p.dbg_tag = (h->d_dbg && ++h->dbg_launches == 16) ? 1u : 0u;
   p.warm_ahead = h->warm_ahead;
   // Design B cannot express the zero history at the start of a stream in bytes: until T-1 real samples have been seen its
@@ -1320,7 +1341,7 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
     uint32_t grid = c.n_streams * p.tiles_per_stream + c.n_streams;
     // design B: state hand-over folded into the last segment's wave (needs M >= Ta so that the d ring alone holds the
     // new history, and the last sub-tile must contain y[M-1], which the kernel arranges)
-    p.fold_state = (h->fast->kind == 'b' && M >= c.audio_taps && !getenv("SDRFM_NO_FOLD")) ? 1u : 0u;
+    p.fold_state = (h->fast->kind == 'b' && M >= c.audio_taps && h->fold_state_ok) ? 1u : 0u;
     if (p.fold_state) grid -= c.n_streams;
     hipLaunchKernelGGL(h->fast->kernel[h->fast_mode], dim3(grid), dim3(64), h->fast_lds, h->stream, p);
     snprintf(h->kernel_name, sizeof(h->kernel_name), "%s", h->fast_name);

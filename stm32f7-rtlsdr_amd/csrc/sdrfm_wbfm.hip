@@ -507,7 +507,7 @@ struct sdrfm_wbfm {
   size_t lds_bytes;
   bool fused_ok;          // P = 128, HD <= 10: the fused kernel applies
   uint32_t n_cu;          // compute units (fused kernel: run-length choice)
-  uint32_t force_nt;      // SDRFM_WBFM_NT: fixed run length (experiments)
+  uint32_t force_nt;      // SDRFM_WBFM_CFG_RUN_STEPS: fixed run length (tests)
   char kernel_name[48];
 };
 
@@ -547,7 +547,7 @@ extern "C" {
 int sdrfm_wbfm_create(const sdrfm_wbfm_config* cfg, sdrfm_wbfm_t** out) {
   if (!out) return SDRFM_EINVAL;
   *out = nullptr;
-  if (!cfg || cfg->struct_size != sizeof(sdrfm_wbfm_config) || cfg->flags) return SDRFM_EINVAL;
+  if (!cfg || cfg->struct_size != sizeof(sdrfm_wbfm_config) || (cfg->flags & 0xfeu)) return SDRFM_EINVAL;
   if (!cfg->n_streams || !cfg->proto_coeffs || !cfg->resamp_coeffs) return SDRFM_EINVAL;
   if (!cfg->proto_taps || cfg->proto_taps % NB || cfg->proto_taps > 512) return SDRFM_EINVAL;
   if (!cfg->resamp_taps || cfg->resamp_taps > 512 || !cfg->resamp_up || !cfg->resamp_down || cfg->resamp_up > 64 ||
@@ -595,10 +595,9 @@ int sdrfm_wbfm_create(const sdrfm_wbfm_config* cfg, sdrfm_wbfm_t** out) {
     wfree(h);
     return SDRFM_NOT_SUPPORTED;
   }
-  h->fused_ok = (cfg->proto_taps == 128 && h->HD <= 10 && cfg->resamp_up * 10u <= 512u && !getenv("SDRFM_WBFM_GENERIC"));
+  h->fused_ok = (cfg->proto_taps == 128 && h->HD <= 10 && cfg->resamp_up * 10u <= 512u && !(cfg->flags & SDRFM_WBFM_CFG_FORCE_GENERIC));
   h->n_cu = (uint32_t)prop.multiProcessorCount;
-  h->force_nt = 0;
-  if (const char* e = getenv("SDRFM_WBFM_NT")) h->force_nt = (uint32_t)atoi(e) & ~1u;
+  h->force_nt = (cfg->flags >> SDRFM_WBFM_CFG_RUN_STEPS_SHIFT) & ~1u;   // test hook: fixed run length of the fused kernel (0 = chosen per call)
   snprintf(h->kernel_name, sizeof(h->kernel_name), "%s", h->fused_ok ? "wbfm-fused (k_wbfm_fused<8,10>)" : "wbfm-generic (k_wbfm_chan + k_wbfm_res)");
   const int rc = sdrfm_wbfm_reset(h);
   if (rc != SDRFM_OK) { wfree(h); return rc; }

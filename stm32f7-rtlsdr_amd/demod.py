@@ -21,13 +21,15 @@ class FmConfig:
     max_bytes_per_call: int = 1 << 20
     device: int = 0
     force_generic: bool = False     # SDRFM_CFG_FORCE_GENERIC: never use a (T,D)-specialised kernel (tests)
+    no_zerocopy: bool = False       # SDRFM_CFG_NO_ZEROCOPY: URB-sized host calls take the staged copy path (tests)
+    dev_library: bool = False       # load csrc/libsdrfm_dev.so (instrumented / ablation kernels, SDRFM_* environment knobs)
 
 
 class FmDemod:
     """One sdrfm_t handle. Not thread-safe (same model as the reference's single superloop, src/main.c:72-80)."""
 
     def __init__(self, cfg: FmConfig):
-        self._lib = _l.load_library()
+        self._lib = _l.load_library(dev=cfg.dev_library)
         self.cfg = cfg
         h = np.ascontiguousarray(cfg.fir_coeffs, dtype=np.float32)
         g = np.ascontiguousarray(cfg.audio_coeffs, dtype=np.float32)
@@ -40,7 +42,7 @@ class FmDemod:
         c.audio_coeffs = g.ctypes.data_as(C.POINTER(C.c_float))
         c.max_bytes_per_call = cfg.max_bytes_per_call
         c.device = cfg.device
-        c.flags = 1 if cfg.force_generic else 0
+        c.flags = (1 if cfg.force_generic else 0) | (2 if cfg.no_zerocopy else 0)
         self._h = C.c_void_p()
         st = self._lib.sdrfm_create(C.byref(c), C.byref(self._h))
         if st != _l.OK:

@@ -21,6 +21,8 @@ ABI_SYMBOLS = [
     "sdrfm_spectrum_create", "sdrfm_spectrum_destroy", "sdrfm_spectrum_process_batch", "sdrfm_spectrum_set_stream",
     "sdrfm_spectrum_synchronize",
     "sdrfm_pcm_deemph_s16", "sdrfm_pcm_alpha",
+    "sdrfm_pcm_sink_create", "sdrfm_pcm_sink_destroy", "sdrfm_pcm_sink_reset", "sdrfm_pcm_sink_process_batch",
+    "sdrfm_pcm_sink_set_stream", "sdrfm_pcm_sink_synchronize", "sdrfm_pcm_sink_get_state",
     "sdrfm_ring_create", "sdrfm_ring_destroy", "sdrfm_ring_submit", "sdrfm_ring_collect",
 ]
 
@@ -62,23 +64,24 @@ class SpectrumConfig(C.Structure):
     ]
 
 
-def library_path():
-    return os.path.join(_HERE, "csrc", "libsdrfm.so")
+def library_path(dev=False):
+    """csrc/libsdrfm.so (the product) or, with dev=True, csrc/libsdrfm_dev.so (same sources built with -DSDRFM_DEV: adds the
+    instrumented / ablation kernels and the SDRFM_* environment knobs that the scripts under tools/ use)."""
+    return os.path.join(_HERE, "csrc", "libsdrfm_dev.so" if dev else "libsdrfm.so")
 
 
-_lib = None
+_libs = {}
 
 
-def load_library():
-    """Load libsdrfm.so or raise — never substitute anything else for it."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    path = library_path()
+def load_library(dev=False):
+    """Load libsdrfm.so (or the development build) or raise — never substitute anything else for it."""
+    if dev in _libs:
+        return _libs[dev]
+    path = library_path(dev)
     if not os.path.exists(path):
         raise ImportError(
             "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            "(or `make -C stm32f7-rtlsdr_amd/csrc`). There is no fallback implementation." % path)
+            "(or `make -C stm32f7-rtlsdr_amd/csrc%s`). There is no fallback implementation." % (path, " dev" if dev else ""))
     lib = C.CDLL(path)
     vp, u32, u32p = C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)
     lib.sdrfm_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
@@ -157,5 +160,19 @@ def load_library():
     lib.sdrfm_ring_submit.restype = C.c_int
     lib.sdrfm_ring_collect.argtypes = [vp, vp, u32, u32p, C.c_int]
     lib.sdrfm_ring_collect.restype = C.c_int
-    _lib = lib
+    lib.sdrfm_pcm_sink_create.argtypes = [u32, C.c_float, C.c_float, C.c_int32, C.POINTER(vp)]
+    lib.sdrfm_pcm_sink_create.restype = C.c_int
+    lib.sdrfm_pcm_sink_destroy.argtypes = [vp]
+    lib.sdrfm_pcm_sink_destroy.restype = None
+    lib.sdrfm_pcm_sink_reset.argtypes = [vp]
+    lib.sdrfm_pcm_sink_reset.restype = C.c_int
+    lib.sdrfm_pcm_sink_process_batch.argtypes = [vp, vp, C.c_size_t, u32, vp, C.c_size_t, u32]
+    lib.sdrfm_pcm_sink_process_batch.restype = C.c_int
+    lib.sdrfm_pcm_sink_set_stream.argtypes = [vp, vp]
+    lib.sdrfm_pcm_sink_set_stream.restype = C.c_int
+    lib.sdrfm_pcm_sink_synchronize.argtypes = [vp]
+    lib.sdrfm_pcm_sink_synchronize.restype = C.c_int
+    lib.sdrfm_pcm_sink_get_state.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.sdrfm_pcm_sink_get_state.restype = C.c_int
+    _libs[dev] = lib
     return lib

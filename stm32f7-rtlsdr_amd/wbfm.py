@@ -18,6 +18,8 @@ class WbfmConfig:
     n_streams: int = 1
     max_bytes_per_call: int = 1 << 20
     device: int = 0
+    force_generic: bool = False       # SDRFM_WBFM_CFG_FORCE_GENERIC (tests): never run the fused kernel
+    run_steps: int = 0                # SDRFM_WBFM_CFG_RUN_STEPS (tests): fixed run length of the fused kernel, 0 = per call
 
 
 class WbfmDemod:
@@ -32,7 +34,8 @@ class WbfmDemod:
         c.proto_taps, c.proto_coeffs = p.size, p.ctypes.data_as(C.POINTER(C.c_float))
         c.resamp_taps, c.resamp_coeffs = g.size, g.ctypes.data_as(C.POINTER(C.c_float))
         c.resamp_up, c.resamp_down = cfg.resamp_up, cfg.resamp_down
-        c.max_bytes_per_call, c.device, c.flags = cfg.max_bytes_per_call, cfg.device, 0
+        c.max_bytes_per_call, c.device = cfg.max_bytes_per_call, cfg.device
+        c.flags = (1 if cfg.force_generic else 0) | (int(cfg.run_steps) << 8)
         self._h = C.c_void_p()
         st = self._lib.sdrfm_wbfm_create(C.byref(c), C.byref(self._h))
         if st != _l.OK:

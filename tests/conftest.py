@@ -51,3 +51,24 @@ def scaled_err(got, want):
 @pytest.fixture(scope="session")
 def tol():
     return TOL
+
+
+# ---- exact fp32 arithmetic in pure Python (small cases only; shared by the oracle and sink tests) ----------------------
+def round_f32(fr):
+    """Correctly rounded (nearest-even) Fraction -> float32, no double rounding."""
+    from fractions import Fraction
+    if fr == 0:
+        return np.float32(0.0)
+    c = np.float32(float(fr))  # candidate (double-rounded, at most one ulp off)
+    best = None
+    for cand in (np.nextafter(c, np.float32(-np.inf)), c, np.nextafter(c, np.float32(np.inf))):
+        err = abs(Fraction(float(cand)) - fr)
+        key = (err, int(np.float32(cand).view(np.uint32)) & 1)
+        if best is None or key < best[0]:
+            best = (key, cand)
+    return np.float32(best[1])
+
+
+def fma32(a, b, c):
+    from fractions import Fraction
+    return round_f32(Fraction(float(a)) * Fraction(float(b)) + Fraction(float(c)))

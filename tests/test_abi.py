@@ -96,3 +96,23 @@ def test_discriminator_conventions(pkg):
     assert lib.sdrfm_host_discriminate(5.0, 7.0, 5.0, 7.0) == 0.0           # identical samples -> exactly 0
     assert lib.sdrfm_host_discriminate(0.0, 1.0, 1.0, 0.0) == pytest.approx(np.pi / 2, abs=1e-6)
     assert lib.sdrfm_host_discriminate(1.0, 0.0, 0.0, 1.0) == pytest.approx(-np.pi / 2, abs=1e-6)
+
+
+def test_product_library_holds_no_development_kernels_or_environment_knobs(pkg):
+    """libsdrfm.so = result-correct kernels only: no ablation / instrumented / design-A instantiation and not one SDRFM_*
+    environment variable name; those live in libsdrfm_dev.so (built with -DSDRFM_DEV)."""
+    import subprocess
+    path = pkg.library_path()
+    syms = subprocess.run(["nm", "-C", path], capture_output=True, text=True, check=True).stdout
+    kernels = re.findall(r"k_fastb?<[^>]*>", syms)
+    assert kernels, "no specialised kernel found in the product library"
+    for k in kernels:
+        assert k.startswith("k_fastb<") and k.rstrip(">").split(",")[-1].strip() == "0", k    # MODE == 0 only
+    blob = open(path, "rb").read()
+    for knob in (b"SDRFM_ABLATE", b"SDRFM_PHASE_PROFILE", b"SDRFM_FAST_KIND", b"SDRFM_FAST_R", b"SDRFM_AUDIO_BATCH", b"SDRFM_WARM_AHEAD",
+                 b"SDRFM_WAVES_PER_CU", b"SDRFM_MIN_SUBTILES", b"SDRFM_NO_PRIO", b"SDRFM_NO_FOLD", b"SDRFM_NO_ZEROCOPY",
+                 b"SDRFM_WBFM_GENERIC", b"SDRFM_WBFM_NT"):
+        assert knob not in blob, knob
+    dev = pkg.library_path(dev=True)
+    if os.path.exists(dev):
+        assert b"SDRFM_PHASE_PROFILE" in open(dev, "rb").read()

@@ -73,8 +73,11 @@ while time.time() < t_end:
             outs.append(dm.process_batch(iq[:, pos:pos + 2])); pos += 2
     dm.close()
     got = np.concatenate(outs, axis=2)
-    want0 = om.WbfmOracle(pwc, gwc, L, M).process(iq[0])
-    e = float(np.max(np.abs(got[0, 0] - want0[0]) / np.maximum(np.abs(want0[0]), 1.0))) if want0.shape[1] else 0.0
+    e = 0.0                                                        # every stream, every band, every sample against the oracle
+    for s_ in range(ns):
+        want = om.WbfmOracle(pwc, gwc, L, M).process(iq[s_])
+        if want.shape != got[s_].shape: e = 1.0
+        elif want.size: e = max(e, float(np.max(np.abs(got[s_].astype(np.float64) - want) / np.maximum(np.abs(want), 1.0))))
     if got.shape != ref.shape or not np.array_equal(got.view(np.uint32), ref.view(np.uint32)) or e > 1e-5:
         wfails += 1; print("WBFM FAIL", dict(ns=ns, nsamp=nsamp, P=pwc.size, Tg=gwc.size, L=L, M=M, shapes=(got.shape, ref.shape), err=e))
     wcases += 1

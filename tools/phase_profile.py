@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-phase shader-cycle breakdown of the fast kernel on the bench workload (needs SDRFM_PHASE_PROFILE=1)."""
+"""Per-phase shader-cycle breakdown of the fast kernel on the bench workload.
+Runs the DEVELOPMENT library (csrc/libsdrfm_dev.so, `make -C stm32f7-rtlsdr_amd/csrc dev`): the product holds no instrumented kernel."""
 import importlib, os, sys
 os.environ["SDRFM_PHASE_PROFILE"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,7 +8,7 @@ import numpy as np, torch
 pkg = importlib.import_module("stm32f7-rtlsdr_amd")
 ns, nsamp = 256, 240000
 h, g = pkg.default_config(int(os.environ.get("TAPS", "64")))
-dm = pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=ns))
+dm = pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=ns, dev_library=True))
 iq = torch.from_numpy(np.tile(pkg.make_iq(16, nsamp), (16, 1))).cuda()
 audio = torch.zeros((ns, 4801), dtype=torch.float32, device="cuda")
 for _ in range(3):
