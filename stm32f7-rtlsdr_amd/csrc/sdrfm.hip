@@ -41,6 +41,9 @@ __device__ int llvm_amdgcn_raw_buffer_load_i32(i4_t rsrc, int voffset, int soffs
     "llvm.amdgcn.raw.buffer.load.i32");
 __device__ i4_t llvm_amdgcn_raw_buffer_load_v4i32(i4_t rsrc, int voffset, int soffset, int aux) __asm(
     "llvm.amdgcn.raw.buffer.load.v4i32");
+// LDS-DMA: global -> LDS without VGPRs; lane t's `size` bytes land at lds + t * size (buffer_load_dwordx4 ... lds)
+__device__ void llvm_amdgcn_raw_buffer_load_lds(i4_t rsrc, __attribute__((address_space(3))) void* lds, int size, int voffset,
+                                                int soffset, int offset, int aux) __asm("llvm.amdgcn.raw.buffer.load.lds");
 
 namespace {
 
@@ -924,6 +927,235 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 3)))
 #undef SDRFM_TICK
 }
 
+// =================================================================================================================
+//  Fast kernel, design S ("streaming lanes"): every LANE owns a contiguous segment of L = NB*S*D samples of one stream and
+//  walks it once, sample by sample; the wave's 64 segments are consecutive pieces of the same stream.
+//
+//    HBM --buffer_load_dwordx4 ... lds (LDS-DMA, no VGPRs): 10 lanes x 16 B = one lane-segment's next 80 samples-->
+//        LDS ring, 2 stages x 64 lanes x 160 B (the transposition: coalesced 160-B runs in, one 16-B read per lane out)
+//    LDS --ds_read_b128 (8 samples of the lane's own segment)--> v_cvt_f32_ubyte0..3 + v_pk_add_f32(-127.5): EVERY SAMPLE
+//        IS CONVERTED ONCE (design B converts the (T-D)-sample overlap of neighbouring lanes 1.45 times)
+//        --> v_pk_fma_f32 into the S = 8 rotating accumulators ("slots") of the outputs the sample belongs to:
+//            slot s holds output m = s (mod S); at phase p = n mod S*D its tap is h[(D*s + D-1 - p) mod S*D] (or none);
+//            the tap is wave-uniform (all lanes are in phase), broadcast from an SGPR/VGPR pair; the first tap of a chain
+//            writes acc = fma(h, x, 0), so no accumulator is ever cleared; the chain order is the oracle's (oldest first)
+//    y (own lane, no shuffles) --> packed conj-product + atan2, two outputs at a time --> 48 d's per lane in VGPRs
+//    end of the walk: d's --> LDS (the ring is free by then), 32-tap audio FIR with lanes = audio outputs --> HBM
+//
+//  What a lane needs from before its segment (FIR history, y[m-1]) comes from one warm-up stage that runs only the chains
+//  which complete inside the segment; what the audio FIR needs from before the wave's span (Ta-1 d's) comes from lane 0,
+//  which re-walks the segment before the span and emits nothing (1/64 of the work) — or from the carried state when the
+//  span starts the call.  No inter-wave communication, no barriers (one wave per workgroup), no halo carry.
+//
+//  Requirements (else design B): decimator phases 0, N a multiple of L and of D*Da, 16-byte aligned rows, T-1 real history
+//  samples (as design B: the first call after a reset is patched by the generic kernel).
+// =================================================================================================================
+
+// acc = fma(tap, x, +0): the first (oldest) tap of a chain — no accumulator is ever cleared
+template <int HI>
+__device__ __forceinline__ void pk_first_bcast_v(f2_t& acc, f2_t tap_pair, f2_t x) {
+  if constexpr (HI == 0)
+    asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(acc) : "v"(tap_pair), "v"(x));
+  else
+    asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=v"(acc) : "v"(tap_pair), "v"(x));
+}
+
+constexpr int SBODY_WARM = 0, SBODY_MID = 1, SBODY_LAST = 2;
+// first phase of the warm-up body at which a chain that is needed starts: the chain of slot S-1 (it ends at the body's last
+// sample: y[-1] of the segment) or any chain that wraps into the next body (an output of the segment)
+constexpr int stream_warm_first_phase(int T, int D, int S) {
+  const int P = S * D;
+  int first = P - T;
+  for (int sl = 0; sl < S; ++sl) {
+    const int cs = ((D * sl + D - 1 - (T - 1)) % P + P) % P;
+    if (cs + T - 1 >= P && cs < first) first = cs;
+  }
+  return first;
+}
+
+// One body = S*D consecutive samples of every lane's segment, read from the lane's 160-byte region `reg` of one ring stage.
+//   WARM: the stage before the segment — only chains that complete inside the segment (and y[-1]) are run, nothing is emitted
+//   MID : all chains, S outputs -> S discriminator values dn[]
+//   LAST: as MID, but chains that would complete in the next lane's segment are not started
+template <int T, int D, int S, int MODE>
+__device__ __forceinline__ void stream_body(const unsigned char* reg, const f2_t (&hp)[T / 2], f2_t (&acc)[S], f2_t& prev, float (&dn)[S]) {
+  constexpr int P = S * D, NCH = P / 8;
+  constexpr int C0 = (MODE == SBODY_WARM) ? stream_warm_first_phase(T, D, S) / 8 : 0;   // first chunk a needed chain of the WARM body uses
+  u4_t cur = *reinterpret_cast<const u4_t*>(reg + 16 * C0), nxt = cur;
+  f2_t x = cvt_iq<0>(cur.x);                                   // converted one sample ahead of its use: the FMAs (inline asm) never
+  static_for<C0, NCH>([&](auto CC) {                           // directly follow the instruction that produced their operand
+    constexpr int c = decltype(CC)::value;
+    if constexpr (c + 1 < NCH) nxt = *reinterpret_cast<const u4_t*>(reg + 16 * (c + 1));
+    __builtin_amdgcn_sched_barrier(0);                         // one 8-sample chunk is one scheduling region (bounds live ranges)
+    static_for<0, 8>([&](auto S8) {
+      constexpr int s8 = decltype(S8)::value;
+      constexpr int ph = 8 * c + s8;
+      f2_t xn = x;
+      if constexpr (s8 < 7) {
+        constexpr int t8 = s8 + 1;
+        const unsigned w = (t8 / 2 == 0) ? cur.x : (t8 / 2 == 1) ? cur.y : (t8 / 2 == 2) ? cur.z : cur.w;
+        xn = cvt_iq<(t8 & 1)>(w);
+      } else if constexpr (c + 1 < NCH) {
+        xn = cvt_iq<0>(nxt.x);
+      }
+      static_for<0, S>([&](auto SS) {
+        constexpr int sl = decltype(SS)::value;
+        constexpr int e = ((D * sl + D - 1 - ph) % P + P) % P;  // tap index of slot sl at this phase (>= T: idle)
+        constexpr int cs = ((D * sl + D - 1 - (T - 1)) % P + P) % P;   // phase at which slot sl starts a chain
+        constexpr bool wraps = (cs + T - 1 >= P);              // that chain completes in the NEXT body
+        constexpr bool head = wraps && ph >= cs;               // this phase belongs to a chain completing in the next body
+        constexpr bool run = (e < T) && ((MODE == SBODY_MID) || (MODE == SBODY_LAST && !head) ||
+                                         (MODE == SBODY_WARM && (head || (sl == S - 1 && ph >= cs))));
+        if constexpr (run) {
+          // the tap is wave-uniform: one half of a VGPR pair, broadcast to both halves of the pack by op_sel
+          if constexpr (e == T - 1) { if constexpr (e & 1) pk_first_bcast_v<1>(acc[sl], hp[e / 2], x); else pk_first_bcast_v<0>(acc[sl], hp[e / 2], x); }
+          else { if constexpr (e & 1) pk_fma_bcast_v<1>(acc[sl], hp[e / 2], x); else pk_fma_bcast_v<0>(acc[sl], hp[e / 2], x); }
+        }
+      });
+      // outputs complete at phases D-1, 2D-1, ...: slot ph / D; every second one closes a pair for the packed discriminator
+      if constexpr (MODE != SBODY_WARM && ph % D == D - 1 && ((ph / D) & 1) == 1) {
+        constexpr int s1 = ph / D, s0 = s1 - 1;
+        const f2_t d2 = discriminate_pair(acc[s0], prev, acc[s1]);
+        dn[s0] = d2.x;
+        dn[s1] = d2.y;
+        prev = acc[s1];
+      }
+      x = xn;
+    });
+    cur = nxt;
+  });
+  if constexpr (MODE == SBODY_WARM) prev = acc[S - 1];       // y[-1] of the segment
+}
+
+template <int T, int D, int S, int NB, int TA, int DA>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_stream(CallParams p) {
+  constexpr int P = S * D, L = NB * P, OPL = NB * S;           // samples per body / per lane segment, outputs per lane
+  constexpr int STAGE = 2 * P;                                  // bytes per lane per ring stage (160)
+  constexpr int SL16 = STAGE / 16;                              // 16-byte pieces per lane per stage (10)
+  constexpr int LPI = 64 / SL16;                                // lane-segments one DMA instruction fills (6)
+  constexpr int NDMA = (64 + LPI - 1) / LPI;                    // DMA instructions per stage (11)
+  constexpr int RING = 64 * STAGE;                              // bytes per stage (10240)
+  static_assert(P % 8 == 0 && S % 2 == 0 && P >= T && T % 2 == 0 && (OPL % 4) == 0 && TA - 1 <= OPL, "design S geometry");
+  static_assert(2 * RING >= (64 * OPL + TA) * 4, "the d array of the audio stage reuses the ring");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = (int)threadIdx.x;
+  const uint32_t stream = blockIdx.x / p.tiles_per_stream;
+  const int w = (int)(blockIdx.x % p.tiles_per_stream);         // wave index inside the stream
+  const int segs = (int)(p.N / L);                              // lane segments of this stream in this call
+  const int g0 = 63 * w - 1;                                    // segment of lane 0 (-1: before the call)
+  int nuse = segs - 63 * w;                                     // useful lanes 1..nuse
+  if (nuse > 63) nuse = 63;
+
+  f2_t hp[T / 2];                                               // taps: wave-uniform pairs held in VGPRs (64 taps would not fit the SGPR
+#pragma unroll                                                  // file next to the kernel's scalars); op_sel picks the half at each use
+  for (int k = 0; k < T / 2; ++k) hp[k] = f2_t{p.h[2 * k], p.h[2 * k + 1]};
+#pragma unroll
+  for (int k = 0; k < T / 2; ++k) asm volatile("" : "+v"(hp[k]));
+
+  // The buffer descriptor starts BIAS bytes before the stream's row so that every per-lane offset is non-negative (the hardware
+  // range-checks the VGPR offset alone, as unsigned); no address below the row is ever fetched (those lanes are switched off).
+  constexpr int BIAS = (L + P) * 2;
+  const unsigned long long gaddr = (unsigned long long)(p.iq + (size_t)stream * p.iq_stride) - BIAS;
+  const i4_t rsrc = {(int)(unsigned)gaddr, (int)(unsigned)(gaddr >> 32), (int)(2u * p.N + BIAS), 0x00020000};
+  // LDS-DMA addressing: lane t of DMA instruction i fetches piece t % 10 of lane-segment q = 6 i + t / 10.  The per-lane part of
+  // the byte offset is one VGPR, the (instruction, stage) part is scalar; a lane whose segment lies outside the call (lane 0
+  // of the first wave, lanes beyond the stream's end, the warm-up stage of the call's first segment) is switched off.
+  const int qsub = lane / SL16;
+  const int vbase = BIAS + ((g0 + qsub) * L - P) * 2 + (lane % SL16) * 16;
+  bool ok[NDMA];
+#pragma unroll
+  for (int i = 0; i < NDMA; ++i) {
+    const int q = LPI * i + qsub, g = g0 + q;
+    ok[i] = lane < LPI * SL16 && q < 64 && g >= 0 && g < segs;
+  }
+  int stage_off = 0;
+  auto issue_stage = [&](int parity, bool first) {
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+      if (ok[i] && !(first && g0 + LPI * i + qsub == 0))
+        llvm_amdgcn_raw_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(smem + parity * RING + i * (LPI * STAGE)), 16,
+                                        vbase, stage_off + i * (LPI * L * 2), 0, 0);
+    }
+    stage_off += STAGE;
+  };
+
+  issue_stage(0, true);
+  f2_t acc[S];
+#pragma unroll
+  for (int k = 0; k < S; ++k) acc[k] = f2_t{0.f, 0.f};
+  f2_t prev = {0.f, 0.f};
+  float dn[S], dreg[OPL];
+  const unsigned char* myreg = smem + lane * STAGE;
+  __builtin_amdgcn_s_waitcnt(0x0f70);                           // vmcnt(0): stage 0 has landed
+  if (w == 0) {
+    // the first segment of the call: its warm-up stage is the carried raw history (T-1 samples right-aligned in lane 1's region)
+    unsigned char* r1 = smem + 1 * STAGE;
+    for (int k = lane; k < T - 1; k += 64)
+      *reinterpret_cast<unsigned short*>(r1 + STAGE - 2 * (T - 1) + 2 * k) =
+          reinterpret_cast<const unsigned short*>(p.hist_b_in)[(size_t)stream * (T - 1) + k];
+    __syncthreads();
+  }
+  issue_stage(1, false);
+  stream_body<T, D, S, SBODY_WARM>(myreg, hp, acc, prev, dn);
+  if (w == 0 && lane == 1) { const float2 yp = p.yprev_in[stream]; prev = f2_t{yp.x, yp.y}; }
+  for (int b = 0; b < NB - 1; ++b) {
+    __builtin_amdgcn_s_waitcnt(0x0f70);                         // stage b+1 has landed
+    issue_stage(b & 1, false);                                  // stage b+2 into the buffer body b-1 (or the warm-up) has drained
+    stream_body<T, D, S, SBODY_MID>(myreg + ((b + 1) & 1) * RING, hp, acc, prev, dn);
+#pragma unroll
+    for (int bb = 0; bb < NB - 1; ++bb)
+      if (b == bb) {
+        asm volatile("" ::: "memory");                          // keep this a scalar branch: S moves, not NB*S selects
+#pragma unroll
+        for (int k = 0; k < S; ++k) dreg[bb * S + k] = dn[k];
+      }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0f70);
+  stream_body<T, D, S, SBODY_LAST>(myreg + (NB & 1) * RING, hp, acc, prev, dn);
+#pragma unroll
+  for (int k = 0; k < S; ++k) dreg[(NB - 1) * S + k] = dn[k];
+
+  // ---- audio stage: d's of the whole span -> LDS (linear in d index; lane 0's segment first), lanes = audio outputs ------
+  float* dl = reinterpret_cast<float*>(smem);
+  float* gs = dl + 64 * OPL;                                    // audio taps, reversed
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < OPL; k += 4) *reinterpret_cast<f4_t*>(dl + lane * OPL + k) = f4_t{dreg[k], dreg[k + 1], dreg[k + 2], dreg[k + 3]};
+  if (lane < TA) gs[lane] = p.g[TA - 1 - lane];
+  if (w == 0 && lane < TA - 1) dl[OPL - (TA - 1) + lane] = p.hist_d_in[(size_t)stream * (TA - 1) + lane];
+  __syncthreads();
+  const int G0 = 63 * w * OPL, G1 = G0 + nuse * OPL;           // d's [G0, G1) belong to this wave; local index = d - G0 + OPL
+  const int jl = G0 / DA, jh = G1 / DA;                         // audio outputs whose newest d lies in [G0, G1)
+  float* out = p.audio + (size_t)stream * p.audio_stride;
+  for (int j = jl + lane; j < jh; j += 192) {
+    const int jb = j + 64, jc = j + 128;
+    const float* w0 = dl + (DA * j + DA - 1 - (TA - 1) - G0 + OPL);
+    const float* w1 = (jb < jh) ? w0 + 64 * DA : w0;
+    const float* w2 = (jc < jh) ? w0 + 128 * DA : w0;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+#pragma unroll 4
+    for (int k = 0; k < TA; ++k) {
+      const float gk = gs[k];
+      a0 = __builtin_fmaf(gk, w0[k], a0);
+      a1 = __builtin_fmaf(gk, w1[k], a1);
+      a2 = __builtin_fmaf(gk, w2[k], a2);
+    }
+    __builtin_nontemporal_store(a0, out + j);
+    if (jb < jh) __builtin_nontemporal_store(a1, out + jb);
+    if (jc < jh) __builtin_nontemporal_store(a2, out + jc);
+  }
+  // ---- state hand-over by the wave that holds the end of the stream's chunk ------------------------------------------------
+  if (p.fold_state && 63 * w + nuse == segs) {
+    if (lane == nuse) p.yprev_out[stream] = make_float2(prev.x, prev.y);
+    for (int k = lane; k < TA - 1; k += 64) p.hist_d_out[(size_t)stream * (TA - 1) + k] = dl[(nuse + 1) * OPL - (TA - 1) + k];
+    for (int k = lane; k < T - 1; k += 64) {
+      const int c = (int)p.N - (T - 1) + k;
+      p.hist_x_out[(size_t)stream * (T - 1) + k] = load_x(p, stream, c);
+      reinterpret_cast<unsigned short*>(p.hist_b_out)[(size_t)stream * (T - 1) + k] = (unsigned short)load_raw(p, stream, c);
+    }
+  }
+}
+
 // test hook: evaluates K3 on the device both ways the kernels do (scalar form and packed-pair form)
 __global__ void k_debug_discriminate(const float* yr, const float* yi, const float* pr, const float* pi, float* out_scalar,
                                      float* out_pair, int n) {
@@ -936,11 +1168,12 @@ __global__ void k_debug_discriminate(const float* yr, const float* yi, const flo
 }
 
 struct FastVariant {
-  char kind;                         // 'a' = float tile (design A), 'b' = raw-byte tile (design B)
-  uint32_t T, D, R;
+  char kind;                         // 'a' = float tile (design A), 'b' = raw-byte tile (design B), 's' = streaming lanes (design S)
+  uint32_t T, D, R;                  // R: outputs per lane and sub-tile (A, B) / accumulator slots (S)
   uint32_t Ta, Da;                   // design B only: compile-time audio geometry (0 = any)
   void (*kernel[8])(CallParams);   // [0] product; [1..7] timing experiments (profile / ablations)
-  uint32_t xbytes;
+  uint32_t xbytes;                   // LDS bytes of the sample tile (A, B) / of the whole ring (S)
+  uint32_t seg;                      // design S: samples per lane segment (0 otherwise)
 };
 #ifdef SDRFM_DEV
 #define SDRFM_FAST(T_, D_, R_) { 'a', T_, D_, R_, 0, 0, {k_fast<T_, D_, R_, 0>, k_fast<T_, D_, R_, 1>, k_fast<T_, D_, R_, 2>, k_fast<T_, D_, R_, 3>, k_fast<T_, D_, R_, 4>, k_fast<T_, D_, R_, 5>, k_fast<T_, D_, R_, 6>, k_fast<T_, D_, R_, 7>}, (uint32_t)fast_xbytes(T_, D_, R_) }
@@ -955,7 +1188,10 @@ struct FastVariant {
 #endif
 #define SDRFM_FASTB2_LITE(T_, D_, R_, TA_, DA_) { 'b', T_, D_, R_, TA_, DA_, {k_fastb<T_, D_, R_, TA_, DA_, 0>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, (uint32_t)fastb_xbytes(T_, D_, R_) }
 #define SDRFM_FASTB(T_, D_, R_) SDRFM_FASTB2(T_, D_, R_, 32, 5)
+#define SDRFM_STREAM(T_, D_, S_, NB_, TA_, DA_) { 's', T_, D_, S_, TA_, DA_, {k_stream<T_, D_, S_, NB_, TA_, DA_>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, 2u * 64u * 2u * (S_) * (D_), (uint32_t)(NB_) * (S_) * (D_) }
 const FastVariant kFastVariants[] = {
+    // design S (streaming lanes): the BASELINE configs[2]/[3] shape; serves calls that are whole numbers of lane segments
+    SDRFM_STREAM(64, 10, 8, 6, 32, 5),
     // 2.4 MS/s -> 240 kS/s -> 48 kHz: the rate the firmware programs (usbh_rtlsdr.c:898) and the BASELINE configs
     SDRFM_FASTB2_ABL(64, 10, 12, 32, 5), SDRFM_FASTB2_LITE(64, 10, 8, 32, 5), SDRFM_FASTB(16, 10, 12), SDRFM_FASTB2_LITE(32, 10, 12, 32, 5),
     // the other rates RTLSDR_set_sample_rate accepts and a dongle is commonly run at:
@@ -999,6 +1235,8 @@ struct sdrfm {
   size_t lds_bytes;
   // fast kernel (when one is instantiated for this T/D)
   const FastVariant* fast;
+  const FastVariant* fast_s;  // design S variant of this geometry, if one is instantiated (serves the calls it is eligible for)
+  char fast_s_name[64];
   size_t fast_lds;
   uint32_t waves_target;   // resident waves the fast kernel aims for (CUs x waves that fit by LDS)
   uint32_t min_subtiles;   // minimum sub-tiles per segment (bounds the per-segment halo recompute)
@@ -1184,8 +1422,17 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
     if (getenv("SDRFM_NO_PRIO")) h->prio_balance = 0;
     if (getenv("SDRFM_NO_FOLD")) h->fold_state_ok = 0;
 #endif
+    for (const FastVariant& v : kFastVariants) {
+      if (v.kind != 's' || v.T != cfg->fir_taps || v.D != cfg->fir_decim || v.Ta != cfg->audio_taps || v.Da != cfg->audio_decim) continue;
+#ifdef SDRFM_DEV
+      if (getenv("SDRFM_NO_STREAM")) continue;
+#endif
+      h->fast_s = &v;
+      snprintf(h->fast_s_name, sizeof(h->fast_s_name), "fast-s T%u D%u S%u L%u Ta%u Da%u", v.T, v.D, v.R, v.seg, v.Ta, v.Da);
+    }
     for (int pass = 0; pass < 3 && !h->fast; ++pass)
     for (const FastVariant& v : kFastVariants) {
+      if (v.kind == 's') continue;
       if (v.T != cfg->fir_taps || v.D != cfg->fir_decim) continue;
       if (v.Ta && (v.Ta != cfg->audio_taps || v.Da != cfg->audio_decim)) continue;
       if (pass == 0 && (v.R != want_r || v.kind != want_kind)) continue;
@@ -1323,7 +1570,16 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
   const bool short_first = h->fast && h->fast->kind == 'b' && h->n_seen + 1 < c.fir_taps && M < y_aff + c.audio_taps;
   const bool fast_ok = h->fast && A > 0 && (h->phase_x % 2 == 0) && ((uintptr_t)d_iq % 4 == 0) && (iq_stride % 4 == 0) &&
                        N < (1u << 30) && !short_first;
-  if (fast_ok) {
+  const bool stream_ok = fast_ok && h->fast_s && h->phase_x == 0 && h->phase_d == 0 && (N % h->fast_s->seg) == 0 &&
+                         (M % c.audio_decim) == 0 && M >= c.audio_taps && ((uintptr_t)d_iq % 16 == 0) && (iq_stride % 16 == 0) &&
+                         h->fold_state_ok;
+  if (stream_ok) {
+    const uint32_t segs = N / h->fast_s->seg;
+    p.tiles_per_stream = (segs + 62) / 63;                      // waves per stream: 63 useful lane segments each
+    p.fold_state = 1;
+    hipLaunchKernelGGL(h->fast_s->kernel[0], dim3(c.n_streams * p.tiles_per_stream), dim3(64), h->fast_s->xbytes, h->stream, p);
+    snprintf(h->kernel_name, sizeof(h->kernel_name), "%s", h->fast_s_name);
+  } else if (fast_ok) {
     // split every stream into segments so that ~waves_target waves are resident; each segment >= min_subtiles sub-tiles
     const uint32_t NYT = 64 * h->fast->R;
     const uint32_t sub_total = (M + NYT - 1) / NYT;
@@ -1345,23 +1601,23 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
     if (p.fold_state) grid -= c.n_streams;
     hipLaunchKernelGGL(h->fast->kernel[h->fast_mode], dim3(grid), dim3(64), h->fast_lds, h->stream, p);
     snprintf(h->kernel_name, sizeof(h->kernel_name), "%s", h->fast_name);
-    if (h->fast->kind == 'b' && h->n_seen + 1 < c.fir_taps) {
-      // Design B reads its halo as bytes, which cannot express the zero history at the start of a stream: the few audio
-      // outputs that depend on inputs before the first real sample are recomputed by the generic kernel (tile 0..k only).
-      const uint32_t a_aff = (y_aff + c.audio_taps + c.audio_decim - 1) / c.audio_decim;  // audio outputs touching them
-      CallParams q = p;
-      q.NA = h->NA;
-      q.tiles_per_stream = (a_aff + h->NA - 1) / h->NA;
-      const uint32_t full = (A + h->NA - 1) / h->NA;
-      if (q.tiles_per_stream > full) q.tiles_per_stream = full;
-      hipLaunchKernelGGL(k_generic, dim3(c.n_streams * q.tiles_per_stream), dim3(256), h->lds_bytes, h->stream, q);
-    }
   } else {
     p.NA = h->NA;
     p.tiles_per_stream = (A + h->NA - 1) / h->NA;
     const uint32_t grid = c.n_streams * p.tiles_per_stream + c.n_streams;
     hipLaunchKernelGGL(k_generic, dim3(grid), dim3(256), h->lds_bytes, h->stream, p);
     snprintf(h->kernel_name, sizeof(h->kernel_name), "%s", h->generic_name);
+  }
+  if ((stream_ok || (fast_ok && h->fast->kind == 'b')) && h->n_seen + 1 < c.fir_taps) {
+    // Designs B and S read their halo as bytes, which cannot express the zero history at the start of a stream: the few audio
+    // outputs that depend on inputs before the first real sample are recomputed by the generic kernel (tile 0..k only).
+    const uint32_t a_aff = (y_aff + c.audio_taps + c.audio_decim - 1) / c.audio_decim;  // audio outputs touching them
+    CallParams q = p;
+    q.NA = h->NA;
+    q.tiles_per_stream = (a_aff + h->NA - 1) / h->NA;
+    const uint32_t full = (A + h->NA - 1) / h->NA;
+    if (q.tiles_per_stream > full) q.tiles_per_stream = full;
+    hipLaunchKernelGGL(k_generic, dim3(c.n_streams * q.tiles_per_stream), dim3(256), h->lds_bytes, h->stream, q);
   }
   HIP_TRY(hipGetLastError(), SDRFM_FAIL);
 

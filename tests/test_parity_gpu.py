@@ -270,6 +270,39 @@ def test_specialised_kernels_equal_generic_kernel_bitwise(pkg, oracle_mod, monke
     fast.close(); gen.close()
 
 
+@pytest.mark.parametrize("ns,calls", [
+    (1, [2400]),                                  # 5 lane segments: one wave, mostly idle lanes, first call (zero history patched)
+    (1, [4800, 2400, 48000, 2400]),               # carried state between streaming-kernel calls
+    (3, [151200, 2400]),                          # 315 segments: five completely full waves per stream
+    (2, [31200, 240000]),                         # 65 segments: two waves per stream, the second nearly empty; then 8 waves
+    (5, [7200, 1000, 2400, 2402, 2398, 24000]),   # eligible and ineligible sizes alternate: design S <-> design B/generic on one state
+])
+def test_streaming_lane_kernel_equals_generic_kernel_bitwise(pkg, oracle_mod, ns, calls):
+    """Design S (streaming lanes, LDS-DMA ring, slot accumulators) runs the oracle's chains in the oracle's order: its audio is
+    bit-identical to the generic kernel's for every call pattern it serves, and the state it hands over is interchangeable
+    with the other kernels'."""
+    h, g = pkg.default_config(64)
+    total = sum(calls)
+    iq = np.concatenate([pkg.make_iq(max(ns - 1, 1), total, mode="fm", first_id=900), pkg.make_iq(1, total, mode="random", first_id=950)])[-ns:]
+    kw = dict(fir_coeffs=h, audio_coeffs=g, n_streams=ns, max_bytes_per_call=2 * max(calls))
+    fast = pkg.FmDemod(pkg.FmConfig(**kw))
+    gen = pkg.FmDemod(pkg.FmConfig(force_generic=True, **kw))
+    pos, names, a_fast, a_gen = 0, [], [], []
+    for n in calls:
+        a_fast.append(fast.process_batch(iq[:, 2 * pos:2 * (pos + n)]))
+        names.append(fast.kernel_name.split()[0])
+        a_gen.append(gen.process_batch(iq[:, 2 * pos:2 * (pos + n)]))
+        pos += n
+    for n, name in zip(calls, names):
+        if n % 2400 == 0:
+            assert name == "fast-s", (n, names)
+    a_fast, a_gen = np.concatenate(a_fast, axis=1), np.concatenate(a_gen, axis=1)
+    assert np.array_equal(a_fast.view(np.uint32), a_gen.view(np.uint32)), int(np.argmax((a_fast != a_gen).any(axis=0)))
+    for s_ in range(ns):
+        assert scaled_err(a_fast[s_], oracle_mod.Oracle(h, g).process(iq[s_])) <= TOL
+    fast.close(); gen.close()
+
+
 @pytest.mark.parametrize("T,D,Da,fs", [(64, 8, 8, 2.048e6), (16, 8, 8, 2.048e6), (64, 4, 8, 1.024e6), (64, 16, 5, 3.2e6)])
 def test_other_dongle_rates_have_specialised_kernels(pkg, oracle_mod, T, D, Da, fs):
     """2.048 / 1.024 / 3.2 MS/s front ends (rates RTLSDR_set_sample_rate accepts) get a design-B kernel too; it must equal
