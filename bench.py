@@ -53,6 +53,8 @@ def parse():
                     help="fm = BASELINE configs[2]/[3] (default, the headline); wbfm = configs[4] channelizer path, 128 streams/GPU; "
                          "spectrum = FFT view (SURVEY 8f-3) of the configs[2] buffers")
     ap.add_argument("--nfft", type=int, default=1024, help="spectrum workload: FFT length")
+    ap.add_argument("--dev-library", action="store_true", help="fm workload: load csrc/libsdrfm_dev.so (honours the SDRFM_* development "
+                    "knobs, e.g. SDRFM_NO_STREAM=1 for design B); the reported line then says so and is not a product figure")
     ap.add_argument("--end-to-end", action="store_true",
                     help="fm workload: every step also scatters the IQ batch from rank 0 to all ranks and gathers the audio back "
                          "over RCCL (SURVEY 8e C1/C2); reported separately from the compute-only default")
@@ -229,7 +231,8 @@ def main():
     h, g = pkg.default_config(args.fir_taps, fs=fs)
     D, Da = 10, 5
 
-    dm = pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, fir_decim=D, audio_decim=Da, n_streams=ns, device=local_rank))
+    dm = pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, fir_decim=D, audio_decim=Da, n_streams=ns, device=local_rank,
+                                  dev_library=args.dev_library))
     stream = torch.cuda.Stream()
     dm.set_stream(stream.cuda_stream)
     nb = pick_batches(args, ns * nbytes)
@@ -324,6 +327,8 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes},
             "gen_seconds": round(t_gen, 2),
         }
+        if args.dev_library:
+            res["library"] = "libsdrfm_dev.so (development build: NOT the product figure)"
         if elapsed_res is not None:
             res["resident_input"] = {"value": round(float(world) * ns * nsamp * res_steps / elapsed_res / 1e6, 1), "unit": "MSamples/s",
                                      "kernel_ms_avg": round(kernel_ms_res, 4), "steps": res_steps,

@@ -1035,6 +1035,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   constexpr int LPI = 64 / SL16;                                // lane-segments one DMA instruction fills (6)
   constexpr int NDMA = (64 + LPI - 1) / LPI;                    // DMA instructions per stage (11)
   constexpr int RING = 64 * STAGE;                              // bytes per stage (10240)
+  constexpr int WARM_PIECE0 = stream_warm_first_phase(T, D, S) / 8;   // first 16-byte piece of the warm-up stage that is read
   static_assert(P % 8 == 0 && S % 2 == 0 && P >= T && T % 2 == 0 && (OPL % 4) == 0 && TA - 1 <= OPL, "design S geometry");
   static_assert(2 * RING >= (64 * OPL + TA) * 4, "the d array of the audio stage reuses the ring");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1072,13 +1073,27 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   auto issue_stage = [&](int parity, bool first) {
 #pragma unroll
     for (int i = 0; i < NDMA; ++i) {
-      if (ok[i] && !(first && g0 + LPI * i + qsub == 0))
+      // the warm-up stage: not for the call's first segment (it gets the carried history), and only the pieces the warm-up reads
+      if (ok[i] && !(first && (g0 + LPI * i + qsub == 0 || lane % SL16 < WARM_PIECE0)))
         llvm_amdgcn_raw_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(smem + parity * RING + i * (LPI * STAGE)), 16,
                                         vbase, stage_off + i * (LPI * L * 2), 0, 0);
     }
     stage_off += STAGE;
   };
 
+#ifdef SDRFM_DEV   // development build: per-wave time stamps (shader cycles) at the phase boundaries, 32 words per wave
+  unsigned long long* const tsp = (p.dbg && p.dbg_tag) ? p.dbg + 32 * (size_t)blockIdx.x : nullptr;
+  int tsi = 0;
+#define SDRFM_STAMP() do { if (tsp && lane == 0) tsp[tsi] = __builtin_readcyclecounter(); ++tsi; } while (0)
+  if (tsp && lane == 0) { tsp[30] = __builtin_amdgcn_s_memrealtime(); tsp[29] = __builtin_amdgcn_s_getreg((3 << 11) | 20) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32); }
+#else
+#define SDRFM_STAMP() do { } while (0)
+#endif
+  SDRFM_STAMP();                                                // 0: entry
+#ifdef SDRFM_DEV
+  if (p.warm_ahead && (__builtin_amdgcn_s_getreg((4 << 11) | 4) & 1))   // experiment: the wave in the odd slot of its SIMD starts late
+    for (uint32_t z = 0; z < p.warm_ahead; ++z) __builtin_amdgcn_s_sleep(16);
+#endif
   issue_stage(0, true);
   f2_t acc[S];
 #pragma unroll
@@ -1087,6 +1102,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   float dn[S], dreg[OPL];
   const unsigned char* myreg = smem + lane * STAGE;
   __builtin_amdgcn_s_waitcnt(0x0f70);                           // vmcnt(0): stage 0 has landed
+  SDRFM_STAMP();                                                // 1: first stage in LDS
   if (w == 0) {
     // the first segment of the call: its warm-up stage is the carried raw history (T-1 samples right-aligned in lane 1's region)
     unsigned char* r1 = smem + 1 * STAGE;
@@ -1098,8 +1114,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   issue_stage(1, false);
   stream_body<T, D, S, SBODY_WARM>(myreg, hp, acc, prev, dn);
   if (w == 0 && lane == 1) { const float2 yp = p.yprev_in[stream]; prev = f2_t{yp.x, yp.y}; }
+  SDRFM_STAMP();                                                // 2: warm-up body done
   for (int b = 0; b < NB - 1; ++b) {
     __builtin_amdgcn_s_waitcnt(0x0f70);                         // stage b+1 has landed
+    SDRFM_STAMP();                                              // 3, 5, 7, ...: stage wait over
     issue_stage(b & 1, false);                                  // stage b+2 into the buffer body b-1 (or the warm-up) has drained
     stream_body<T, D, S, SBODY_MID>(myreg + ((b + 1) & 1) * RING, hp, acc, prev, dn);
 #pragma unroll
@@ -1109,12 +1127,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
         for (int k = 0; k < S; ++k) dreg[bb * S + k] = dn[k];
       }
+    SDRFM_STAMP();                                              // 4, 6, 8, ...: body done
   }
   __builtin_amdgcn_s_waitcnt(0x0f70);
   stream_body<T, D, S, SBODY_LAST>(myreg + (NB & 1) * RING, hp, acc, prev, dn);
 #pragma unroll
   for (int k = 0; k < S; ++k) dreg[(NB - 1) * S + k] = dn[k];
 
+  SDRFM_STAMP();                                                // 3 + 2(NB-1): last body done
   // ---- audio stage: d's of the whole span -> LDS (linear in d index; lane 0's segment first), lanes = audio outputs ------
   float* dl = reinterpret_cast<float*>(smem);
   float* gs = dl + 64 * OPL;                                    // audio taps, reversed
@@ -1126,24 +1146,43 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   __syncthreads();
   const int G0 = 63 * w * OPL, G1 = G0 + nuse * OPL;           // d's [G0, G1) belong to this wave; local index = d - G0 + OPL
   const int jl = G0 / DA, jh = G1 / DA;                         // audio outputs whose newest d lies in [G0, G1)
-  float* out = p.audio + (size_t)stream * p.audio_stride;
-  for (int j = jl + lane; j < jh; j += 192) {
-    const int jb = j + 64, jc = j + 128;
-    const float* w0 = dl + (DA * j + DA - 1 - (TA - 1) - G0 + OPL);
-    const float* w1 = (jb < jh) ? w0 + 64 * DA : w0;
-    const float* w2 = (jc < jh) ? w0 + 128 * DA : w0;
-    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
-#pragma unroll 4
-    for (int k = 0; k < TA; ++k) {
-      const float gk = gs[k];
-      a0 = __builtin_fmaf(gk, w0[k], a0);
-      a1 = __builtin_fmaf(gk, w1[k], a1);
-      a2 = __builtin_fmaf(gk, w2[k], a2);
+  // Every lane computes NOUT consecutive outputs from ND consecutive d's: all LDS reads are issued up front (nothing in the
+  // chains waits on memory), the taps sit in registers, and the results go back through LDS so that the stores are coalesced.
+  constexpr int NOUT = ((63 * OPL + DA - 1) / DA + 63) / 64, ND = (NOUT - 1) * DA + TA;
+  float* outl = gs + TA;                                        // 64 * NOUT results
+  static_assert((64 * OPL + TA + 64 * NOUT) * 4 <= 2 * RING && (DA * 64 * NOUT + TA + OPL) * 4 <= 2 * RING, "audio stage scratch exceeds the ring");
+  float gv[TA];
+#pragma unroll
+  for (int k = 0; k < TA; ++k) gv[k] = gs[k];
+  {
+    const int j0 = jl + lane * NOUT;
+    // local index of the oldest d of output j0.  The lanes around the last output read past the d array, into the taps and
+    // the (not yet written) result area behind it: still inside the ring, and only into outputs that are never stored
+    const int base = DA * j0 + DA - 1 - (TA - 1) - G0 + OPL;
+    const float* wd = dl + base;
+    float dw[ND];
+#pragma unroll
+    for (int k = 0; k < ND; ++k) dw[k] = wd[k];
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) {
+      float a = 0.0f;
+#pragma unroll
+      for (int k = 0; k < TA; ++k) a = __builtin_fmaf(gv[k], dw[DA * i + k], a);
+      outl[lane * NOUT + i] = a;
     }
-    __builtin_nontemporal_store(a0, out + j);
-    if (jb < jh) __builtin_nontemporal_store(a1, out + jb);
-    if (jc < jh) __builtin_nontemporal_store(a2, out + jc);
   }
+  __syncthreads();
+  float* out = p.audio + (size_t)stream * p.audio_stride;
+#pragma unroll
+  for (int m = 0; m < NOUT; ++m) {
+    const int j = jl + 64 * m + lane;
+    if (j < jh) __builtin_nontemporal_store(outl[64 * m + lane], out + j);
+  }
+  SDRFM_STAMP();                                                // audio stage done
+#ifdef SDRFM_DEV
+  if (tsp && lane == 0) tsp[31] = __builtin_amdgcn_s_memrealtime();
+#endif
+#undef SDRFM_STAMP
   // ---- state hand-over by the wave that holds the end of the stream's chunk ------------------------------------------------
   if (p.fold_state && 63 * w + nuse == segs) {
     if (lane == nuse) p.yprev_out[stream] = make_float2(prev.x, prev.y);
@@ -1246,6 +1285,7 @@ struct sdrfm {
   uint32_t dbg_launches;      // launches since the debug counters were last reset
   int fast_mode;              // 0 product; 1..7 timing experiments (libsdrfm_dev.so only)
   uint32_t prio_balance, fold_state_ok;   // design B knobs, fixed at create
+  uint32_t stream_profile;                // development build: d_dbg holds per-wave time stamps of design S
   char kernel_name[64];
   char generic_name[64];
   char fast_name[64];
@@ -1427,6 +1467,12 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
 #ifdef SDRFM_DEV
       if (getenv("SDRFM_NO_STREAM")) continue;
 #endif
+#ifdef SDRFM_DEV
+      if (getenv("SDRFM_STREAM_PROFILE") && !h->d_dbg) {        // 16 words per wave, up to 16384 waves
+        if (hipMalloc(&h->d_dbg, 32 * 16384 * sizeof(unsigned long long)) != hipSuccess) h->d_dbg = nullptr;
+        else { (void)hipMemset(h->d_dbg, 0, 32 * 16384 * sizeof(unsigned long long)); h->stream_profile = 1; }
+      }
+#endif
       h->fast_s = &v;
       snprintf(h->fast_s_name, sizeof(h->fast_s_name), "fast-s T%u D%u S%u L%u Ta%u Da%u", v.T, v.D, v.R, v.seg, v.Ta, v.Da);
     }
@@ -1453,7 +1499,7 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
 #ifdef SDRFM_DEV
       if (const char* e = getenv("SDRFM_WARM_AHEAD")) h->warm_ahead = (uint32_t)atoi(e);
       if (const char* e = getenv("SDRFM_ABLATE")) { const int m = atoi(e); if (m >= 2 && m <= 7 && v.kernel[m]) h->fast_mode = m; }
-      if (getenv("SDRFM_PHASE_PROFILE") && !h->d_dbg && v.kernel[1]) {
+      if (getenv("SDRFM_PHASE_PROFILE") && !h->d_dbg && v.kernel[1] && !h->stream_profile) {
         if (hipMalloc(&h->d_dbg, 560 * sizeof(unsigned long long)) != hipSuccess) h->d_dbg = nullptr;
         else { (void)hipMemset(h->d_dbg, 0, 560 * sizeof(unsigned long long)); for (int x = 0; x < 8; ++x) { (void)hipMemset(h->d_dbg + 520 + 4 * x, 0xff, 8); (void)hipMemset(h->d_dbg + 522 + 4 * x, 0xff, 8); } h->fast_mode = 1; }
       }
@@ -1855,6 +1901,19 @@ int sdrfm_debug_raw(sdrfm_t* h, unsigned long long* out512) {
   HIP_TRY(hipMemcpy(out512, h->d_dbg, 560 * sizeof(unsigned long long), hipMemcpyDeviceToHost), SDRFM_FAIL);
   return SDRFM_OK;
 }
+
+#ifdef SDRFM_DEV
+/* Development library only (not in include/sdrfm.h): copy of the first n debug words (design S: 16 time stamps per wave of the
+ * launch tagged by the 16th call after create / after the last read). */
+int sdrfm_dev_read_debug(sdrfm_t* h, unsigned long long* out, uint32_t n) {
+  if (!h || !out || !h->d_dbg || !h->stream_profile || n > 32u * 16384u) return SDRFM_EINVAL;
+  HIP_TRY(hipSetDevice(h->device), SDRFM_FAIL);
+  HIP_TRY(hipStreamSynchronize(h->stream), SDRFM_FAIL);
+  HIP_TRY(hipMemcpy(out, h->d_dbg, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost), SDRFM_FAIL);
+  h->dbg_launches = 0;
+  return SDRFM_OK;
+}
+#endif
 
 /* Host evaluation of the device's atan2 / discriminator arithmetic (same header, same rounding) so that its accuracy
  * can be unit-tested without a GPU.  Not used by any compute path. */

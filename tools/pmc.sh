@@ -16,7 +16,7 @@ from collections import defaultdict
 acc = defaultdict(float); cnt = defaultdict(int)
 for fn in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(fn)):
-        if any(k in row["Kernel_Name"] for k in os.environ.get("KFILTER", "k_fast,k_generic").split(",")):
+        if any(k in row["Kernel_Name"] for k in os.environ.get("KFILTER", "k_fast,k_generic,k_stream").split(",")):
             acc[row["Counter_Name"]] += float(row["Counter_Value"]); cnt[row["Counter_Name"]] += 1
 print(" ".join("%s=%.3g" % (k, acc[k] / cnt[k]) for k in sorted(acc)))
 PY

@@ -28,7 +28,7 @@ def main(work, out, tag):
         json.dump(summary, f, indent=1)
     kern = None
     for k in summary:
-        if ("k_fast" in k or "k_generic" in k) and "FETCH_SIZE" in summary[k]:
+        if ("k_fast" in k or "k_generic" in k or "k_stream" in k) and "FETCH_SIZE" in summary[k]:
             if kern is None or summary[k]["FETCH_SIZE"]["mean_per_dispatch"] > summary[kern]["FETCH_SIZE"]["mean_per_dispatch"]:
                 kern = k
     bench = {}
