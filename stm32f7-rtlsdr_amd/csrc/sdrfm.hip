@@ -973,19 +973,50 @@ constexpr int stream_warm_first_phase(int T, int D, int S) {
   return first;
 }
 
-// One body = S*D consecutive samples of every lane's segment, read from the lane's 160-byte region `reg` of one ring stage.
-//   WARM: the stage before the segment — only chains that complete inside the segment (and y[-1]) are run, nothing is emitted
+// line fetched by the refill at the last (lo = false) / first (lo = true) chunk u with u % 4 == 0 below `uend` resp. at or after
+// the start of the last body of NCH = 10 chunks (helper of a static_assert)
+constexpr int stream_refill_line_range(int uend, bool first_of_last_body) {
+  int u = first_of_last_body ? ((uend - 10 + 3) / 4) * 4 : ((uend - 1) / 4) * 4;
+  const int cls = (u >> 2) & 1;
+  return ((u + 4 * cls) >> 3) + 1;
+}
+
+// The lane's view of the LDS ring: two 128-byte line slots per lane (slot stride 8 KiB, lane region `base`), read 16 bytes at a
+// time.  t16 = 16 x the index of the next piece, counted from the start of the lane's first line; bit 7 of t16 is the slot, bits
+// 4..6 the piece, XOR-swizzled per region so that the 16 lanes a ds_read_b128 serves together hit 16 different bank groups.
+struct StreamRing {
+  unsigned base, rot16, t16;
+  __device__ __forceinline__ u4_t read(const unsigned char* smem) {
+    const unsigned a = base + (((t16 ^ rot16) & 0x70u) | ((t16 & 0x80u) << 6));
+    t16 += 16;
+    return *reinterpret_cast<const u4_t*>(smem + a);
+  }
+};
+
+// One body = S*D consecutive samples of every lane's segment.  `ub + c` is the index u of the 16-byte piece that chunk c uses,
+// counted from the first piece the warm-up reads (the same for all lanes); the ring hooks hang on it:
+//   before a piece u with u % 4 == 0 is read, the line it may start must have landed (even-segment lanes start lines at
+//     u % 8 == 0, odd-segment lanes at u % 8 == 4): `wait`;
+//   when chunk u with u % 4 == 0 begins, one class of lanes has used up a line: `refill(u)` fetches the line after next into it.
+//   WARM: the 64 samples before the segment — only chains that complete inside the segment (and y[-1]) run, nothing is emitted
 //   MID : all chains, S outputs -> S discriminator values dn[]
 //   LAST: as MID, but chains that would complete in the next lane's segment are not started
-template <int T, int D, int S, int MODE>
-__device__ __forceinline__ void stream_body(const unsigned char* reg, const f2_t (&hp)[T / 2], f2_t (&acc)[S], f2_t& prev, float (&dn)[S]) {
+template <int T, int D, int S, int MODE, class FW, class FR>
+__device__ __forceinline__ void stream_body(const unsigned char* smem, StreamRing& ring, int ub, FW&& wait, FR&& refill,
+                                            const f2_t (&hp)[T / 2], f2_t (&acc)[S], f2_t& prev, float (&dn)[S]) {
   constexpr int P = S * D, NCH = P / 8;
   constexpr int C0 = (MODE == SBODY_WARM) ? stream_warm_first_phase(T, D, S) / 8 : 0;   // first chunk a needed chain of the WARM body uses
-  u4_t cur = *reinterpret_cast<const u4_t*>(reg + 16 * C0), nxt = cur;
+  if (((ub + C0) & 3) == 0) wait();
+  u4_t cur = ring.read(smem), nxt = cur;
   f2_t x = cvt_iq<0>(cur.x);                                   // converted one sample ahead of its use: the FMAs (inline asm) never
   static_for<C0, NCH>([&](auto CC) {                           // directly follow the instruction that produced their operand
     constexpr int c = decltype(CC)::value;
-    if constexpr (c + 1 < NCH) nxt = *reinterpret_cast<const u4_t*>(reg + 16 * (c + 1));
+    const int u = ub + c;
+    if ((u & 3) == 0 && u >= 4) refill(u);
+    if constexpr (c + 1 < NCH) {
+      if (((u + 1) & 3) == 0) wait();
+      nxt = ring.read(smem);
+    }
     __builtin_amdgcn_sched_barrier(0);                         // one 8-sample chunk is one scheduling region (bounds live ranges)
     static_for<0, 8>([&](auto S8) {
       constexpr int s8 = decltype(S8)::value;
@@ -1030,14 +1061,16 @@ __device__ __forceinline__ void stream_body(const unsigned char* reg, const f2_t
 template <int T, int D, int S, int NB, int TA, int DA>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_stream(CallParams p) {
   constexpr int P = S * D, L = NB * P, OPL = NB * S;           // samples per body / per lane segment, outputs per lane
-  constexpr int STAGE = 2 * P;                                  // bytes per lane per ring stage (160)
-  constexpr int SL16 = STAGE / 16;                              // 16-byte pieces per lane per stage (10)
-  constexpr int LPI = 64 / SL16;                                // lane-segments one DMA instruction fills (6)
-  constexpr int NDMA = (64 + LPI - 1) / LPI;                    // DMA instructions per stage (11)
-  constexpr int RING = 64 * STAGE;                              // bytes per stage (10240)
-  constexpr int WARM_PIECE0 = stream_warm_first_phase(T, D, S) / 8;   // first 16-byte piece of the warm-up stage that is read
+  constexpr int NCH = P / 8;                                    // 16-byte pieces (8 samples) a body reads
+  constexpr int WP = NCH - stream_warm_first_phase(T, D, S) / 8;   // pieces the warm-up reads
+  constexpr int SLOT = 64 * 128;                                // bytes per line slot of the ring (64 lanes x one 128-byte line)
+  constexpr int NLINES = (WP + NB * NCH + 4 + 7) / 8;           // lines a lane walks through (odd-segment lanes start mid-line)
   static_assert(P % 8 == 0 && S % 2 == 0 && P >= T && T % 2 == 0 && (OPL % 4) == 0 && TA - 1 <= OPL, "design S geometry");
-  static_assert(2 * RING >= (64 * OPL + TA) * 4, "the d array of the audio stage reuses the ring");
+  static_assert(WP == 8 && (L * 2) % 128 == 64, "design S: the warm-up is one line; segment starts alternate between line starts and line middles");
+  // the ring schedule relies on: every refill due in the warm-up / MID bodies fetches a line that exists (vmcnt(4) then always
+  // leaves exactly the youngest refill outstanding), and none is due in the LAST body (which waits for everything)
+  static_assert(stream_refill_line_range(WP + (NB - 1) * NCH, false) < NLINES && stream_refill_line_range(WP + NB * NCH, true) >= NLINES,
+                "design S ring schedule");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = (int)threadIdx.x;
   const uint32_t stream = blockIdx.x / p.tiles_per_stream;
@@ -1053,33 +1086,47 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
   for (int k = 0; k < T / 2; ++k) asm volatile("" : "+v"(hp[k]));
 
-  // The buffer descriptor starts BIAS bytes before the stream's row so that every per-lane offset is non-negative (the hardware
-  // range-checks the VGPR offset alone, as unsigned); no address below the row is ever fetched (those lanes are switched off).
-  constexpr int BIAS = (L + P) * 2;
-  const unsigned long long gaddr = (unsigned long long)(p.iq + (size_t)stream * p.iq_stride) - BIAS;
-  const i4_t rsrc = {(int)(unsigned)gaddr, (int)(unsigned)(gaddr >> 32), (int)(2u * p.N + BIAS), 0x00020000};
-  // LDS-DMA addressing: lane t of DMA instruction i fetches piece t % 10 of lane-segment q = 6 i + t / 10.  The per-lane part of
-  // the byte offset is one VGPR, the (instruction, stage) part is scalar; a lane whose segment lies outside the call (lane 0
-  // of the first wave, lanes beyond the stream's end, the warm-up stage of the call's first segment) is switched off.
-  const int qsub = lane / SL16;
-  const int vbase = BIAS + ((g0 + qsub) * L - P) * 2 + (lane % SL16) * 16;
-  bool ok[NDMA];
+  // ---- the ring: HBM --LDS-DMA--> LDS, whole 128-byte lines, every line of the stream fetched by exactly one lane-stage ------
+  // A lane's byte stream starts 64 samples (one line) before its segment: at a line start for even segments (class 0), in the
+  // middle of a line for odd ones (class 1: L*2 = 7.5 lines), so class 1 begins at piece 4 of its first line.  Lanes are grouped
+  // by class in LDS (region rho = 32 class + lane / 2): one DMA instruction fills the current line slot of 8 regions of ONE
+  // class (lane t of the instruction: region 8 i + t / 8, piece t % 8, fetched from column piece ^ swizzle), so a class is
+  // refilled the moment its lanes cross a line boundary.  Lanes whose segment lies outside the call fetch (and never use)
+  // the row's first line; nothing is ever switched off, so vmcnt counts DMA instructions exactly.
+  const unsigned long long gaddr = (unsigned long long)(p.iq + (size_t)stream * p.iq_stride);
+  const i4_t rsrc = {(int)(unsigned)gaddr, (int)(unsigned)(gaddr >> 32), (int)(2u * p.N), 0x00020000};
+  const int g0odd = g0 & 1;
+  auto swz = [](int rho) { return ((rho >> 1) + 4 * (rho >> 5)) & 7; };
+  int voffs[2][4];                                              // byte offset (in the row) of this lane's piece of line 0, per (class, i)
+  bool first_seg[4];                                            // class 0: the lane-segment is segment 0 of the call (its line 0 precedes the row)
 #pragma unroll
-  for (int i = 0; i < NDMA; ++i) {
-    const int q = LPI * i + qsub, g = g0 + q;
-    ok[i] = lane < LPI * SL16 && q < 64 && g >= 0 && g < segs;
-  }
-  int stage_off = 0;
-  auto issue_stage = [&](int parity, bool first) {
+  for (int cls = 0; cls < 2; ++cls)
 #pragma unroll
-    for (int i = 0; i < NDMA; ++i) {
-      // the warm-up stage: not for the call's first segment (it gets the carried history), and only the pieces the warm-up reads
-      if (ok[i] && !(first && (g0 + LPI * i + qsub == 0 || lane % SL16 < WARM_PIECE0)))
-        llvm_amdgcn_raw_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(smem + parity * RING + i * (LPI * STAGE)), 16,
-                                        vbase, stage_off + i * (LPI * L * 2), 0, 0);
+    for (int i = 0; i < 4; ++i) {
+      const int l = 16 * i + 2 * (lane >> 3) + (cls ^ g0odd), g = g0 + l, rho = 32 * cls + 8 * i + (lane >> 3);
+      const int col = (lane & 7) ^ swz(rho);
+      const bool ok = g >= 0 && g < segs;
+      voffs[cls][i] = (ok ? g * (L * 2) - 128 - 64 * cls : 0) + 16 * col;
+      if (cls == 0) first_seg[i] = ok && g == 0;
     }
-    stage_off += STAGE;
+  auto fill = [&](int cls, int n, bool initial) {               // line n of every lane of one class -> slot n & 1
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int v = (cls ? voffs[1][i] : voffs[0][i]) + 128 * n;
+      if (initial && first_seg[i]) v += 128;                    // segment 0's line 0 lies before the row: its place is patched below
+      llvm_amdgcn_raw_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(smem + (n & 1) * SLOT + (32 * cls + 8 * i) * 128), 16,
+                                      v, 0, 0, 0);
+    }
   };
+  auto refill = [&](int u) {                                    // chunk u begins: class (u / 4) % 2 has just finished a line
+    const int cls = (u >> 2) & 1, n = ((u + 4 * cls) >> 3) + 1;
+    if (n < NLINES) {
+      if (cls) fill(1, n, false); else fill(0, n, false);
+    }
+  };
+  auto wait4 = [] { __builtin_amdgcn_s_waitcnt(0x0f74); };      // vmcnt(4): everything but the youngest refill (4 instructions) has landed
+  auto wait0 = [] { __builtin_amdgcn_s_waitcnt(0x0f70); };
+  auto no_refill = [](int) {};
 
 #ifdef SDRFM_DEV   // development build: per-wave time stamps (shader cycles) at the phase boundaries, 32 words per wave
   unsigned long long* const tsp = (p.dbg && p.dbg_tag) ? p.dbg + 32 * (size_t)blockIdx.x : nullptr;
@@ -1090,36 +1137,37 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #define SDRFM_STAMP() do { } while (0)
 #endif
   SDRFM_STAMP();                                                // 0: entry
-#ifdef SDRFM_DEV
-  if (p.warm_ahead && (__builtin_amdgcn_s_getreg((4 << 11) | 4) & 1))   // experiment: the wave in the odd slot of its SIMD starts late
-    for (uint32_t z = 0; z < p.warm_ahead; ++z) __builtin_amdgcn_s_sleep(16);
-#endif
-  issue_stage(0, true);
+  fill(0, 0, true); fill(1, 0, true); fill(1, 1, false); fill(0, 1, false);   // class 1 needs its second line first
   f2_t acc[S];
 #pragma unroll
   for (int k = 0; k < S; ++k) acc[k] = f2_t{0.f, 0.f};
   f2_t prev = {0.f, 0.f};
   float dn[S], dreg[OPL];
-  const unsigned char* myreg = smem + lane * STAGE;
-  __builtin_amdgcn_s_waitcnt(0x0f70);                           // vmcnt(0): stage 0 has landed
-  SDRFM_STAMP();                                                // 1: first stage in LDS
+  const int mycls = (g0 + lane) & 1, myrho = 32 * mycls + (lane >> 1);
+  StreamRing ring = {(unsigned)(myrho * 128), (unsigned)(16 * swz(myrho)), (unsigned)(64 * mycls)};
+  __builtin_amdgcn_s_waitcnt(0x0f78);                           // vmcnt(8): the first line of both classes has landed
+  SDRFM_STAMP();                                                // 1: first lines in LDS
   if (w == 0) {
-    // the first segment of the call: its warm-up stage is the carried raw history (T-1 samples right-aligned in lane 1's region)
-    unsigned char* r1 = smem + 1 * STAGE;
+    // the first segment of the call (lane 1, class 0, region 0, swizzle 0): its first line is the carried raw history
     for (int k = lane; k < T - 1; k += 64)
-      *reinterpret_cast<unsigned short*>(r1 + STAGE - 2 * (T - 1) + 2 * k) =
+      *reinterpret_cast<unsigned short*>(smem + 128 - 2 * (T - 1) + 2 * k) =
           reinterpret_cast<const unsigned short*>(p.hist_b_in)[(size_t)stream * (T - 1) + k];
     __syncthreads();
   }
-  issue_stage(1, false);
-  stream_body<T, D, S, SBODY_WARM>(myreg, hp, acc, prev, dn);
+  stream_body<T, D, S, SBODY_WARM>(smem, ring, -(NCH - WP), wait4, refill, hp, acc, prev, dn);
   if (w == 0 && lane == 1) { const float2 yp = p.yprev_in[stream]; prev = f2_t{yp.x, yp.y}; }
   SDRFM_STAMP();                                                // 2: warm-up body done
   for (int b = 0; b < NB - 1; ++b) {
-    __builtin_amdgcn_s_waitcnt(0x0f70);                         // stage b+1 has landed
-    SDRFM_STAMP();                                              // 3, 5, 7, ...: stage wait over
-    issue_stage(b & 1, false);                                  // stage b+2 into the buffer body b-1 (or the warm-up) has drained
-    stream_body<T, D, S, SBODY_MID>(myreg + ((b + 1) & 1) * RING, hp, acc, prev, dn);
+    // The two waves of a SIMD are arbitrated oldest-first: one runs ahead at the single-wave rate and the other finishes alone.
+    // Priority falls with progress, so whichever is behind wins the issue slot and the pair finishes together.
+    if (p.prio_balance) {
+      const int left = NB - 1 - b;
+      if (left >= 3) __builtin_amdgcn_s_setprio(3);
+      else if (left == 2) __builtin_amdgcn_s_setprio(2);
+      else __builtin_amdgcn_s_setprio(1);
+    }
+    SDRFM_STAMP();                                              // 3, 5, 7, ...
+    stream_body<T, D, S, SBODY_MID>(smem, ring, WP + NCH * b, wait4, refill, hp, acc, prev, dn);
 #pragma unroll
     for (int bb = 0; bb < NB - 1; ++bb)
       if (b == bb) {
@@ -1129,8 +1177,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       }
     SDRFM_STAMP();                                              // 4, 6, 8, ...: body done
   }
-  __builtin_amdgcn_s_waitcnt(0x0f70);
-  stream_body<T, D, S, SBODY_LAST>(myreg + (NB & 1) * RING, hp, acc, prev, dn);
+  if (p.prio_balance) __builtin_amdgcn_s_setprio(0);
+  // the last body: no line is left to fetch (the refills it would trigger lie beyond the lane's last line), so every wait is for
+  // all outstanding requests
+  stream_body<T, D, S, SBODY_LAST>(smem, ring, WP + NCH * (NB - 1), wait0, no_refill, hp, acc, prev, dn);
 #pragma unroll
   for (int k = 0; k < S; ++k) dreg[(NB - 1) * S + k] = dn[k];
 
@@ -1150,7 +1200,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // chains waits on memory), the taps sit in registers, and the results go back through LDS so that the stores are coalesced.
   constexpr int NOUT = ((63 * OPL + DA - 1) / DA + 63) / 64, ND = (NOUT - 1) * DA + TA;
   float* outl = gs + TA;                                        // 64 * NOUT results
-  static_assert((64 * OPL + TA + 64 * NOUT) * 4 <= 2 * RING && (DA * 64 * NOUT + TA + OPL) * 4 <= 2 * RING, "audio stage scratch exceeds the ring");
+  static_assert((64 * OPL + TA + 64 * NOUT) * 4 <= 2 * SLOT && (DA * 64 * NOUT + TA + OPL) * 4 <= 2 * SLOT, "audio stage scratch exceeds the ring");
   float gv[TA];
 #pragma unroll
   for (int k = 0; k < TA; ++k) gv[k] = gs[k];
@@ -1163,13 +1213,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     float dw[ND];
 #pragma unroll
     for (int k = 0; k < ND; ++k) dw[k] = wd[k];
+    float a[NOUT];
 #pragma unroll
-    for (int i = 0; i < NOUT; ++i) {
-      float a = 0.0f;
+    for (int i = 0; i < NOUT; ++i) a[i] = 0.0f;
 #pragma unroll
-      for (int k = 0; k < TA; ++k) a = __builtin_fmaf(gv[k], dw[DA * i + k], a);
-      outl[lane * NOUT + i] = a;
-    }
+    for (int k = 0; k < TA; ++k)                               // NOUT independent chains side by side, each in the oracle's order
+#pragma unroll
+      for (int i = 0; i < NOUT; ++i) a[i] = __builtin_fmaf(gv[k], dw[DA * i + k], a[i]);
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) outl[lane * NOUT + i] = a[i];
   }
   __syncthreads();
   float* out = p.audio + (size_t)stream * p.audio_stride;
@@ -1227,7 +1279,7 @@ struct FastVariant {
 #endif
 #define SDRFM_FASTB2_LITE(T_, D_, R_, TA_, DA_) { 'b', T_, D_, R_, TA_, DA_, {k_fastb<T_, D_, R_, TA_, DA_, 0>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, (uint32_t)fastb_xbytes(T_, D_, R_) }
 #define SDRFM_FASTB(T_, D_, R_) SDRFM_FASTB2(T_, D_, R_, 32, 5)
-#define SDRFM_STREAM(T_, D_, S_, NB_, TA_, DA_) { 's', T_, D_, S_, TA_, DA_, {k_stream<T_, D_, S_, NB_, TA_, DA_>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, 2u * 64u * 2u * (S_) * (D_), (uint32_t)(NB_) * (S_) * (D_) }
+#define SDRFM_STREAM(T_, D_, S_, NB_, TA_, DA_) { 's', T_, D_, S_, TA_, DA_, {k_stream<T_, D_, S_, NB_, TA_, DA_>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, 2u * 64u * 128u, (uint32_t)(NB_) * (S_) * (D_) }
 const FastVariant kFastVariants[] = {
     // design S (streaming lanes): the BASELINE configs[2]/[3] shape; serves calls that are whole numbers of lane segments
     SDRFM_STREAM(64, 10, 8, 6, 32, 5),

@@ -25,7 +25,7 @@ lib.sdrfm_dev_read_debug.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_uint
 assert lib.sdrfm_dev_read_debug(dm._h, raw, 32 * waves) == 0
 t = np.frombuffer(raw, dtype=np.uint64).reshape(waves, 32).astype(np.int64)
 cyc = t[:, :3 + 2 * (NB - 1) + 2]                     # entry, stage0, warm, (wait, body) x5, last, audio
-names = ["first stage wait", "warm-up body"] + [x for b in range(NB - 1) for x in ("stage wait %d" % (b + 1), "body %d" % b)] + ["last body (+wait)", "audio stage"]
+names = ["first line wait", "warm-up body"] + [x for b in range(NB - 1) for x in ("prio %d" % b, "body %d" % b)] + ["last body", "audio stage"]
 d = np.diff(cyc, axis=1)
 hw = t[:, 29]; xcc = hw & 0xf; hwid = hw >> 32
 simd = (hwid >> 4) & 3; cu = (hwid >> 8) & 0xf; se = (hwid >> 13) & 7; sh = (hwid >> 12) & 1
