@@ -1137,7 +1137,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #define SDRFM_STAMP() do { } while (0)
 #endif
   SDRFM_STAMP();                                                // 0: entry
-  fill(0, 0, true); fill(1, 0, true); fill(1, 1, false); fill(0, 1, false);   // class 1 needs its second line first
+  fill(0, 0, true); fill(1, 0, true); fill(1, 1, false);       // class 1 starts mid-line: it needs its second line during the warm-up
   f2_t acc[S];
 #pragma unroll
   for (int k = 0; k < S; ++k) acc[k] = f2_t{0.f, 0.f};
@@ -1145,8 +1145,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   float dn[S], dreg[OPL];
   const int mycls = (g0 + lane) & 1, myrho = 32 * mycls + (lane >> 1);
   StreamRing ring = {(unsigned)(myrho * 128), (unsigned)(16 * swz(myrho)), (unsigned)(64 * mycls)};
-  __builtin_amdgcn_s_waitcnt(0x0f78);                           // vmcnt(8): the first line of both classes has landed
-  SDRFM_STAMP();                                                // 1: first lines in LDS
+  __builtin_amdgcn_s_waitcnt(0x0f74);                           // vmcnt(4): the first line of both classes has landed
+  fill(0, 1, false);                                            // class 0's second line is not needed before the first body: it queues
+  SDRFM_STAMP();                                                // behind the opening burst instead of lengthening it.  1: first lines in LDS
   if (w == 0) {
     // the first segment of the call (lane 1, class 0, region 0, swizzle 0): its first line is the carried raw history
     for (int k = lane; k < T - 1; k += 64)
