@@ -1328,6 +1328,7 @@ struct sdrfm {
   // fast kernel (when one is instantiated for this T/D)
   const FastVariant* fast;
   const FastVariant* fast_s;  // design S variant of this geometry, if one is instantiated (serves the calls it is eligible for)
+  uint32_t n_cu;              // compute units of the device
   char fast_s_name[64];
   size_t fast_lds;
   uint32_t waves_target;   // resident waves the fast kernel aims for (CUs x waves that fit by LDS)
@@ -1527,6 +1528,7 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
       }
 #endif
       h->fast_s = &v;
+      h->n_cu = (uint32_t)prop.multiProcessorCount;
       snprintf(h->fast_s_name, sizeof(h->fast_s_name), "fast-s T%u D%u S%u L%u Ta%u Da%u", v.T, v.D, v.R, v.seg, v.Ta, v.Da);
     }
     for (int pass = 0; pass < 3 && !h->fast; ++pass)
@@ -1671,7 +1673,11 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
                        N < (1u << 30) && !short_first;
   const bool stream_ok = fast_ok && h->fast_s && h->phase_x == 0 && h->phase_d == 0 && (N % h->fast_s->seg) == 0 &&
                          (M % c.audio_decim) == 0 && M >= c.audio_taps && ((uintptr_t)d_iq % 16 == 0) && (iq_stride % 16 == 0) &&
-                         h->fold_state_ok;
+                         h->fold_state_ok &&
+                         // a lane-segment wave is long (its 64 lanes walk 480 samples each, ~25 us alone on a SIMD): design S pays when
+                         // the call fills the machine (>= one wave per SIMD); a single dongle's call is served faster by design B,
+                         // which cuts its segments as short as the call needs
+                         (uint64_t)c.n_streams * ((N / h->fast_s->seg + 62) / 63) >= 4ull * h->n_cu;
   if (stream_ok) {
     const uint32_t segs = N / h->fast_s->seg;
     p.tiles_per_stream = (segs + 62) / 63;                      // waves per stream: 63 useful lane segments each
