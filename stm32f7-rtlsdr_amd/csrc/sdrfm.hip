@@ -961,6 +961,9 @@ __device__ __forceinline__ void pk_first_bcast_v(f2_t& acc, f2_t tap_pair, f2_t 
 }
 
 constexpr int SBODY_WARM = 0, SBODY_MID = 1, SBODY_LAST = 2;
+#ifndef SDRFM_STREAM_AUX
+#define SDRFM_STREAM_AUX 0   // cache policy bits of the ring's line fetches (2 = nt)
+#endif
 // first phase of the warm-up body at which a chain that is needed starts: the chain of slot S-1 (it ends at the body's last
 // sample: y[-1] of the segment) or any chain that wraps into the next body (an output of the segment)
 constexpr int stream_warm_first_phase(int T, int D, int S) {
@@ -1115,7 +1118,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       int v = (cls ? voffs[1][i] : voffs[0][i]) + 128 * n;
       if (initial && first_seg[i]) v += 128;                    // segment 0's line 0 lies before the row: its place is patched below
       llvm_amdgcn_raw_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(smem + (n & 1) * SLOT + (32 * cls + 8 * i) * 128), 16,
-                                      v, 0, 0, 0);
+                                      v, 0, 0, SDRFM_STREAM_AUX);
     }
   };
   auto refill = [&](int u) {                                    // chunk u begins: class (u / 4) % 2 has just finished a line
