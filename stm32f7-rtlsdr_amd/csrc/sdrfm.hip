@@ -1008,20 +1008,26 @@ template <int T, int D, int S, int MODE, class FW, class FR>
 __device__ __forceinline__ void stream_body(const unsigned char* smem, StreamRing& ring, int ub, FW&& wait, FR&& refill,
                                             const f2_t (&hp)[T / 2], f2_t (&acc)[S], f2_t& prev, float (&dn)[S]) {
   constexpr int P = S * D, NCH = P / 8;
-  constexpr int C0 = (MODE == SBODY_WARM) ? stream_warm_first_phase(T, D, S) / 8 : 0;   // first chunk a needed chain of the WARM body uses
-  if (((ub + C0) & 3) == 0) wait();
+  // the warm-up READS its last 8 pieces (the ring starts one line before the segment) and COMPUTES from the first chunk a needed
+  // chain uses (short filters need less history than a line)
+  constexpr int CR = (MODE == SBODY_WARM) ? NCH - 8 : 0;
+  constexpr int C0 = (MODE == SBODY_WARM) ? stream_warm_first_phase(T, D, S) / 8 : 0;
+  static_assert(C0 >= CR && C0 < NCH, "design S: the filter history must fit the one line before the segment");
+  if (((ub + CR) & 3) == 0) wait();
   u4_t cur = ring.read(smem), nxt = cur;
-  f2_t x = cvt_iq<0>(cur.x);                                   // converted one sample ahead of its use: the FMAs (inline asm) never
-  static_for<C0, NCH>([&](auto CC) {                           // directly follow the instruction that produced their operand
+  f2_t x = {0.f, 0.f};
+  static_for<CR, NCH>([&](auto CC) {
     constexpr int c = decltype(CC)::value;
     const int u = ub + c;
+    if constexpr (c == C0) x = cvt_iq<0>(cur.x);               // converted one sample ahead of its use: the FMAs (inline asm) never
+                                                               // directly follow the instruction that produced their operand
     if ((u & 3) == 0 && u >= 4) refill(u);
     if constexpr (c + 1 < NCH) {
       if (((u + 1) & 3) == 0) wait();
       nxt = ring.read(smem);
     }
     __builtin_amdgcn_sched_barrier(0);                         // one 8-sample chunk is one scheduling region (bounds live ranges)
-    static_for<0, 8>([&](auto S8) {
+    static_for<0, (c >= C0 ? 8 : 0)>([&](auto S8) {
       constexpr int s8 = decltype(S8)::value;
       constexpr int ph = 8 * c + s8;
       f2_t xn = x;
@@ -1065,11 +1071,11 @@ template <int T, int D, int S, int NB, int TA, int DA>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_stream(CallParams p) {
   constexpr int P = S * D, L = NB * P, OPL = NB * S;           // samples per body / per lane segment, outputs per lane
   constexpr int NCH = P / 8;                                    // 16-byte pieces (8 samples) a body reads
-  constexpr int WP = NCH - stream_warm_first_phase(T, D, S) / 8;   // pieces the warm-up reads
+  constexpr int WP = 8;                                         // pieces the warm-up reads: the one line before the segment
   constexpr int SLOT = 64 * 128;                                // bytes per line slot of the ring (64 lanes x one 128-byte line)
   constexpr int NLINES = (WP + NB * NCH + 4 + 7) / 8;           // lines a lane walks through (odd-segment lanes start mid-line)
   static_assert(P % 8 == 0 && S % 2 == 0 && P >= T && T % 2 == 0 && (OPL % 4) == 0 && TA - 1 <= OPL, "design S geometry");
-  static_assert(WP == 8 && (L * 2) % 128 == 64, "design S: the warm-up is one line; segment starts alternate between line starts and line middles");
+  static_assert((L * 2) % 128 == 64 && T - 1 <= 64, "design S: segment starts alternate between line starts and line middles; the history fits one line");
   // the ring schedule relies on: every refill due in the warm-up / MID bodies fetches a line that exists (vmcnt(4) then always
   // leaves exactly the youngest refill outstanding), and none is due in the LAST body (which waits for everything)
   static_assert(stream_refill_line_range(WP + (NB - 1) * NCH, false) < NLINES && stream_refill_line_range(WP + NB * NCH, true) >= NLINES,
@@ -1286,7 +1292,8 @@ struct FastVariant {
 #define SDRFM_STREAM(T_, D_, S_, NB_, TA_, DA_) { 's', T_, D_, S_, TA_, DA_, {k_stream<T_, D_, S_, NB_, TA_, DA_>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, 2u * 64u * 128u, (uint32_t)(NB_) * (S_) * (D_) }
 const FastVariant kFastVariants[] = {
     // design S (streaming lanes): the BASELINE configs[2]/[3] shape; serves calls that are whole numbers of lane segments
-    SDRFM_STREAM(64, 10, 8, 6, 32, 5),
+    // (a 16-tap instance is correct too but no faster than design B on cold inputs: 35.2 vs 34.1 us; it is not instantiated)
+    SDRFM_STREAM(64, 10, 8, 6, 32, 5), SDRFM_STREAM(32, 10, 8, 6, 32, 5),
     // 2.4 MS/s -> 240 kS/s -> 48 kHz: the rate the firmware programs (usbh_rtlsdr.c:898) and the BASELINE configs
     SDRFM_FASTB2_ABL(64, 10, 12, 32, 5), SDRFM_FASTB2_LITE(64, 10, 8, 32, 5), SDRFM_FASTB(16, 10, 12), SDRFM_FASTB2_LITE(32, 10, 12, 32, 5),
     // the other rates RTLSDR_set_sample_rate accepts and a dongle is commonly run at:

@@ -277,7 +277,8 @@ def test_specialised_kernels_equal_generic_kernel_bitwise(pkg, oracle_mod, monke
     (520, [31200, 48000]),                        # 65 segments: two waves per stream, the second nearly empty; then 100 segments
     (1030, [7200, 1000, 2400, 2402, 2398, 4800]), # eligible and ineligible sizes alternate: design S <-> design B/generic on one state
 ])
-def test_streaming_lane_kernel_equals_generic_kernel_bitwise(pkg, oracle_mod, ns, calls):
+@pytest.mark.parametrize("T", [64, 32])
+def test_streaming_lane_kernel_equals_generic_kernel_bitwise(pkg, oracle_mod, ns, calls, T):
     """Design S (streaming lanes, LDS-DMA ring, slot accumulators) runs the oracle's chains in the oracle's order: its audio is
     bit-identical to the generic kernel's for every call pattern it serves, and the state it hands over is interchangeable
     with the other kernels'."""
