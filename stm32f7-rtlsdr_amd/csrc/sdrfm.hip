@@ -960,22 +960,9 @@ __device__ __forceinline__ void pk_first_bcast_v(f2_t& acc, f2_t tap_pair, f2_t 
     asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=v"(acc) : "v"(tap_pair), "v"(x));
 }
 
-constexpr int SBODY_WARM = 0, SBODY_MID = 1, SBODY_LAST = 2;
 #ifndef SDRFM_STREAM_AUX
 #define SDRFM_STREAM_AUX 0   // cache policy bits of the ring's line fetches (2 = nt)
 #endif
-// first phase of the warm-up body at which a chain that is needed starts: the chain of slot S-1 (it ends at the body's last
-// sample: y[-1] of the segment) or any chain that wraps into the next body (an output of the segment)
-constexpr int stream_warm_first_phase(int T, int D, int S) {
-  const int P = S * D;
-  int first = P - T;
-  for (int sl = 0; sl < S; ++sl) {
-    const int cs = ((D * sl + D - 1 - (T - 1)) % P + P) % P;
-    if (cs + T - 1 >= P && cs < first) first = cs;
-  }
-  return first;
-}
-
 // line fetched by the refill at the last (lo = false) / first (lo = true) chunk u with u % 4 == 0 below `uend` resp. at or after
 // the start of the last body of NCH = 10 chunks (helper of a static_assert)
 constexpr int stream_refill_line_range(int uend, bool first_of_last_body) {
@@ -996,38 +983,64 @@ struct StreamRing {
   }
 };
 
-// One body = S*D consecutive samples of every lane's segment.  `ub + c` is the index u of the 16-byte piece that chunk c uses,
-// counted from the first piece the warm-up reads (the same for all lanes); the ring hooks hang on it:
-//   before a piece u with u % 4 == 0 is read, the line it may start must have landed (even-segment lanes start lines at
-//     u % 8 == 0, odd-segment lanes at u % 8 == 4): `wait`;
-//   when chunk u with u % 4 == 0 begins, one class of lanes has used up a line: `refill(u)` fetches the line after next into it.
-//   WARM: the 64 samples before the segment — only chains that complete inside the segment (and y[-1]) run, nothing is emitted
-//   MID : all chains, S outputs -> S discriminator values dn[]
-//   LAST: as MID, but chains that would complete in the next lane's segment are not started
-template <int T, int D, int S, int MODE, class FW, class FR>
-__device__ __forceinline__ void stream_body(const unsigned char* smem, StreamRing& ring, int ub, FW&& wait, FR&& refill,
-                                            const f2_t (&hp)[T / 2], f2_t (&acc)[S], f2_t& prev, float (&dn)[S]) {
-  constexpr int P = S * D, NCH = P / 8;
-  // the warm-up READS its last 8 pieces (the ring starts one line before the segment) and COMPUTES from the first chunk a needed
-  // chain uses (short filters need less history than a line)
-  constexpr int CR = (MODE == SBODY_WARM) ? NCH - 8 : 0;
-  constexpr int C0 = (MODE == SBODY_WARM) ? stream_warm_first_phase(T, D, S) / 8 : 0;
-  static_assert(C0 >= CR && C0 < NCH, "design S: the filter history must fit the one line before the segment");
+// slots whose chain wraps from one body into the next (they are 0 .. NH-1): the outputs a lane cannot finish without the samples
+// before its segment — its "head" outputs
+template <int HI>
+__device__ __forceinline__ void pk_first_bcast(f2_t& acc, f2_t tap_pair, f2_t x) {   // as pk_first_bcast_v, tap pair in SGPRs
+  if constexpr (HI == 0)
+    asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(acc) : "s"(tap_pair), "v"(x));
+  else
+    asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=v"(acc) : "s"(tap_pair), "v"(x));
+}
+
+constexpr int stream_heads(int T, int D, int S) {
+  const int P = S * D;
+  int nh = 0;
+  for (int sl = 0; sl < S; ++sl) {
+    const int cs = ((D * sl + D - 1 - (T - 1)) % P + P) % P;
+    if (cs + T - 1 >= P) ++nh;
+  }
+  return nh;
+}
+
+// One body = S*D consecutive samples of every lane's segment, 8 samples (one 16-byte piece, `read()`) per chunk.  `ub + c` is the
+// index u of the piece chunk c uses, counted from the segment's first piece; the ring hooks hang on it:
+//   before a piece u with u % 4 == 0 is read, `wait()`: a class of lanes may be about to start a line (even-segment lanes at
+//     u % 8 == 0, odd-segment lanes at u % 8 == 4), which has to have landed;
+//   when chunk u with u % 4 == 0 begins, `refill(u)`: one class of lanes has used up a line, the line after next is fetched into it.
+// A slot's chain that starts in one body and completes in the next is split into its "head" (the phases in the first body) and
+// its "tail"; the first NH slots wrap, so a segment's first NH outputs need the NH heads run on the samples BEFORE the segment:
+//   FIRST : the segment's first body — tails are skipped (their heads have not run): outputs NH.. only; the first CB pieces are
+//           kept (raw) for the HEADB pass
+//   MID   : all chains, S outputs -> S discriminator values dn[]
+//   LAST  : as MID, but heads are not started (they belong to the next lane's segment)
+//   HEADA : after the walk, on the LEFT neighbour's last pieces (still in its ring slots): the heads of this lane's first outputs
+//   HEADB : then on the lane's own first pieces (kept by FIRST): their tails -> outputs 0 .. NH-1 and d[0 .. NH]
+constexpr int SBODY_FIRST = 0, SBODY_MID = 1, SBODY_LAST = 2, SBODY_HEADA = 3, SBODY_HEADB = 4;
+constexpr int stream_kept_pieces(int T, int D, int S) { return (D * (stream_heads(T, D, S) - 1) + D - 1) / 8 + 1; }   // pieces HEADB reads
+constexpr int stream_sgpr_pairs(int T) { return T >= 64 ? 8 : 0; }   // tap pairs (the last ones) held in SGPRs instead of VGPRs
+template <int T, int D, int S, int MODE, class RD, class FW, class FR>
+__device__ __forceinline__ void stream_body(RD&& read, int ub, FW&& wait, FR&& refill, const f2_t (&hp)[T / 2], f2_t (&acc)[S], f2_t& prev,
+                                            float (&dn)[S], f2_t& ysave, u4_t (&kept)[stream_kept_pieces(T, D, S)]) {
+  constexpr int P = S * D, NCH = P / 8, NH = stream_heads(T, D, S);
+  constexpr int CS0 = ((D - 1 - (T - 1)) % P + P) % P;          // phase at which slot 0 starts its (wrapping) chain: the first head phase
+  constexpr int CR = (MODE == SBODY_HEADA) ? CS0 / 8 : 0;      // first chunk that is read / computed
+  constexpr int CE = (MODE == SBODY_HEADB) ? (D * (NH - 1) + D - 1) / 8 + 1 : NCH;   // one past the last chunk (HEADB: the last tail phase)
+  static_assert(NH >= 1 && NH < S - 1, "design S geometry");
   if (((ub + CR) & 3) == 0) wait();
-  u4_t cur = ring.read(smem), nxt = cur;
-  f2_t x = {0.f, 0.f};
-  static_for<CR, NCH>([&](auto CC) {
+  u4_t cur = read(std::integral_constant<int, CR>{}), nxt = cur;
+  f2_t x = cvt_iq<0>(cur.x);                                   // converted one sample ahead of its use: the FMAs (inline asm) never
+  static_for<CR, CE>([&](auto CC) {                            // directly follow the instruction that produced their operand
     constexpr int c = decltype(CC)::value;
     const int u = ub + c;
-    if constexpr (c == C0) x = cvt_iq<0>(cur.x);               // converted one sample ahead of its use: the FMAs (inline asm) never
-                                                               // directly follow the instruction that produced their operand
     if ((u & 3) == 0 && u >= 4) refill(u);
-    if constexpr (c + 1 < NCH) {
+    if constexpr (MODE == SBODY_FIRST && c < stream_kept_pieces(T, D, S)) kept[c] = cur;
+    if constexpr (c + 1 < CE) {
       if (((u + 1) & 3) == 0) wait();
-      nxt = ring.read(smem);
+      nxt = read(std::integral_constant<int, c + 1>{});
     }
     __builtin_amdgcn_sched_barrier(0);                         // one 8-sample chunk is one scheduling region (bounds live ranges)
-    static_for<0, (c >= C0 ? 8 : 0)>([&](auto S8) {
+    static_for<0, 8>([&](auto S8) {
       constexpr int s8 = decltype(S8)::value;
       constexpr int ph = 8 * c + s8;
       f2_t xn = x;
@@ -1035,7 +1048,7 @@ __device__ __forceinline__ void stream_body(const unsigned char* smem, StreamRin
         constexpr int t8 = s8 + 1;
         const unsigned w = (t8 / 2 == 0) ? cur.x : (t8 / 2 == 1) ? cur.y : (t8 / 2 == 2) ? cur.z : cur.w;
         xn = cvt_iq<(t8 & 1)>(w);
-      } else if constexpr (c + 1 < NCH) {
+      } else if constexpr (c + 1 < CE) {
         xn = cvt_iq<0>(nxt.x);
       }
       static_for<0, S>([&](auto SS) {
@@ -1043,42 +1056,71 @@ __device__ __forceinline__ void stream_body(const unsigned char* smem, StreamRin
         constexpr int e = ((D * sl + D - 1 - ph) % P + P) % P;  // tap index of slot sl at this phase (>= T: idle)
         constexpr int cs = ((D * sl + D - 1 - (T - 1)) % P + P) % P;   // phase at which slot sl starts a chain
         constexpr bool wraps = (cs + T - 1 >= P);              // that chain completes in the NEXT body
-        constexpr bool head = wraps && ph >= cs;               // this phase belongs to a chain completing in the next body
-        constexpr bool run = (e < T) && ((MODE == SBODY_MID) || (MODE == SBODY_LAST && !head) ||
-                                         (MODE == SBODY_WARM && (head || (sl == S - 1 && ph >= cs))));
+        constexpr bool head = wraps && ph >= cs;               // this phase starts a chain completing in the next body
+        constexpr bool tail = wraps && ph <= D * sl + D - 1;   // this phase completes a chain started in the previous body
+        constexpr bool run = (e < T) && ((MODE == SBODY_MID) || (MODE == SBODY_LAST && !head) || (MODE == SBODY_FIRST && !tail) ||
+                                         (MODE == SBODY_HEADA && head) || (MODE == SBODY_HEADB && tail));
         if constexpr (run) {
-          // the tap is wave-uniform: one half of a VGPR pair, broadcast to both halves of the pack by op_sel
-          if constexpr (e == T - 1) { if constexpr (e & 1) pk_first_bcast_v<1>(acc[sl], hp[e / 2], x); else pk_first_bcast_v<0>(acc[sl], hp[e / 2], x); }
-          else { if constexpr (e & 1) pk_fma_bcast_v<1>(acc[sl], hp[e / 2], x); else pk_fma_bcast_v<0>(acc[sl], hp[e / 2], x); }
+          // the tap is wave-uniform: one half of a register pair (VGPR; the last few pairs SGPR), broadcast to both halves of the
+          // pack by op_sel
+          constexpr bool sg = e / 2 >= T / 2 - stream_sgpr_pairs(T);
+          if constexpr (e == T - 1) {
+            if constexpr (sg) { if constexpr (e & 1) pk_first_bcast<1>(acc[sl], hp[e / 2], x); else pk_first_bcast<0>(acc[sl], hp[e / 2], x); }
+            else { if constexpr (e & 1) pk_first_bcast_v<1>(acc[sl], hp[e / 2], x); else pk_first_bcast_v<0>(acc[sl], hp[e / 2], x); }
+          } else {
+            if constexpr (sg) { if constexpr (e & 1) pk_fma_bcast<1>(acc[sl], hp[e / 2], x); else pk_fma_bcast<0>(acc[sl], hp[e / 2], x); }
+            else { if constexpr (e & 1) pk_fma_bcast_v<1>(acc[sl], hp[e / 2], x); else pk_fma_bcast_v<0>(acc[sl], hp[e / 2], x); }
+          }
         }
       });
-      // outputs complete at phases D-1, 2D-1, ...: slot ph / D; every second one closes a pair for the packed discriminator
-      if constexpr (MODE != SBODY_WARM && ph % D == D - 1 && ((ph / D) & 1) == 1) {
+      // outputs complete at phases D-1, 2D-1, ...: slot ph / D; every second one closes a pair for the packed discriminator.
+      // Outputs 0 .. NH-1 of a segment (and with them d[0 .. NH]) are not available in its FIRST body: HEADB supplies them.
+      if constexpr (MODE != SBODY_HEADA && ph % D == D - 1 && ((ph / D) & 1) == 1) {
         constexpr int s1 = ph / D, s0 = s1 - 1;
-        const f2_t d2 = discriminate_pair(acc[s0], prev, acc[s1]);
-        dn[s0] = d2.x;
-        dn[s1] = d2.y;
-        prev = acc[s1];
+        if constexpr (MODE == SBODY_FIRST && s1 < NH) {
+        } else if constexpr (MODE == SBODY_FIRST && s0 < NH) {     // s0 = NH-1, s1 = NH (NH odd): y[NH] waits for y[NH-1]
+          ysave = acc[s1];
+          prev = acc[s1];
+        } else if constexpr (MODE == SBODY_FIRST && s0 == NH) {    // (NH even): d[NH] waits for y[NH-1], d[NH+1] is complete
+          const f2_t d2 = discriminate_pair(acc[s0], acc[s0], acc[s1]);
+          dn[s1] = d2.y;
+          ysave = acc[s0];
+          prev = acc[s1];
+        } else if constexpr (MODE == SBODY_HEADB && s1 > NH) {
+        } else if constexpr (MODE == SBODY_HEADB && s1 == NH) {    // (NH odd): the pair (y[NH-1], y[NH] kept by FIRST)
+          const f2_t d2 = discriminate_pair(acc[s0], prev, ysave);
+          dn[s0] = d2.x;
+          dn[s1] = d2.y;
+        } else {
+          const f2_t d2 = discriminate_pair(acc[s0], prev, acc[s1]);
+          dn[s0] = d2.x;
+          dn[s1] = d2.y;
+          prev = acc[s1];
+        }
       }
       x = xn;
     });
     cur = nxt;
   });
-  if constexpr (MODE == SBODY_WARM) prev = acc[S - 1];       // y[-1] of the segment
+  if constexpr (MODE == SBODY_HEADB && (NH % 2) == 0) {        // d[NH] = K3(y[NH] kept by FIRST | y[NH-1])
+    const f2_t d2 = discriminate_pair(ysave, prev, ysave);
+    dn[NH] = d2.x;
+  }
 }
 
 template <int T, int D, int S, int NB, int TA, int DA>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_stream(CallParams p) {
   constexpr int P = S * D, L = NB * P, OPL = NB * S;           // samples per body / per lane segment, outputs per lane
   constexpr int NCH = P / 8;                                    // 16-byte pieces (8 samples) a body reads
-  constexpr int WP = 8;                                         // pieces the warm-up reads: the one line before the segment
   constexpr int SLOT = 64 * 128;                                // bytes per line slot of the ring (64 lanes x one 128-byte line)
-  constexpr int NLINES = (WP + NB * NCH + 4 + 7) / 8;           // lines a lane walks through (odd-segment lanes start mid-line)
+  constexpr int NLINES = (NB * NCH + 4 + 7) / 8;                // lines a lane walks through (odd-segment lanes start mid-line)
+  constexpr int NH = stream_heads(T, D, S);                     // head outputs per segment (deferred to the end of the walk)
+  constexpr int CS0 = ((D - 1 - (T - 1)) % P + P) % P, NHA = NCH - CS0 / 8;   // pieces of the left neighbour the heads read
   static_assert(P % 8 == 0 && S % 2 == 0 && P >= T && T % 2 == 0 && (OPL % 4) == 0 && TA - 1 <= OPL, "design S geometry");
-  static_assert((L * 2) % 128 == 64 && T - 1 <= 64, "design S: segment starts alternate between line starts and line middles; the history fits one line");
-  // the ring schedule relies on: every refill due in the warm-up / MID bodies fetches a line that exists (vmcnt(4) then always
+  static_assert((L * 2) % 128 == 64 && NHA <= 8, "design S: segment starts alternate between line starts and line middles; the heads fit the neighbour's last line(s)");
+  // the ring schedule relies on: every refill due in the FIRST / MID bodies fetches a line that exists (vmcnt(4) then always
   // leaves exactly the youngest refill outstanding), and none is due in the LAST body (which waits for everything)
-  static_assert(stream_refill_line_range(WP + (NB - 1) * NCH, false) < NLINES && stream_refill_line_range(WP + NB * NCH, true) >= NLINES,
+  static_assert(stream_refill_line_range((NB - 1) * NCH, false) < NLINES && stream_refill_line_range(NB * NCH, true) >= NLINES,
                 "design S ring schedule");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = (int)threadIdx.x;
@@ -1089,52 +1131,51 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   int nuse = segs - 63 * w;                                     // useful lanes 1..nuse
   if (nuse > 63) nuse = 63;
 
-  f2_t hp[T / 2];                                               // taps: wave-uniform pairs held in VGPRs (64 taps would not fit the SGPR
-#pragma unroll                                                  // file next to the kernel's scalars); op_sel picks the half at each use
-  for (int k = 0; k < T / 2; ++k) hp[k] = f2_t{p.h[2 * k], p.h[2 * k + 1]};
+  f2_t hp[T / 2];                                               // taps: wave-uniform pairs, op_sel picks the half at each use; most live in
+#pragma unroll                                                  // VGPRs (64 taps do not fit the SGPR file next to the kernel's scalars), the
+  for (int k = 0; k < T / 2; ++k) hp[k] = f2_t{p.h[2 * k], p.h[2 * k + 1]};   // last few in SGPRs (VGPRs are the scarcer file here)
 #pragma unroll
-  for (int k = 0; k < T / 2; ++k) asm volatile("" : "+v"(hp[k]));
+  for (int k = 0; k < T / 2; ++k) {
+    if (k < T / 2 - stream_sgpr_pairs(T)) asm volatile("" : "+v"(hp[k]));
+    else asm volatile("" : "+s"(hp[k]));
+  }
 
-  // ---- the ring: HBM --LDS-DMA--> LDS, whole 128-byte lines, every line of the stream fetched by exactly one lane-stage ------
-  // A lane's byte stream starts 64 samples (one line) before its segment: at a line start for even segments (class 0), in the
-  // middle of a line for odd ones (class 1: L*2 = 7.5 lines), so class 1 begins at piece 4 of its first line.  Lanes are grouped
-  // by class in LDS (region rho = 32 class + lane / 2): one DMA instruction fills the current line slot of 8 regions of ONE
-  // class (lane t of the instruction: region 8 i + t / 8, piece t % 8, fetched from column piece ^ swizzle), so a class is
-  // refilled the moment its lanes cross a line boundary.  Lanes whose segment lies outside the call fetch (and never use)
-  // the row's first line; nothing is ever switched off, so vmcnt counts DMA instructions exactly.
+  // ---- the ring: HBM --LDS-DMA--> LDS, whole 128-byte lines --------------------------------------------------------------
+  // A lane's byte stream starts at its segment: at a line start for even segments (class 0), in the middle of a line for odd
+  // ones (class 1: L*2 = 7.5 lines), so class 1 begins at piece 4 of its first line.  Lanes are grouped by class in LDS (region
+  // rho = 32 class + lane / 2): one DMA instruction fills the current line slot of 8 regions of ONE class (lane t of the
+  // instruction: region 8 i + t / 8, piece t % 8, fetched from column piece ^ swizzle), so a class is refilled the moment its
+  // lanes cross a line boundary.  Lanes whose segment lies outside the call fetch (and never use) the row's first line; nothing
+  // is ever switched off, so vmcnt counts DMA instructions exactly.  Only the line an even segment shares with its odd right
+  // neighbour is fetched twice (16 fetches per 15 lines).
   const unsigned long long gaddr = (unsigned long long)(p.iq + (size_t)stream * p.iq_stride);
   const i4_t rsrc = {(int)(unsigned)gaddr, (int)(unsigned)(gaddr >> 32), (int)(2u * p.N), 0x00020000};
   const int g0odd = g0 & 1;
   auto swz = [](int rho) { return ((rho >> 1) + 4 * (rho >> 5)) & 7; };
   int voffs[2][4];                                              // byte offset (in the row) of this lane's piece of line 0, per (class, i)
-  bool first_seg[4];                                            // class 0: the lane-segment is segment 0 of the call (its line 0 precedes the row)
 #pragma unroll
   for (int cls = 0; cls < 2; ++cls)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int l = 16 * i + 2 * (lane >> 3) + (cls ^ g0odd), g = g0 + l, rho = 32 * cls + 8 * i + (lane >> 3);
       const int col = (lane & 7) ^ swz(rho);
-      const bool ok = g >= 0 && g < segs;
-      voffs[cls][i] = (ok ? g * (L * 2) - 128 - 64 * cls : 0) + 16 * col;
-      if (cls == 0) first_seg[i] = ok && g == 0;
+      voffs[cls][i] = ((g >= 0 && g < segs) ? g * (L * 2) - 64 * cls : 0) + 16 * col;
     }
-  auto fill = [&](int cls, int n, bool initial) {               // line n of every lane of one class -> slot n & 1
+  auto fill = [&](int cls, int n) {                             // line n of every lane of one class -> slot n & 1
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int v = (cls ? voffs[1][i] : voffs[0][i]) + 128 * n;
-      if (initial && first_seg[i]) v += 128;                    // segment 0's line 0 lies before the row: its place is patched below
+    for (int i = 0; i < 4; ++i)
       llvm_amdgcn_raw_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(smem + (n & 1) * SLOT + (32 * cls + 8 * i) * 128), 16,
-                                      v, 0, 0, SDRFM_STREAM_AUX);
-    }
+                                      (cls ? voffs[1][i] : voffs[0][i]) + 128 * n, 0, 0, SDRFM_STREAM_AUX);
   };
   auto refill = [&](int u) {                                    // chunk u begins: class (u / 4) % 2 has just finished a line
     const int cls = (u >> 2) & 1, n = ((u + 4 * cls) >> 3) + 1;
     if (n < NLINES) {
-      if (cls) fill(1, n, false); else fill(0, n, false);
+      if (cls) fill(1, n); else fill(0, n);
     }
   };
   auto wait4 = [] { __builtin_amdgcn_s_waitcnt(0x0f74); };      // vmcnt(4): everything but the youngest refill (4 instructions) has landed
   auto wait0 = [] { __builtin_amdgcn_s_waitcnt(0x0f70); };
+  auto no_wait = [] {};
   auto no_refill = [](int) {};
 
 #ifdef SDRFM_DEV   // development build: per-wave time stamps (shader cycles) at the phase boundaries, 32 words per wave
@@ -1146,28 +1187,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #define SDRFM_STAMP() do { } while (0)
 #endif
   SDRFM_STAMP();                                                // 0: entry
-  fill(0, 0, true); fill(1, 0, true); fill(1, 1, false);       // class 1 starts mid-line: it needs its second line during the warm-up
+  fill(0, 0); fill(1, 0); fill(1, 1);                           // class 1 starts mid-line: it needs its second line after 32 samples
   f2_t acc[S];
 #pragma unroll
   for (int k = 0; k < S; ++k) acc[k] = f2_t{0.f, 0.f};
-  f2_t prev = {0.f, 0.f};
+  f2_t prev = {0.f, 0.f}, ysave = {0.f, 0.f};
   float dn[S], dreg[OPL];
+  u4_t kept[stream_kept_pieces(T, D, S)];
   const int mycls = (g0 + lane) & 1, myrho = 32 * mycls + (lane >> 1);
   StreamRing ring = {(unsigned)(myrho * 128), (unsigned)(16 * swz(myrho)), (unsigned)(64 * mycls)};
+  auto rd = [&](auto) { return ring.read(smem); };
   __builtin_amdgcn_s_waitcnt(0x0f74);                           // vmcnt(4): the first line of both classes has landed
-  fill(0, 1, false);                                            // class 0's second line is not needed before the first body: it queues
-  SDRFM_STAMP();                                                // behind the opening burst instead of lengthening it.  1: first lines in LDS
-  if (w == 0) {
-    // the first segment of the call (lane 1, class 0, region 0, swizzle 0): its first line is the carried raw history
-    for (int k = lane; k < T - 1; k += 64)
-      *reinterpret_cast<unsigned short*>(smem + 128 - 2 * (T - 1) + 2 * k) =
-          reinterpret_cast<const unsigned short*>(p.hist_b_in)[(size_t)stream * (T - 1) + k];
-    __syncthreads();
-  }
-  stream_body<T, D, S, SBODY_WARM>(smem, ring, -(NCH - WP), wait4, refill, hp, acc, prev, dn);
-  if (w == 0 && lane == 1) { const float2 yp = p.yprev_in[stream]; prev = f2_t{yp.x, yp.y}; }
-  SDRFM_STAMP();                                                // 2: warm-up body done
-  for (int b = 0; b < NB - 1; ++b) {
+  fill(0, 1);                                                   // class 0's second line is not needed for 64 samples: it queues behind the
+  SDRFM_STAMP();                                                // opening burst instead of lengthening it.  1: first lines in LDS
+  stream_body<T, D, S, SBODY_FIRST>(rd, 0, wait4, refill, hp, acc, prev, dn, ysave, kept);
+#pragma unroll
+  for (int k = 0; k < S; ++k) dreg[k] = dn[k];                  // (d[0 .. NH] are placeholders until the head pass)
+  SDRFM_STAMP();                                                // 2: first body done
+  for (int b = 1; b < NB - 1; ++b) {
     // The two waves of a SIMD are arbitrated oldest-first: one runs ahead at the single-wave rate and the other finishes alone.
     // Priority falls with progress, so whichever is behind wins the issue slot and the pair finishes together.
     if (p.prio_balance) {
@@ -1177,9 +1214,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       else __builtin_amdgcn_s_setprio(1);
     }
     SDRFM_STAMP();                                              // 3, 5, 7, ...
-    stream_body<T, D, S, SBODY_MID>(smem, ring, WP + NCH * b, wait4, refill, hp, acc, prev, dn);
+    stream_body<T, D, S, SBODY_MID>(rd, NCH * b, wait4, refill, hp, acc, prev, dn, ysave, kept);
 #pragma unroll
-    for (int bb = 0; bb < NB - 1; ++bb)
+    for (int bb = 1; bb < NB - 1; ++bb)
       if (b == bb) {
         asm volatile("" ::: "memory");                          // keep this a scalar branch: S moves, not NB*S selects
 #pragma unroll
@@ -1190,11 +1227,41 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   if (p.prio_balance) __builtin_amdgcn_s_setprio(0);
   // the last body: no line is left to fetch (the refills it would trigger lie beyond the lane's last line), so every wait is for
   // all outstanding requests
-  stream_body<T, D, S, SBODY_LAST>(smem, ring, WP + NCH * (NB - 1), wait0, no_refill, hp, acc, prev, dn);
+  stream_body<T, D, S, SBODY_LAST>(rd, NCH * (NB - 1), wait0, no_refill, hp, acc, prev, dn, ysave, kept);
 #pragma unroll
   for (int k = 0; k < S; ++k) dreg[(NB - 1) * S + k] = dn[k];
+  const f2_t ylast = prev;                                      // y of the segment's last output
+  SDRFM_STAMP();                                                // last body done
 
-  SDRFM_STAMP();                                                // 3 + 2(NB-1): last body done
+  // ---- the heads: outputs 0 .. NH-1 of every segment, from the left neighbour's last NHA pieces (in its ring slots: nothing has
+  // been fetched into them since) and the lane's own first pieces (kept raw by the first body) ---------------------------------
+  {
+    const int ll = lane > 0 ? lane - 1 : 0, lcls = (g0 + ll) & 1, lrho = 32 * lcls + (ll >> 1);
+    if (w == 0) {
+      // the first segment of the call (lane 1) has the carried raw history for a left neighbour: the last T-1 samples of "segment
+      // -1" go where lane 0's ring region would hold them (lane 0's own walk ran on the row's first line: unused)
+      __syncthreads();
+      const int rho0 = 32 * ((g0 + 0) & 1), rot0 = 16 * swz(rho0);
+      for (int k = lane; k < T - 1; k += 64) {
+        const int sl = L - (T - 1) + k, t16 = 16 * ((sl >> 3) + 4 * ((g0 + 0) & 1));
+        *reinterpret_cast<unsigned short*>(smem + rho0 * 128 + (((t16 ^ rot0) & 0x70) | ((t16 & 0x80) << 6)) + 2 * (sl & 7)) =
+            reinterpret_cast<const unsigned short*>(p.hist_b_in)[(size_t)stream * (T - 1) + k];
+      }
+      __syncthreads();
+    }
+    StreamRing lring = {(unsigned)(lrho * 128), (unsigned)(16 * swz(lrho)), (unsigned)(16 * (NB * NCH - NHA + 4 * lcls))};
+    auto lrd = [&](auto) { return lring.read(smem); };
+    auto krd = [&](auto C) { return kept[decltype(C)::value]; };
+    prev.x = __shfl_up(ylast.x, 1);                             // y[-1] of the segment = the left neighbour's last output
+    prev.y = __shfl_up(ylast.y, 1);
+    if (w == 0 && lane == 1) { const float2 yp = p.yprev_in[stream]; prev = f2_t{yp.x, yp.y}; }
+    stream_body<T, D, S, SBODY_HEADA>(lrd, 0, no_wait, no_refill, hp, acc, prev, dn, ysave, kept);
+    stream_body<T, D, S, SBODY_HEADB>(krd, 0, no_wait, no_refill, hp, acc, prev, dn, ysave, kept);
+#pragma unroll
+    for (int k = 0; k <= NH; ++k) dreg[k] = dn[k];
+  }
+  SDRFM_STAMP();                                                // heads done
+
   // ---- audio stage: d's of the whole span -> LDS (linear in d index; lane 0's segment first), lanes = audio outputs ------
   float* dl = reinterpret_cast<float*>(smem);
   float* gs = dl + 64 * OPL;                                    // audio taps, reversed
@@ -1247,7 +1314,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #undef SDRFM_STAMP
   // ---- state hand-over by the wave that holds the end of the stream's chunk ------------------------------------------------
   if (p.fold_state && 63 * w + nuse == segs) {
-    if (lane == nuse) p.yprev_out[stream] = make_float2(prev.x, prev.y);
+    if (lane == nuse) p.yprev_out[stream] = make_float2(ylast.x, ylast.y);
     for (int k = lane; k < TA - 1; k += 64) p.hist_d_out[(size_t)stream * (TA - 1) + k] = dl[(nuse + 1) * OPL - (TA - 1) + k];
     for (int k = lane; k < T - 1; k += 64) {
       const int c = (int)p.N - (T - 1) + k;

@@ -24,8 +24,8 @@ lib = pkg.load_library(dev=True)
 lib.sdrfm_dev_read_debug.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32]
 assert lib.sdrfm_dev_read_debug(dm._h, raw, 32 * waves) == 0
 t = np.frombuffer(raw, dtype=np.uint64).reshape(waves, 32).astype(np.int64)
-cyc = t[:, :3 + 2 * (NB - 1) + 2]                     # entry, stage0, warm, (wait, body) x5, last, audio
-names = ["first line wait", "warm-up body"] + [x for b in range(NB - 1) for x in ("prio %d" % b, "body %d" % b)] + ["last body", "audio stage"]
+cyc = t[:, :3 + 2 * (NB - 2) + 3]                 # entry, first lines, first body, (prio, body) x4, last, heads, audio
+names = ["first line wait", "first body"] + [x for b in range(1, NB - 1) for x in ("prio %d" % b, "body %d" % b)] + ["last body", "head pass", "audio stage"]
 d = np.diff(cyc, axis=1)
 hw = t[:, 29]; xcc = hw & 0xf; hwid = hw >> 32
 simd = (hwid >> 4) & 3; cu = (hwid >> 8) & 0xf; se = (hwid >> 13) & 7; sh = (hwid >> 12) & 1
