@@ -1296,7 +1296,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
     for (int k = 0; k < TA; ++k)                               // NOUT independent chains side by side, each in the oracle's order
 #pragma unroll
-      for (int i = 0; i < NOUT; ++i) a[i] = __builtin_fmaf(gv[k], dw[DA * i + k], a[i]);
+      for (int i = 0; i < NOUT; ++i) asm("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "v"(gv[k]), "v"(dw[DA * i + k]));   // (plain fmaf: the compiler packs pairs of chains and spends 120 v_mov on it)
 #pragma unroll
     for (int i = 0; i < NOUT; ++i) outl[lane * NOUT + i] = a[i];
   }
