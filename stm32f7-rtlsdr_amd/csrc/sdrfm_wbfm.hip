@@ -671,22 +671,23 @@ static int wenqueue(sdrfm_wbfm* h, const uint8_t* d_iq, size_t iq_stride, uint32
   w.iq_span = (uint32_t)span;
   if (h->fused_ok && Tn >= 64 && span < (1ull << 32)) {
     // fused kernel: every stream is cut into runs of NT steps (even: steps are processed in pairs); one 16-lane group per
-    // run, the 4 groups of a wave = the same run of 4 neighbouring streams, 4 waves per block.  The kernel is VALU-bound and
-    // issues best with 4 blocks (4 waves per SIMD) resident on every CU, all started together: NT is chosen so that the grid
-    // is R full rounds of 4 blocks per CU (measured, 128 streams x 20 000 steps: 4 blocks per CU in one round 113 us, the
-    // 3 blocks per CU a "fewest warm-up steps" model picked 132 us; a handful of surplus blocks costs nothing, they start in
-    // the skew of the first finishers), with the R that minimises rounds x (steps per run incl. ~20 warm-up steps).
+    // run, the 4 groups of a wave = the same run of 4 neighbouring streams, 4 waves per block.  Every run re-computes ~20 warm-up
+    // steps (12.7 % of the work and of the input traffic at NT = 158), so runs should be long; the kernel is VALU-bound and two
+    // blocks per CU (two waves per SIMD) already keep the pipe as busy as four do (128 streams x 20 000 steps, same box, three
+    // measurements each: NT = 158, 4 blocks per CU: 113-127 us; NT = 210, 3 per CU: 118-132 us; NT = 312-320, 2 per CU: 116-120 us).
+    // NT is chosen so that the grid is R full rounds of 2 blocks per CU, with the R that minimises rounds x (NT + 20); a handful
+    // of surplus blocks costs nothing, they start in the skew of the first finishers.
     const uint64_t quads = (c.n_streams + 3) / 4;
     uint64_t best = ~0ull;
     w.NT = 64;
     for (uint32_t R = 1; R <= 64; ++R) {
-      uint64_t runs = 16ull * h->n_cu * R / quads;              // runs per stream that make R rounds of 4 blocks per CU
+      uint64_t runs = 8ull * h->n_cu * R / quads;               // runs per stream that make R rounds of 2 blocks per CU
       if (runs < 1) runs = 1;
       uint64_t nt = ((Tn + runs - 1) / runs + 1) & ~1ull;
       if (nt < 64) nt = 64;
       if (nt > 8192) nt = 8192;
       const uint64_t blocks = (quads * ((Tn + nt - 1) / nt) + 3) / 4;
-      const uint64_t rounds = (blocks + 4ull * h->n_cu - 1) / (4ull * h->n_cu);
+      const uint64_t rounds = (blocks + 2ull * h->n_cu - 1) / (2ull * h->n_cu);
       const uint64_t cost = rounds * (nt + 20);
       if (cost < best) { best = cost; w.NT = (uint32_t)nt; }
       if (nt == 64) break;

@@ -25,9 +25,12 @@ run_wl() {   # name, kernel filter, bench args...
   done
   python3 tools/profile_round2_summarize.py "$W" "$OUT" "$TAG" "$WL" "$KF" "$COMMIT"
 }
-run_wl fm256 k_stream
-run_wl fm512 k_stream --streams-per-gpu 512
-run_wl fm256_T16 k_fastb --fir-taps 16
-run_wl wbfm k_wbfm_fused --workload wbfm
-run_wl spectrum k_spectrum --workload spectrum
+WLS=${WLS:-"fm256 fm512 fm256_T16 wbfm spectrum"}      # WLS="wbfm" re-takes one workload only
+for wl in $WLS; do case $wl in
+  fm256)     run_wl fm256 k_stream ;;
+  fm512)     run_wl fm512 k_stream --streams-per-gpu 512 ;;
+  fm256_T16) run_wl fm256_T16 k_fastb --fir-taps 16 ;;
+  wbfm)      run_wl wbfm k_wbfm_fused --workload wbfm ;;
+  spectrum)  run_wl spectrum k_spectrum --workload spectrum ;;
+esac; done
 ls -la "$OUT"
