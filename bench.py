@@ -84,15 +84,22 @@ def self_launch(args):
     sys.exit(proc.returncode if proc.returncode else (0 if line else 1))
 
 
-def latest_traffic(kernel_name):
-    """HBM bytes per launch from the newest committed PMC summary (profiles/traffic_r*.json), if it is for this kernel."""
+def latest_traffic(kernel_name, alg_bytes=None):
+    """HBM bytes per launch from the newest committed PMC summary (profiles/traffic_r*.json, profiles/r*_pmc.json) taken for this
+    kernel AND this workload size (same algorithmic bytes per launch); None when no committed profile matches."""
     best = None
-    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json"))):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_pmc.json")) + glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")),
+                   key=lambda fn: (os.path.basename(fn).replace("traffic_", "")[:3], os.path.basename(fn).startswith("traffic_")))
+    for fn in files:
         try:
             with open(fn) as f:
                 t = json.load(f)
-            if t.get("kernel_name") == kernel_name:
-                best = dict(t, file=os.path.basename(fn))
+            if t.get("kernel_name") != kernel_name or "hbm_bytes_per_launch" not in t:
+                continue
+            ab = t.get("algorithmic_bytes_per_launch")
+            if alg_bytes is not None and ab and abs(ab - alg_bytes) > 1e-3 * alg_bytes:
+                continue
+            best = dict(t, file=os.path.basename(fn))
         except Exception:
             pass
     return best
@@ -300,7 +307,7 @@ def main():
         samples_per_launch = ns * nsamp
         alg_bytes = samples_per_launch * 2.0 + ns * n_audio * 4.0        # 2 B in + 4/(D*Da) B out per IQ sample
         achieved = alg_bytes / (kernel_ms_avg * 1e-3) / 1e9
-        traffic = latest_traffic(dm.kernel_name)
+        traffic = latest_traffic(dm.kernel_name, alg_bytes)
         res = {
             "metric": "IQ MSamples/s through FIR+FM-demod+resample",
             "value": round(value, 1), "unit": "MSamples/s",
@@ -320,7 +327,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
-                         "traffic_source": ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at commit %s)" % (traffic["file"], traffic.get("commit", "?"))) if traffic else None,
+                         "traffic_source": ("profiles/%s (rocprofv3 --pmc TCC_EA0 read/write request passes at commit %s; same kernel, same workload size)" % (traffic["file"], traffic.get("commit", "?"))) if traffic else None,
                          "kernel": dm.kernel_name, "kernel_ms_avg": round(kernel_ms_avg, 4),
                          "kernel_ms_isolated_avg": round(float(np.mean(kernel_ms)), 4),
                          "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
@@ -375,7 +382,7 @@ def main_wbfm(args, pkg, world, rank, local_rank, use_dist, rccl_world):
     n_audio = last["n"]
     if rank == 0:
         alg = ns * nsamp * 2.0 + ns * 16 * n_audio * 4.0
-        tr = latest_traffic(kname)
+        tr = latest_traffic(kname, alg)
         res = {"metric": "IQ MSamples/s through FIR+FM-demod+resample", "value": round(world * ns * nsamp * args.steps / elapsed / 1e6, 1),
                "unit": "MSamples/s", "n_gpus": world, "rccl_world": rccl_world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -432,7 +439,7 @@ def main_spectrum(args, pkg, world, rank, local_rank, use_dist, rccl_world):
                           "streams_per_gpu": ns, "bytes_per_stream": 2 * nsamp, "kernel": kname, "input_batches_rotated": nb},
                "roofline": {"bound": "hbm", "achieved": round(alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                             "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                            "traffic": (latest_traffic(kname) or {}).get("hbm_bytes_per_launch"),
+                            "traffic": (latest_traffic(kname, alg) or {}).get("hbm_bytes_per_launch"),
                             "kernel_ms_avg": round(ms, 4), "algorithmic_bytes_per_launch": alg}}
         print(json.dumps(res), flush=True)
     sv.set_stream(None)
