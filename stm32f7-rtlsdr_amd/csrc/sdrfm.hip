@@ -75,6 +75,7 @@ struct CallParams {
   uint32_t AB;                // fast kernel: sub-tiles of d buffered per audio flush
   uint32_t warm_ahead;        // fast kernel: L2 warm-up distance in sub-tiles (0 = off)
   uint32_t prio_balance;      // design B: wave priority falls with progress (keeps the two waves of a SIMD in step)
+  uint32_t end_prio;          // design S: priorities of the last body / head pass / audio stage: 2 bits each, slot-0 wave in bits 0-5, slot-1 wave in bits 6-11
   uint32_t dbg_tag;           // profiling build: 1 on the one launch whose wave start/end skew is recorded
   uint32_t fold_state;        // design B: the last segment's wave hands the state over (no state blocks in the grid)
   unsigned long long* dbg;    // phase-cycle accumulators (profiling build of the fast kernel only), else nullptr
@@ -1118,6 +1119,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   constexpr int CS0 = ((D - 1 - (T - 1)) % P + P) % P, NHA = NCH - CS0 / 8;   // pieces of the left neighbour the heads read
   static_assert(P % 8 == 0 && S % 2 == 0 && P >= T && T % 2 == 0 && (OPL % 4) == 0 && TA - 1 <= OPL, "design S geometry");
   static_assert((L * 2) % 128 == 64 && NHA <= 8, "design S: segment starts alternate between line starts and line middles; the heads fit the neighbour's last line(s)");
+  static_assert((NB * NCH) % 8 == 4, "design S: a class-0 lane ends, and a class-1 lane starts, in the middle of a line (the half-line fetches rely on it)");
   // the ring schedule relies on: every refill due in the FIRST / MID bodies fetches a line that exists (vmcnt(4) then always
   // leaves exactly the youngest refill outstanding), and none is due in the LAST body (which waits for everything)
   static_assert(stream_refill_line_range((NB - 1) * NCH, false) < NLINES && stream_refill_line_range(NB * NCH, true) >= NLINES,
@@ -1145,9 +1147,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // ones (class 1: L*2 = 7.5 lines), so class 1 begins at piece 4 of its first line.  Lanes are grouped by class in LDS (region
   // rho = 32 class + lane / 2): one DMA instruction fills the current line slot of 8 regions of ONE class (lane t of the
   // instruction: region 8 i + t / 8, piece t % 8, fetched from column piece ^ swizzle), so a class is refilled the moment its
-  // lanes cross a line boundary.  Lanes whose segment lies outside the call fetch (and never use) the row's first line; nothing
-  // is ever switched off, so vmcnt counts DMA instructions exactly.  Only the line an even segment shares with its odd right
-  // neighbour is fetched twice (16 fetches per 15 lines).
+  // lanes cross a line boundary.  Lanes whose segment lies outside the call fetch (and never use) the row's first line; no
+  // instruction is ever skipped, so vmcnt counts DMA instructions exactly.  The line an even segment shares with its odd right
+  // neighbour is fetched half by each (64-byte requests): every byte of the row crosses the fabric once.
   const unsigned long long gaddr = (unsigned long long)(p.iq + (size_t)stream * p.iq_stride);
   const i4_t rsrc = {(int)(unsigned)gaddr, (int)(unsigned)(gaddr >> 32), (int)(2u * p.N), 0x00020000};
   const int g0odd = g0 & 1;
@@ -1161,16 +1163,25 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       const int col = (lane & 7) ^ swz(rho);
       voffs[cls][i] = ((g >= 0 && g < segs) ? g * (L * 2) - 64 * cls : 0) + 16 * col;
     }
-  auto fill = [&](int cls, int n) {                             // line n of every lane of one class -> slot n & 1
+  // half: 0 = whole lines; 1 / 2 = only the lower / upper 64 bytes of every line (the other lanes of the instruction are switched
+  // off: the instruction still counts in vmcnt).  A class-1 lane starts at piece 4 of its line 0 and a class-0 lane ends with piece
+  // 3 of its last line; the other half of those lines is the neighbour segment's, who fetches it itself.  The line offset goes in
+  // the scalar offset operand (no vector add per instruction).
+  auto fill = [&](int cls, int n, int half = 0) {               // line n of every lane of one class -> slot n & 1
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      llvm_amdgcn_raw_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(smem + (n & 1) * SLOT + (32 * cls + 8 * i) * 128), 16,
-                                      (cls ? voffs[1][i] : voffs[0][i]) + 128 * n, 0, 0, SDRFM_STREAM_AUX);
+    for (int i = 0; i < 4; ++i) {
+      const int vo = cls ? voffs[1][i] : voffs[0][i];
+      auto* dst = (__attribute__((address_space(3))) void*)(smem + (n & 1) * SLOT + (32 * cls + 8 * i) * 128);
+      if (half == 0) llvm_amdgcn_raw_buffer_load_lds(rsrc, dst, 16, vo, 128 * n, 0, SDRFM_STREAM_AUX);
+      else if ((half == 2) == ((vo & 64) != 0)) llvm_amdgcn_raw_buffer_load_lds(rsrc, dst, 16, vo, 128 * n, 0, SDRFM_STREAM_AUX);
+    }
   };
   auto refill = [&](int u) {                                    // chunk u begins: class (u / 4) % 2 has just finished a line
     const int cls = (u >> 2) & 1, n = ((u + 4 * cls) >> 3) + 1;
     if (n < NLINES) {
-      if (cls) fill(1, n); else fill(0, n);
+      if (cls) fill(1, n);
+      else if (n == NLINES - 1) fill(0, n, 1);
+      else fill(0, n);
     }
   };
   auto wait4 = [] { __builtin_amdgcn_s_waitcnt(0x0f74); };      // vmcnt(4): everything but the youngest refill (4 instructions) has landed
@@ -1187,7 +1198,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #define SDRFM_STAMP() do { } while (0)
 #endif
   SDRFM_STAMP();                                                // 0: entry
-  fill(0, 0); fill(1, 0); fill(1, 1);                           // class 1 starts mid-line: it needs its second line after 32 samples
+  fill(0, 0); fill(1, 0, 2); fill(1, 1);                        // class 1 starts mid-line: it needs its second line after 32 samples
   f2_t acc[S];
 #pragma unroll
   for (int k = 0; k < S; ++k) acc[k] = f2_t{0.f, 0.f};
@@ -1224,7 +1235,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       }
     SDRFM_STAMP();                                              // 4, 6, 8, ...: body done
   }
-  if (p.prio_balance) __builtin_amdgcn_s_setprio(0);
+  // From here on both waves of a SIMD would run at priority 0, where the arbiter prefers the wave in hardware slot 0: it ran ahead
+  // at the single-wave rate and the slot-1 wave finished the kernel alone (3.8 us later, measured).  The slot-1 wave therefore
+  // keeps priority 1 through the last body and the head pass: the pair then ends within 0.4 us of each other.
+  const uint32_t endp = (p.end_prio >> ((__builtin_amdgcn_s_getreg((31 << 11) | 4) & 1) ? 6 : 0)) & 63u;   // HW_ID.wave_id & 1
+  auto set_end_prio = [&](uint32_t v) {
+    if (!p.prio_balance) return;
+    v &= 3u;
+    if (v == 0) __builtin_amdgcn_s_setprio(0); else if (v == 1) __builtin_amdgcn_s_setprio(1);
+    else if (v == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
+  };
+  set_end_prio(endp);
   // the last body: no line is left to fetch (the refills it would trigger lie beyond the lane's last line), so every wait is for
   // all outstanding requests
   stream_body<T, D, S, SBODY_LAST>(rd, NCH * (NB - 1), wait0, no_refill, hp, acc, prev, dn, ysave, kept);
@@ -1233,6 +1254,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const f2_t ylast = prev;                                      // y of the segment's last output
   SDRFM_STAMP();                                                // last body done
 
+  set_end_prio(endp >> 2);
   // ---- the heads: outputs 0 .. NH-1 of every segment, from the left neighbour's last NHA pieces (in its ring slots: nothing has
   // been fetched into them since) and the lane's own first pieces (kept raw by the first body) ---------------------------------
   {
@@ -1262,50 +1284,83 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   }
   SDRFM_STAMP();                                                // heads done
 
-  // ---- audio stage: d's of the whole span -> LDS (linear in d index; lane 0's segment first), lanes = audio outputs ------
+  set_end_prio(endp >> 4);
+  // ---- audio stage: d's of the whole span -> LDS (lane 0's segment first), lanes = audio outputs ---------------------------
+  // All eight waves of a CU reach this stage together and it is LDS-bound, so the layout is chosen for the LDS: the d array is
+  // linear in the d index with a 4-word gap after every second segment (position(i) = i + 4 (i / (2 OPL))), which spreads the
+  // 16-byte stores of 8 neighbouring lanes (lane stride OPL words = 16 mod 32 banks otherwise: 4-way conflicts) over all banks;
+  // the windows are read as aligned 8-byte pairs at an even lane stride of NOUT DA words (conflict-free at 256 B per clock; the
+  // 4-byte reads they replace ran at 128 B per clock, 2-way conflicting).
   float* dl = reinterpret_cast<float*>(smem);
-  float* gs = dl + 64 * OPL;                                    // audio taps, reversed
+  constexpr int DLW = 64 * OPL + 4 * 32;                        // words of the gapped d array
+  auto dpos = [](int i) { return i + 4 * (int)((unsigned)i / (unsigned)(2 * OPL)); };
+  float* gs = dl + DLW;                                         // (TA words kept free: the window reads of the last lanes run into them)
+  float gv[TA];                                                 // audio taps, reversed: wave-uniform scalar loads, issued before the d's
+#pragma unroll                                                  // are written so that their latency hides behind the LDS stores
+  for (int k = 0; k < TA; ++k) gv[k] = p.g[TA - 1 - k];
   __syncthreads();
+  {
+    float* myd = dl + lane * OPL + 4 * (lane >> 1);
 #pragma unroll
-  for (int k = 0; k < OPL; k += 4) *reinterpret_cast<f4_t*>(dl + lane * OPL + k) = f4_t{dreg[k], dreg[k + 1], dreg[k + 2], dreg[k + 3]};
-  if (lane < TA) gs[lane] = p.g[TA - 1 - lane];
-  if (w == 0 && lane < TA - 1) dl[OPL - (TA - 1) + lane] = p.hist_d_in[(size_t)stream * (TA - 1) + lane];
+    for (int k = 0; k < OPL; k += 4) *reinterpret_cast<f4_t*>(myd + k) = f4_t{dreg[k], dreg[k + 1], dreg[k + 2], dreg[k + 3]};
+  }
+  SDRFM_STAMP();                                                // d's written
+  if (w == 0 && lane < TA - 1) dl[OPL - (TA - 1) + lane] = p.hist_d_in[(size_t)stream * (TA - 1) + lane];   // (before the first gap)
   __syncthreads();
+  SDRFM_STAMP();                                                // history in LDS
   const int G0 = 63 * w * OPL, G1 = G0 + nuse * OPL;           // d's [G0, G1) belong to this wave; local index = d - G0 + OPL
   const int jl = G0 / DA, jh = G1 / DA;                         // audio outputs whose newest d lies in [G0, G1)
   // Every lane computes NOUT consecutive outputs from ND consecutive d's: all LDS reads are issued up front (nothing in the
   // chains waits on memory), the taps sit in registers, and the results go back through LDS so that the stores are coalesced.
-  constexpr int NOUT = ((63 * OPL + DA - 1) / DA + 63) / 64, ND = (NOUT - 1) * DA + TA;
+  // The lanes start one output early where that makes the window's first d an even local index (the extra output belongs to
+  // the previous wave and is not stored), so that every pair read is 8-byte aligned and never straddles a gap.
+  constexpr int NOUT = ((63 * OPL + DA) / DA + 63) / 64, ND = (NOUT - 1) * DA + TA, NR = (ND + 1) / 2;
+  static_assert((DA % 2) == 1 && ((NOUT * DA) % 2) == 0 && (OPL % 2) == 0 && OPL >= TA + DA - 1 && 2 * NR <= 2 * OPL,
+                "audio stage of design S: even window starts, at most one gap inside a window");
   float* outl = gs + TA;                                        // 64 * NOUT results
-  static_assert((64 * OPL + TA + 64 * NOUT) * 4 <= 2 * SLOT && (DA * 64 * NOUT + TA + OPL) * 4 <= 2 * SLOT, "audio stage scratch exceeds the ring");
-  float gv[TA];
-#pragma unroll
-  for (int k = 0; k < TA; ++k) gv[k] = gs[k];
+  static_assert((DLW + TA + 64 * NOUT) * 4 <= 2 * SLOT && (DA * 64 * NOUT + TA + OPL + 4 * 34 + 2) * 4 <= 2 * SLOT, "audio stage scratch exceeds the ring");
+  const int jlo = jl - ((DA * jl + DA - 1 - (TA - 1) - G0 + OPL) & 1);
   {
-    const int j0 = jl + lane * NOUT;
-    // local index of the oldest d of output j0.  The lanes around the last output read past the d array, into the taps and
-    // the (not yet written) result area behind it: still inside the ring, and only into outputs that are never stored
+    const int j0 = jlo + lane * NOUT;
+    // local index of the oldest d of output j0 (even).  The lanes around the last output read past the d array, into the taps
+    // and the (not yet written) result area behind it: still inside the ring, and only into outputs that are never stored
     const int base = DA * j0 + DA - 1 - (TA - 1) - G0 + OPL;
-    const float* wd = dl + base;
-    float dw[ND];
+    const int gq = (int)((unsigned)base / (unsigned)(2 * OPL)), kb = 2 * OPL * (gq + 1) - base;   // window elements >= kb lie behind the next gap
+    const float* w0 = dl + base + 4 * gq;
+    const float* w1 = w0 + 4;
+    f2_t dw2[NR];
 #pragma unroll
-    for (int k = 0; k < ND; ++k) dw[k] = wd[k];
+    for (int i = 0; i < NR; ++i) dw2[i] = *reinterpret_cast<const f2_t*>((2 * i >= kb ? w1 : w0) + 2 * i);
     float a[NOUT];
 #pragma unroll
     for (int i = 0; i < NOUT; ++i) a[i] = 0.0f;
+    SDRFM_STAMP();                                              // window reads issued
 #pragma unroll
     for (int k = 0; k < TA; ++k)                               // NOUT independent chains side by side, each in the oracle's order
 #pragma unroll
-      for (int i = 0; i < NOUT; ++i) asm("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "v"(gv[k]), "v"(dw[DA * i + k]));   // (plain fmaf: the compiler packs pairs of chains and spends 120 v_mov on it)
+      for (int i = 0; i < NOUT; ++i) {                         // (plain fmaf: the compiler packs pairs of chains and spends 120 v_mov on it)
+        const int e = DA * i + k;
+        if (e & 1) asm("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "v"(gv[k]), "v"(dw2[e >> 1].y));
+        else asm("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "v"(gv[k]), "v"(dw2[e >> 1].x));
+      }
 #pragma unroll
-    for (int i = 0; i < NOUT; ++i) outl[lane * NOUT + i] = a[i];
+    for (int i = 0; i < NOUT; i += 2) {
+      if (i + 1 < NOUT) *reinterpret_cast<f2_t*>(outl + lane * NOUT + i) = f2_t{a[i], a[i + 1]};
+      else outl[lane * NOUT + i] = a[i];
+    }
   }
   __syncthreads();
+  SDRFM_STAMP();                                                // results in LDS
   float* out = p.audio + (size_t)stream * p.audio_stride;
+  float res[NOUT];
+#pragma unroll
+  for (int m = 0; m < NOUT; ++m) res[m] = outl[64 * m + lane];
+#pragma unroll
+  for (int m = 0; m < NOUT; ++m) asm volatile("" : "+v"(res[m]));   // all reads first, then the stores
 #pragma unroll
   for (int m = 0; m < NOUT; ++m) {
-    const int j = jl + 64 * m + lane;
-    if (j < jh) __builtin_nontemporal_store(outl[64 * m + lane], out + j);
+    const int j = jlo + 64 * m + lane;
+    if (j >= jl && j < jh) __builtin_nontemporal_store(res[m], out + j);
   }
   SDRFM_STAMP();                                                // audio stage done
 #ifdef SDRFM_DEV
@@ -1315,7 +1370,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // ---- state hand-over by the wave that holds the end of the stream's chunk ------------------------------------------------
   if (p.fold_state && 63 * w + nuse == segs) {
     if (lane == nuse) p.yprev_out[stream] = make_float2(ylast.x, ylast.y);
-    for (int k = lane; k < TA - 1; k += 64) p.hist_d_out[(size_t)stream * (TA - 1) + k] = dl[(nuse + 1) * OPL - (TA - 1) + k];
+    for (int k = lane; k < TA - 1; k += 64) p.hist_d_out[(size_t)stream * (TA - 1) + k] = dl[dpos((nuse + 1) * OPL - (TA - 1) + k)];
     for (int k = lane; k < T - 1; k += 64) {
       const int c = (int)p.N - (T - 1) + k;
       p.hist_x_out[(size_t)stream * (T - 1) + k] = load_x(p, stream, c);
@@ -1416,6 +1471,7 @@ struct sdrfm {
   uint32_t dbg_launches;      // launches since the debug counters were last reset
   int fast_mode;              // 0 product; 1..7 timing experiments (libsdrfm_dev.so only)
   uint32_t prio_balance, fold_state_ok;   // design B knobs, fixed at create
+  uint32_t end_prio;                      // design S: see CallParams
   uint32_t stream_profile;                // development build: d_dbg holds per-wave time stamps of design S
   char kernel_name[64];
   char generic_name[64];
@@ -1538,7 +1594,7 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
   h->device = cfg->device;
   h->max_bytes = cfg->max_bytes_per_call ? cfg->max_bytes_per_call : (1u << 20);
   h->zc_off = (cfg->flags & SDRFM_CFG_NO_ZEROCOPY) != 0;
-  h->prio_balance = 1; h->fold_state_ok = 1;
+  h->prio_balance = 1; h->fold_state_ok = 1; h->end_prio = (1u | (1u << 2)) << 6;
   h->max_bytes &= ~1u;
   float* hc = (float*)malloc(sizeof(float) * cfg->fir_taps);
   float* gc = (float*)malloc(sizeof(float) * cfg->audio_taps);
@@ -1591,6 +1647,7 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
     if (const char* e = getenv("SDRFM_FAST_R")) want_r = (uint32_t)atoi(e);
     if (const char* e = getenv("SDRFM_AUDIO_BATCH")) ab_env = (uint32_t)atoi(e);
     if (getenv("SDRFM_NO_PRIO")) h->prio_balance = 0;
+    if (const char* e = getenv("SDRFM_END_PRIO")) h->end_prio = (uint32_t)strtoul(e, nullptr, 0);
     if (getenv("SDRFM_NO_FOLD")) h->fold_state_ok = 0;
 #endif
     for (const FastVariant& v : kFastVariants) {
@@ -1738,6 +1795,7 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
   p.AB = h->AB;
   p.dbg = h->d_dbg;
   p.prio_balance = h->prio_balance;
+  p.end_prio = h->end_prio;
   p.dbg_tag = (h->d_dbg && ++h->dbg_launches == 16) ? 1u : 0u;
   p.warm_ahead = h->warm_ahead;
   // Design B cannot express the zero history at the start of a stream in bytes: until T-1 real samples have been seen its

@@ -24,18 +24,18 @@ lib = pkg.load_library(dev=True)
 lib.sdrfm_dev_read_debug.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32]
 assert lib.sdrfm_dev_read_debug(dm._h, raw, 32 * waves) == 0
 t = np.frombuffer(raw, dtype=np.uint64).reshape(waves, 32).astype(np.int64)
-cyc = t[:, :3 + 2 * (NB - 2) + 3]                 # entry, first lines, first body, (prio, body) x4, last, heads, audio
-names = ["first line wait", "first body"] + [x for b in range(1, NB - 1) for x in ("prio %d" % b, "body %d" % b)] + ["last body", "head pass", "audio stage"]
+cyc = t[:, :3 + 2 * (NB - 2) + 7]                 # entry, first lines, first body, (prio, body) x4, last, heads, audio (5 stamps)
+names = ["first line wait", "first body"] + [x for b in range(1, NB - 1) for x in ("prio %d" % b, "body %d" % b)] + ["last body", "head pass", "audio: d -> LDS", "audio: taps + history", "audio: window reads issued", "audio: chains + results -> LDS", "audio: stores issued"]
 d = np.diff(cyc, axis=1)
 hw = t[:, 29]; xcc = hw & 0xf; hwid = hw >> 32
-simd = (hwid >> 4) & 3; cu = (hwid >> 8) & 0xf; se = (hwid >> 13) & 7; sh = (hwid >> 12) & 1
+slot = hwid & 0xf; simd = (hwid >> 4) & 3; cu = (hwid >> 8) & 0xf; se = (hwid >> 13) & 7; sh = (hwid >> 12) & 1
 rt0, rt1 = t[:, 30], t[:, 31]
 print("kernel:", dm.kernel_name, " waves:", waves)
-print("%-20s %10s %10s %10s %10s" % ("phase", "mean cyc", "p10", "p90", "max"))
+print("%-32s %10s %10s %10s %10s" % ("phase", "mean cyc", "p10", "p90", "max"))
 for i, n in enumerate(names):
-    print("%-20s %10.0f %10.0f %10.0f %10.0f" % (n, d[:, i].mean(), np.percentile(d[:, i], 10), np.percentile(d[:, i], 90), d[:, i].max()))
+    print("%-32s %10.0f %10.0f %10.0f %10.0f" % (n, d[:, i].mean(), np.percentile(d[:, i], 10), np.percentile(d[:, i], 90), d[:, i].max()))
 tot = cyc[:, -1] - cyc[:, 0]
-print("%-20s %10.0f %10.0f %10.0f %10.0f" % ("whole wave", tot.mean(), np.percentile(tot, 10), np.percentile(tot, 90), tot.max()))
+print("%-32s %10.0f %10.0f %10.0f %10.0f" % ("whole wave", tot.mean(), np.percentile(tot, 10), np.percentile(tot, 90), tot.max()))
 dur_us = (rt1 - rt0) / 100.0
 print("wave duration us: mean %.2f p10 %.2f p90 %.2f max %.2f  => shader clock %.3f GHz" % (dur_us.mean(), np.percentile(dur_us, 10), np.percentile(dur_us, 90), dur_us.max(), (tot / dur_us).mean() / 1e3))
 for x in range(8):
@@ -54,3 +54,7 @@ if late.any():
 ks = key * 4 + simd
 per_simd = np.bincount(ks.astype(np.int64)); per_simd = per_simd[per_simd > 0]
 print("waves per SIMD: histogram", np.bincount(per_simd).tolist())
+print("hardware wave slots used: ", dict(zip(*[x.tolist() for x in np.unique(slot, return_counts=True)])))
+for sl in np.unique(slot):
+    m = slot == sl
+    print("slot %d: first line wait mean %.0f, whole wave mean %.0f cycles, end p50 %.2f us" % (sl, d[m, 0].mean(), tot[m].mean(), (np.median(rt1[m]) - rt0.min()) / 100.0))
