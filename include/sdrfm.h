@@ -164,8 +164,9 @@ int  sdrfm_ring_collect(sdrfm_ring_t* r, float* audio, uint32_t audio_cap, uint3
  * audio layout: audio[(stream * 16 + band) * band_stride + j].
  * ------------------------------------------------------------------------------------------------------------------ */
 #define SDRFM_WBFM_BANDS 16
-/* flags for sdrfm_wbfm_config.flags (both are test hooks; results do not depend on them) */
-#define SDRFM_WBFM_CFG_FORCE_GENERIC 1u        /* never run the fused kernel */
+/* flags for sdrfm_wbfm_config.flags (all are test hooks; results do not depend on them) */
+#define SDRFM_WBFM_CFG_FORCE_GENERIC 1u        /* never run a fused kernel */
+#define SDRFM_WBFM_CFG_BRANCH_LANES 2u         /* fused kernel with one lane per polyphase branch instead of one lane per step */
 #define SDRFM_WBFM_CFG_RUN_STEPS_SHIFT 8       /* flags >> 8 = fixed run length (steps) of the fused kernel, 0 = chosen per call */
 
 typedef struct sdrfm_wbfm_config {

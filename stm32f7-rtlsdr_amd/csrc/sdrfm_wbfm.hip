@@ -52,6 +52,8 @@ struct WParams {
   float* dbuf;                  // [ns][NB][dcap]   new discriminator outputs of this call
   const float* p;               // P prototype taps
   const float* g;               // Tg resampler taps
+  const float* pperm;           // step kernel: prototype taps in DFT input order, pperm[16 q + k] = p[bitrev4(k) + 16 q]
+  uint32_t inv_L32;             // step kernel: floor(2^32 / L) + 1
   uint32_t P, Tg, L, M, HD, dcap;
   uint32_t N;                   // new IQ samples per stream
   uint32_t Tn;                  // channelizer steps this call
@@ -488,11 +490,389 @@ __global__ void __launch_bounds__(256) k_wbfm_fused(WParams w) {
 
 }  // namespace
 
+
+// =================================================================================================================
+//  WBFM step kernel: ONE LANE = ONE CHANNELIZER STEP (P = 128, HD <= HDMAX).
+//
+//  A wave owns a run of consecutive steps of one stream and walks it in blocks of 64 steps, lane l = step s0 + l.  Per block
+//    1. every lane converts the 16 new input samples of its step (32 bytes, prefetched one block ahead) and stores them in an LDS
+//       tile as two 16-float planes (re | im) in DFT INPUT ORDER: plane position k holds the sample of branch r = bitrev4(k).
+//       The tile keeps 64 + Q - 1 step groups (the Q - 1 oldest are carried from the previous block): every input byte is
+//       fetched and converted once (the kernel with one lane per branch re-computed ~20 warm-up steps per run);
+//    2. polyphase FIR: for q = Q-1 .. 0 (oldest first, the spec's order) the lane reads the group of step s - q (8 x 16 bytes,
+//       lane stride 144 bytes: conflict-free) and feeds all 16 branches, two per v_pk_fma_f32: accumulator pair k' holds the
+//       branches at DFT positions (2k', 2k'+1), the tap pair comes straight from SGPRs (taps are stored pre-permuted);
+//    3. the 16-point DFT runs in the lane's registers on (position 2k', 2k'+1) pairs: stage m = 2 is an add/sub inside each
+//       pair (its twiddle is (1, 0) and its inputs are FIR outputs, which are never -0: multiplying by (1, 0) is then the
+//       identity, bit for bit), stages 4, 8, 16 are the spec's butterflies on whole pairs with packed twiddle constants —
+//       no cross-lane traffic, no selects;  band pairs (2i, 2i+1) come out as (re, re) / (im, im) register pairs, exactly
+//       the packing the two-at-a-time discriminator wants;
+//    4. c[s-1] comes from the left lane through LDS (the tile is free by then), K3 runs packed on band pairs;
+//    5. the 16 d's of the step go to per-band rows in LDS ([HDMAX history | 64 new]) and the block's audio samples (about
+//       64 L / M per band) are evaluated by lane (band, 4 consecutive samples) from those rows and a [phase][tap] table.
+//  A run that does not start the call warms up HD + 1 steps (the FIR has no memory beyond its window); the last run of a
+//  stream hands the streaming state over.
+// =================================================================================================================
+// scalar (SGPR) load of 16 consecutive floats through a buffer descriptor: wave-uniform taps without spending VGPRs or LDS cycles
+typedef float wf16_t __attribute__((ext_vector_type(16)));
+__device__ wf16_t wbfm_s_buffer_load16(wi4_t rsrc, int offset, int aux) __asm("llvm.amdgcn.s.buffer.load.v16f32");
+
+namespace {
+
+typedef float wf4_t __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(2))) wraw16 { unsigned int w[4]; };
+
+// K3 for all 16 bands of a step, two bands per packed operation, written stage by stage over the 8 band pairs so that the eight
+// dependent chains are interleaved in program order (same roundings as sdrfm_discriminate / watan2_pair)
+__device__ __forceinline__ void wdisc_bands8(const wf2_t (&yr)[8], const wf2_t (&yi)[8], const wf2_t (&pr)[8], const wf2_t (&pi)[8], wf2_t (&d)[8]) {
+  wf2_t re[8], im[8], t[8], s[8], q[8], ax[8], ay[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { re[k] = __builtin_elementwise_fma(yr[k], pr[k], yi[k] * pi[k]); im[k] = yi[k] * pr[k] - yr[k] * pi[k]; }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {                                 // atan2(y = im, x = re)
+    ax[k] = __builtin_elementwise_abs(re[k]); ay[k] = __builtin_elementwise_abs(im[k]);
+    const wf2_t mx = __builtin_elementwise_max(ax[k], ay[k]), mn = __builtin_elementwise_min(ax[k], ay[k]);
+    t[k] = mn * wf2_t{__builtin_amdgcn_rcpf(mx.x), __builtin_amdgcn_rcpf(mx.y)};
+    s[k] = t[k] * t[k];
+    q[k] = wf2_t{0x1.57b128p-9f, 0x1.57b128p-9f};
+  }
+  constexpr float cf[7] = {-0x1.efda1p-7f, 0x1.50dd96p-5f, -0x1.2dbcfap-4f, 0x1.b11b74p-4f, -0x1.228754p-3f, 0x1.99673ep-3f, -0x1.55546cp-2f};
+#pragma unroll
+  for (int c = 0; c < 7; ++c)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) q[k] = __builtin_elementwise_fma(q[k], s[k], wf2_t{cf[c], cf[c]});
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const wf2_t a = __builtin_elementwise_fma(t[k], s[k] * q[k], t[k]);
+    float a0 = a.x, a1 = a.y;
+    if (ay[k].x > ax[k].x) a0 = 0x1.921fb6p+0f - a0;
+    if (ay[k].y > ax[k].y) a1 = 0x1.921fb6p+0f - a1;
+    if (re[k].x < 0.0f) a0 = 0x1.921fb6p+1f - a0;
+    if (re[k].y < 0.0f) a1 = 0x1.921fb6p+1f - a1;
+    a0 = __builtin_copysignf(a0, im[k].x); a1 = __builtin_copysignf(a1, im[k].y);
+    d[k] = wf2_t{(re[k].x == 0.0f && im[k].x == 0.0f) ? 0.0f : a0, (re[k].y == 0.0f && im[k].y == 0.0f) ? 0.0f : a1};
+  }
+}
+
+// value of the lane below (wave_shr:1); lane 0 keeps `keep`
+__device__ __forceinline__ float wshr1(float keep, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, keep), __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, false));
+}
+
+// keeps both the IR passes (memory clobber) and the machine scheduler (sched_barrier) from moving code across: without it
+// every LDS read of a block is hoisted to the top and the kernel spills
+__device__ __forceinline__ void wfence() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// the spec's butterfly on two element pairs at once: (A, B) -> (A + W B, A - W B), W = (wr, wi) per half
+__device__ __forceinline__ void wbfly(wf2_t& ar, wf2_t& ai, wf2_t& br, wf2_t& bi, wf2_t wr, wf2_t wi) {
+  const wf2_t tr = __builtin_elementwise_fma(wr, br, -(wi * bi));
+  const wf2_t ti = __builtin_elementwise_fma(wr, bi, wi * br);
+  br = ar - tr; bi = ai - ti;
+  ar = ar + tr; ai = ai + ti;
+}
+
+template <int Q, int HDMAX>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_wbfm_steps(WParams w) {
+  constexpr int GS = 144;                                       // bytes per step group in the tile: 16 re + 16 im floats + 16 pad
+  constexpr int RING = 72;                                      // tile slots: a ring over the step index (>= 64 + Q - 1)
+  constexpr int DROW = 64 + HDMAX + 2;                          // words per band row: [HDMAX history | 64 new | pad]
+  constexpr int GT = (HDMAX + 3) & ~3;                          // words per phase row of the tap table
+  constexpr int rev[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
+  static_assert(RING >= 64 + Q - 1, "ring");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const xt = smem;                               // RING step groups
+  float* const cslot = reinterpret_cast<float*>(xt + RING * GS);   // c of the step before the block: 16 re | 16 im (| pad)
+  float* const drow = cslot + GS / 4;
+  float* const gT = drow + 16 * DROW;                           // [L][GT]: gT[phi][i] = g[phi + L i], zero beyond Tg / HDMAX
+  const int lane = (int)threadIdx.x;
+  const uint32_t run = blockIdx.x / w.n_streams, stream = blockIdx.x % w.n_streams;
+  const int HD = (int)w.HD, L = (int)w.L;
+  const int ta = (int)(run * w.NT);
+  const bool last_run = run + 1 == w.tiles_per_stream;
+  const int tb = last_run ? (int)w.Tn : ta + (int)w.NT;
+  const int t0 = run == 0 ? 0 : ta - (HD + 1);                  // first step computed: c from t0, d from t0 + 1
+
+  for (int i = lane; i < L * GT; i += 64) {
+    const int phi = i / GT, k = i % GT;
+    gT[i] = (k < HDMAX && (uint32_t)(phi + L * k) < w.Tg) ? w.g[phi + L * k] : 0.0f;
+  }
+  for (int i = lane; i < 16 * DROW; i += 64) drow[i] = 0.0f;
+  if (lane < 32) cslot[lane] = 0.0f;                            // c[t0 - 1]: only d[t0] depends on it, which no audio sample reads
+  __syncthreads();
+  if (run == 0) {                                               // the call's carried state: d history and c[-1]
+    for (int i = lane; i < 16 * HD; i += 64) {
+      const int b = i / HD, k = i % HD;
+      drow[b * DROW + HDMAX - HD + k] = w.hist_d_in[((size_t)stream * NB + b) * HD + k];
+    }
+    if (lane < NB) {
+      const float2 cp = w.cprev_in[(size_t)stream * NB + lane];
+      cslot[lane] = cp.x;
+      cslot[16 + lane] = cp.y;
+    }
+  }
+
+  const uint8_t* const row = w.iq + (size_t)stream * w.iq_stride;
+  const unsigned long long pa = (unsigned long long)w.pperm;
+  const wi4_t prsrc = {(int)(unsigned)pa, (int)(unsigned)(pa >> 32), (int)(4u * w.P), 0x00020000};
+  // ---- input of one step group: fast (all 16 samples inside this call's bytes), zero (beyond them: such steps do not exist),
+  //      or slow (reaches before the call start: carried history, sample by sample)
+  auto group_kind = [&](int step) -> int {
+    const int n_lo = 16 * step - (int)w.phase_x;
+    if (n_lo >= 0 && n_lo + 16 <= (int)w.N) return 0;
+    return n_lo < 0 ? 2 : 1;
+  };
+  auto fetch = [&](int step, wraw16& a, wraw16& b) {
+    const wraw16* gp = reinterpret_cast<const wraw16*>(row + 2 * (size_t)(16 * step - (int)w.phase_x));
+    a = gp[0]; b = gp[1];
+  };
+  auto store_group = [&](int off, const wraw16& a, const wraw16& b) {   // convert + store in DFT input order (off = slot * GS)
+    float re[16], im[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int j = 15 - rev[k];                                // branch r = rev[k] reads sample 15 - r of the group
+      const unsigned int d = (j >> 1) < 4 ? a.w[j >> 1] : b.w[(j >> 1) - 4];
+      re[k] = (float)((d >> (16 * (j & 1))) & 0xffu) - 127.5f;
+      im[k] = (float)((d >> (16 * (j & 1) + 8)) & 0xffu) - 127.5f;
+    }
+    wf4_t* dst = reinterpret_cast<wf4_t*>(xt + off);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      dst[m] = wf4_t{re[4 * m], re[4 * m + 1], re[4 * m + 2], re[4 * m + 3]};
+      dst[4 + m] = wf4_t{im[4 * m], im[4 * m + 1], im[4 * m + 2], im[4 * m + 3]};
+    }
+  };
+  auto store_group_slow = [&](int off, int step, int kind) {
+    float* dst = reinterpret_cast<float*>(xt + off);
+    for (int k = 0; k < 16; ++k) {
+      float2 x = make_float2(0.f, 0.f);
+      if (kind == 2) {
+        const int r = ((k & 1) << 3) | ((k & 2) << 1) | ((k & 4) >> 1) | ((k & 8) >> 3);
+        const int n = 16 * step - (int)w.phase_x + 15 - r;
+        if (n < (int)w.N) x = wload_x(w, stream, n);
+      }
+      dst[k] = x.x; dst[16 + k] = x.y;
+    }
+  };
+
+  wraw16 ra, rb;                                                // raw bytes of this lane's step of the CURRENT block
+  int kind = group_kind(t0 + lane);
+  if (kind == 0) fetch(t0 + lane, ra, rb);
+  // the Q - 1 groups before the first block
+  if (lane < Q - 1) {
+    const int st = t0 - (Q - 1) + lane, kd = group_kind(st);
+    if (kd == 0) { wraw16 ha, hb; fetch(st, ha, hb); store_group(lane * GS, ha, hb); }
+    else store_group_slow(lane * GS, st, kd);
+  }
+  // resampler bookkeeping: call-relative audio index jl has its newest d at call-relative step res_q0 + floor((res_r0 + jl M) / L)
+  auto first_jl = [&](int x) -> int {                           // first jl whose newest d lies at or after step x
+    const int num = (x - w.res_q0) * L - (int)w.res_r0;         // (the host admits this kernel only while these fit 32 bits)
+    if (num <= 0) return 0;
+    const uint32_t jl = ((uint32_t)num + w.M - 1) / w.M;
+    return jl > w.A ? (int)w.A : (int)jl;
+  };
+  int jl_lo = first_jl(ta);
+
+  wf2_t cr[8], ci[8];
+  int s0_last = t0;
+  int ring0 = Q - 1;                                            // ring slot of lane 0's step (the Q - 1 older groups sit below it)
+  for (int s0 = t0; s0 < tb; s0 += 64) {
+    s0_last = s0;
+    const int s = s0 + lane;
+    if (s0 != t0) {                                             // d history: the last HDMAX columns become columns 0 .. HDMAX-1
+      for (int i = lane; i < 16 * HDMAX; i += 64) {
+        const int b = i / HDMAX, k = i % HDMAX;
+        drow[b * DROW + k] = drow[b * DROW + 64 + k];
+      }
+    }
+    int tap0 = 0;                                               // (opaque zero: keeps the tap loads inside the block loop)
+    asm volatile("" : "+s"(tap0));
+    wf16_t th[4];                                               // taps of q = Q-1 .. Q-4 (SGPRs); the other half follows when these are spent
+#pragma unroll
+    for (int j = 0; j < 4; ++j) th[j] = wbfm_s_buffer_load16(prsrc, tap0 + 64 * (Q - 1 - j), 0);
+    // ---- 1. this block's samples -> tile; prefetch the next block's
+    int off0 = (ring0 + lane) * GS;                             // byte offset of this lane's group in the ring
+    if (off0 >= RING * GS) off0 -= RING * GS;
+    if (kind == 0) store_group(off0, ra, rb);
+    else store_group_slow(off0, s, kind);
+    wfence();
+    kind = group_kind(s + 64);
+    if (kind == 0 && s0 + 64 < tb) fetch(s + 64, ra, rb);
+    __syncthreads();
+    wfence();
+
+    // ---- 2. polyphase FIR, oldest tap first
+    wf2_t ar[8], ai[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { ar[k] = wf2_t{0.f, 0.f}; ai[k] = wf2_t{0.f, 0.f}; }
+    // software-pipelined: the group of q - 1 is read while q is accumulated (LDS returns in order, so the waits are exact); the
+    // fence after each q keeps the scheduler from issuing all 64 reads at once (256 VGPRs)
+    auto group_of = [&](int q) -> const wf4_t* {                // the group of step s - q
+      int o = off0 - q * GS;
+      if (o < 0) o += RING * GS;
+      return reinterpret_cast<const wf4_t*>(xt + o);
+    };
+    wf4_t xr[4], xi[4];
+    {
+      const wf4_t* gp = group_of(Q - 1);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) { xr[m] = gp[m]; xi[m] = gp[4 + m]; }
+    }
+    wf16_t tl[4];
+#pragma unroll
+    for (int q = Q - 1; q >= 0; --q) {
+      wf4_t nxr[4], nxi[4];
+      if (q > 0) {
+        const wf4_t* gp = group_of(q - 1);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { nxr[m] = gp[m]; nxi[m] = gp[4 + m]; }
+      } else {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { nxr[m] = xr[m]; nxi[m] = xi[m]; }
+      }
+      const wf16_t tq = q >= 4 ? th[Q - 1 - q] : tl[3 - q];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const wf2_t t0p = wf2_t{tq[4 * m], tq[4 * m + 1]}, t1p = wf2_t{tq[4 * m + 2], tq[4 * m + 3]};
+        ar[2 * m] = __builtin_elementwise_fma(t0p, wf2_t{xr[m].x, xr[m].y}, ar[2 * m]);
+        ar[2 * m + 1] = __builtin_elementwise_fma(t1p, wf2_t{xr[m].z, xr[m].w}, ar[2 * m + 1]);
+        ai[2 * m] = __builtin_elementwise_fma(t0p, wf2_t{xi[m].x, xi[m].y}, ai[2 * m]);
+        ai[2 * m + 1] = __builtin_elementwise_fma(t1p, wf2_t{xi[m].z, xi[m].w}, ai[2 * m + 1]);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { asm volatile("" : "+v"(ar[k])); asm volatile("" : "+v"(ai[k])); }   // pins this q's FMAs before the fence
+      wfence();
+      if (q == 4) {                                             // first half of the taps spent: fetch the second half into the same SGPRs
+        int tap1 = 0;
+        asm volatile("" : "+s"(tap1));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tl[j] = wbfm_s_buffer_load16(prsrc, tap1 + 64 * (3 - j), 0);
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) { xr[m] = nxr[m]; xi[m] = nxi[m]; }
+    }
+    wfence();
+    // ---- 3. 16-point DFT on position pairs (2k', 2k'+1)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {                               // stage m = 2: partner inside the pair, W = (1, 0)
+      ar[k] = wf2_t{ar[k].x + ar[k].y, ar[k].x - ar[k].y};
+      ai[k] = wf2_t{ai[k].x + ai[k].y, ai[k].x - ai[k].y};
+    }
+#pragma unroll
+    for (int g = 0; g < 8; g += 2)                              // stage m = 4: positions (g0, g0+1) with (g0+2, g0+3), W = (W0, W4)
+      wbfly(ar[g], ai[g], ar[g + 1], ai[g + 1], wf2_t{1.0f, 0.0f}, wf2_t{0.0f, 1.0f});
+#pragma unroll
+    for (int g = 0; g < 8; g += 4) {                            // stage m = 8: W = (W0, W2), (W4, W6)
+      wbfly(ar[g], ai[g], ar[g + 2], ai[g + 2], wf2_t{1.0f, 0x1.6a09e6p-1f}, wf2_t{0.0f, 0x1.6a09e6p-1f});
+      wbfly(ar[g + 1], ai[g + 1], ar[g + 3], ai[g + 3], wf2_t{0.0f, -0x1.6a09e6p-1f}, wf2_t{1.0f, 0x1.6a09e6p-1f});
+    }
+    // stage m = 16: W = (W0, W1), (W2, W3), (W4, W5), (W6, W7)
+    wbfly(ar[0], ai[0], ar[4], ai[4], wf2_t{1.0f, 0x1.d906bcp-1f}, wf2_t{0.0f, 0x1.87de2ap-2f});
+    wbfly(ar[1], ai[1], ar[5], ai[5], wf2_t{0x1.6a09e6p-1f, 0x1.87de2ap-2f}, wf2_t{0x1.6a09e6p-1f, 0x1.d906bcp-1f});
+    wbfly(ar[2], ai[2], ar[6], ai[6], wf2_t{0.0f, -0x1.87de2ap-2f}, wf2_t{1.0f, 0x1.d906bcp-1f});
+    wbfly(ar[3], ai[3], ar[7], ai[7], wf2_t{-0x1.6a09e6p-1f, -0x1.d906bcp-1f}, wf2_t{0x1.6a09e6p-1f, 0x1.87de2ap-2f});
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { cr[k] = ar[k]; ci[k] = ai[k]; }   // band pair k = (2k, 2k+1)
+
+    // ---- 4. c[s-1] from the left lane: one DPP move per component (wave_shr:1); lane 0 keeps the value handed over in LDS by
+    //         lane 63 of the previous block (or the call's carried state / zeros)
+    float dn[16];
+    {
+      const wf4_t* hand = reinterpret_cast<const wf4_t*>(cslot);
+      wf2_t pr[8], pi[8];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const wf4_t a = hand[m], b = hand[4 + m];
+        pr[2 * m] = wf2_t{wshr1(a.x, cr[2 * m].x), wshr1(a.y, cr[2 * m].y)};
+        pr[2 * m + 1] = wf2_t{wshr1(a.z, cr[2 * m + 1].x), wshr1(a.w, cr[2 * m + 1].y)};
+        pi[2 * m] = wf2_t{wshr1(b.x, ci[2 * m].x), wshr1(b.y, ci[2 * m].y)};
+        pi[2 * m + 1] = wf2_t{wshr1(b.z, ci[2 * m + 1].x), wshr1(b.w, ci[2 * m + 1].y)};
+      }
+      wf2_t d8[8];
+      wdisc_bands8(cr, ci, pr, pi, d8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { dn[2 * k] = d8[k].x; dn[2 * k + 1] = d8[k].y; }
+    }
+    wfence();
+    if (lane == 63) {                                           // for the next block: this block's last c
+      wf4_t* z = reinterpret_cast<wf4_t*>(cslot);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        z[m] = wf4_t{cr[2 * m].x, cr[2 * m].y, cr[2 * m + 1].x, cr[2 * m + 1].y};
+        z[4 + m] = wf4_t{ci[2 * m].x, ci[2 * m].y, ci[2 * m + 1].x, ci[2 * m + 1].y};
+      }
+    }
+    // ---- 5. d rows and the block's audio samples
+#pragma unroll
+    for (int b = 0; b < 16; ++b) drow[b * DROW + HDMAX + lane] = dn[b];
+    __syncthreads();
+    const int hi = s0 + 64 < tb ? s0 + 64 : tb;
+    const int jl_hi = first_jl(hi);
+    {
+      const int b = lane >> 2;
+      const float* const myrow = drow + b * DROW + HDMAX - s0;   // myrow[n] = d_b[n] (call-relative step n)
+      float* const aout = w.audio + ((size_t)stream * NB + b) * w.band_stride;
+      for (int base = jl_lo; base < jl_hi; base += 16) {
+        const float* dp[4];
+        float gt[4][GT], a[4];
+        bool ok[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int jl = base + 4 * (lane & 3) + i;
+          const uint32_t loc = w.res_r0 + (uint32_t)jl * w.M;
+          const uint32_t qq = __umulhi(loc, w.inv_L32);
+          const int nrel = w.res_q0 + (int)qq;
+          const uint32_t phi = loc - qq * (uint32_t)L;
+          ok[i] = jl < jl_hi;
+          dp[i] = myrow + (ok[i] ? nrel : s0);                   // (inactive lanes read inside the row)
+          const wf4_t* tp = reinterpret_cast<const wf4_t*>(gT + (ok[i] ? phi : 0u) * GT);
+#pragma unroll
+          for (int m = 0; m < GT / 4; ++m) { const wf4_t t4 = tp[m]; gt[i][4 * m] = t4.x; gt[i][4 * m + 1] = t4.y; gt[i][4 * m + 2] = t4.z; gt[i][4 * m + 3] = t4.w; }
+          a[i] = 0.0f;
+        }
+#pragma unroll
+        for (int k = HDMAX - 1; k >= 0; --k)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) a[i] = __builtin_fmaf(gt[i][k], dp[i][-k], a[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (ok[i]) aout[base + 4 * (lane & 3) + i] = a[i];
+      }
+    }
+    jl_lo = jl_hi;
+    ring0 += 64;
+    if (ring0 >= RING) ring0 -= RING;
+    __syncthreads();
+  }
+
+  // ---- state hand-over by the last run of the stream ----------------------------------------------------------------
+  if (last_run) {
+    const int sl = (int)w.Tn - 1 - s0_last;                      // lane of the call's last step in the last block
+    if (lane == sl) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        w.cprev_out[(size_t)stream * NB + 2 * k] = make_float2(cr[k].x, ci[k].x);
+        w.cprev_out[(size_t)stream * NB + 2 * k + 1] = make_float2(cr[k].y, ci[k].y);
+      }
+    }
+    for (int i = lane; i < 16 * HD; i += 64) {
+      const int b = i / HD, k = i % HD;
+      w.hist_d_out[((size_t)stream * NB + b) * HD + k] = drow[b * DROW + HDMAX + ((int)w.Tn - s0_last) - HD + k];
+    }
+    for (uint32_t i = (uint32_t)lane; i + 1 < w.P; i += 64)
+      w.hist_x_out[(size_t)stream * (w.P - 1) + i] = wload_x(w, stream, (int)w.N - (int)(w.P - 1) + (int)i);
+  }
+}
+
+}  // namespace
+
 struct sdrfm_wbfm {
   sdrfm_wbfm_config cfg;
   int device;
   hipStream_t own_stream, stream;
-  float *d_p, *d_g;
+  float *d_p, *d_g, *d_pperm;
   float2* d_hist_x[2];
   float2* d_cprev[2];
   float* d_hist_d[2];
@@ -505,7 +885,8 @@ struct sdrfm_wbfm {
   float* d_audio; size_t d_band_stride;
   uint32_t max_bytes, NT;
   size_t lds_bytes;
-  bool fused_ok;          // P = 128, HD <= 10: the fused kernel applies
+  bool fused_ok;          // P = 128, HD <= 10: the one-lane-per-branch fused kernel applies
+  bool steps_ok;          // ... and L >= 2: the one-lane-per-step kernel applies (preferred)
   uint32_t n_cu;          // compute units (fused kernel: run-length choice)
   uint32_t force_nt;      // SDRFM_WBFM_CFG_RUN_STEPS: fixed run length (tests)
   char kernel_name[48];
@@ -523,7 +904,7 @@ struct sdrfm_wbfm {
 static void wfree(sdrfm_wbfm* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
-  void* ptrs[] = {h->d_p, h->d_g, h->d_hist_x[0], h->d_hist_x[1], h->d_cprev[0], h->d_cprev[1], h->d_hist_d[0], h->d_hist_d[1],
+  void* ptrs[] = {h->d_p, h->d_g, h->d_pperm, h->d_hist_x[0], h->d_hist_x[1], h->d_cprev[0], h->d_cprev[1], h->d_hist_d[0], h->d_hist_d[1],
                   h->d_dbuf, h->d_iq, h->d_audio};
   for (void* q : ptrs) if (q) (void)hipFree(q);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -547,7 +928,7 @@ extern "C" {
 int sdrfm_wbfm_create(const sdrfm_wbfm_config* cfg, sdrfm_wbfm_t** out) {
   if (!out) return SDRFM_EINVAL;
   *out = nullptr;
-  if (!cfg || cfg->struct_size != sizeof(sdrfm_wbfm_config) || (cfg->flags & 0xfeu)) return SDRFM_EINVAL;
+  if (!cfg || cfg->struct_size != sizeof(sdrfm_wbfm_config) || (cfg->flags & 0xfcu)) return SDRFM_EINVAL;
   if (!cfg->n_streams || !cfg->proto_coeffs || !cfg->resamp_coeffs) return SDRFM_EINVAL;
   if (!cfg->proto_taps || cfg->proto_taps % NB || cfg->proto_taps > 512) return SDRFM_EINVAL;
   if (!cfg->resamp_taps || cfg->resamp_taps > 512 || !cfg->resamp_up || !cfg->resamp_down || cfg->resamp_up > 64 ||
@@ -579,6 +960,7 @@ int sdrfm_wbfm_create(const sdrfm_wbfm_config* cfg, sdrfm_wbfm_t** out) {
   h->stream = h->own_stream;
   CR(hipMalloc(&h->d_p, 4 * P));
   CR(hipMalloc(&h->d_g, 4 * cfg->resamp_taps));
+  CR(hipMalloc(&h->d_pperm, 4 * P));
   for (int i = 0; i < 2; ++i) {
     CR(hipMalloc(&h->d_hist_x[i], sizeof(float2) * ns * (P - 1)));
     CR(hipMalloc(&h->d_cprev[i], sizeof(float2) * ns * NB));
@@ -587,6 +969,19 @@ int sdrfm_wbfm_create(const sdrfm_wbfm_config* cfg, sdrfm_wbfm_t** out) {
   CR(hipMalloc(&h->d_dbuf, sizeof(float) * ns * NB * h->dcap));
   CR(hipMemcpy(h->d_p, pc, 4 * P, hipMemcpyHostToDevice));
   CR(hipMemcpy(h->d_g, gc, 4 * cfg->resamp_taps, hipMemcpyHostToDevice));
+  {
+    // taps in DFT input order for the step kernel: pperm[16 q + k] = p[bitrev4(k) + 16 q]
+    float* pp = (float*)malloc(4 * P);
+    if (!pp) { wfree(h); return SDRFM_ENOMEM; }
+    for (size_t q = 0; q < P / NB; ++q)
+      for (int k = 0; k < NB; ++k) {
+        const int r = ((k & 1) << 3) | ((k & 2) << 1) | ((k & 4) >> 1) | ((k & 8) >> 3);
+        pp[NB * q + k] = pc[r + NB * q];
+      }
+    const hipError_t e = hipMemcpy(h->d_pperm, pp, 4 * P, hipMemcpyHostToDevice);
+    free(pp);
+    CR(e);
+  }
 #undef CR
   h->NT = 64;
   h->lds_bytes = ((size_t)(h->NT + 1) * NB + P) * 8 + (size_t)(h->NT + 1) * NB * 8 + P * 4;
@@ -596,9 +991,10 @@ int sdrfm_wbfm_create(const sdrfm_wbfm_config* cfg, sdrfm_wbfm_t** out) {
     return SDRFM_NOT_SUPPORTED;
   }
   h->fused_ok = (cfg->proto_taps == 128 && h->HD <= 10 && cfg->resamp_up * 10u <= 512u && !(cfg->flags & SDRFM_WBFM_CFG_FORCE_GENERIC));
+  h->steps_ok = h->fused_ok && cfg->resamp_up >= 2 && !(cfg->flags & SDRFM_WBFM_CFG_BRANCH_LANES);
   h->n_cu = (uint32_t)prop.multiProcessorCount;
   h->force_nt = (cfg->flags >> SDRFM_WBFM_CFG_RUN_STEPS_SHIFT) & ~1u;   // test hook: fixed run length of the fused kernel (0 = chosen per call)
-  snprintf(h->kernel_name, sizeof(h->kernel_name), "%s", h->fused_ok ? "wbfm-fused (k_wbfm_fused<8,10>)" : "wbfm-generic (k_wbfm_chan + k_wbfm_res)");
+  snprintf(h->kernel_name, sizeof(h->kernel_name), "%s", h->steps_ok ? "wbfm-fused (k_wbfm_steps<8,10>)" : h->fused_ok ? "wbfm-fused (k_wbfm_fused<8,10>)" : "wbfm-generic (k_wbfm_chan + k_wbfm_res)");
   const int rc = sdrfm_wbfm_reset(h);
   if (rc != SDRFM_OK) { wfree(h); return rc; }
   *out = h;
@@ -662,13 +1058,32 @@ static int wenqueue(sdrfm_wbfm* h, const uint8_t* d_iq, size_t iq_stride, uint32
   w.hist_x_in = h->d_hist_x[h->cur]; w.hist_x_out = h->d_hist_x[h->cur ^ 1];
   w.cprev_in = h->d_cprev[h->cur]; w.cprev_out = h->d_cprev[h->cur ^ 1];
   w.hist_d_in = h->d_hist_d[h->cur]; w.hist_d_out = h->d_hist_d[h->cur ^ 1];
-  w.dbuf = h->d_dbuf; w.p = h->d_p; w.g = h->d_g;
+  w.dbuf = h->d_dbuf; w.p = h->d_p; w.g = h->d_g; w.pperm = h->d_pperm;
+  w.inv_L32 = c.resamp_up >= 2 ? (uint32_t)((1ull << 32) / c.resamp_up) + 1u : 0u;
   w.P = c.proto_taps; w.Tg = c.resamp_taps; w.L = c.resamp_up; w.M = c.resamp_down; w.HD = h->HD; w.dcap = h->dcap;
   w.N = N; w.Tn = Tn; w.A = A; w.phase_x = h->phase_x; w.n_d = h->n_d; w.n_a = h->n_a;
   w.res_q0 = (int)((long long)((h->n_a * c.resamp_down) / c.resamp_up) - (long long)h->n_d);
   w.res_r0 = (uint32_t)((h->n_a * c.resamp_down) % c.resamp_up);
   const uint64_t span = (uint64_t)(c.n_streams - 1) * iq_stride + nbytes;
   w.iq_span = (uint32_t)span;
+  if (h->steps_ok && Tn >= 64 && ((uint64_t)A + 16) * c.resamp_down + c.resamp_up < (1ull << 26) && ((uint64_t)Tn + 64) * c.resamp_up < (1ull << 31)) {
+    // step kernel: one wave per run of NT steps of one stream; a run that does not start the call re-computes HD + 1 steps.
+    // One round of two waves per SIMD (8 waves per CU) when the streams allow it, runs of at least 128 steps.
+    uint64_t runs = (8ull * h->n_cu + c.n_streams - 1) / c.n_streams;
+    if (runs > Tn / 128) runs = Tn / 128;
+    if (runs < 1) runs = 1;
+    w.NT = (uint32_t)((Tn + runs - 1) / runs);
+    if (h->force_nt) w.NT = h->force_nt;
+    w.tiles_per_stream = (Tn + w.NT - 1) / w.NT;
+    w.n_streams = c.n_streams;
+    const size_t lds = (size_t)72 * 144 + 144 + 16 * (64 + 10 + 2) * 4 + (size_t)c.resamp_up * 12 * 4;   // ring tile, c slot, d rows, tap table
+    hipLaunchKernelGGL((k_wbfm_steps<8, 10>), dim3(c.n_streams * w.tiles_per_stream), dim3(64), lds, h->stream, w);
+    WTRY(hipGetLastError(), SDRFM_FAIL);
+    h->cur ^= 1;
+    h->phase_x = (uint32_t)((h->phase_x + (uint64_t)N) % NB);
+    h->n_d += Tn; h->n_a += A;
+    return SDRFM_OK;
+  }
   if (h->fused_ok && Tn >= 64 && span < (1ull << 32)) {
     // fused kernel: every stream is cut into runs of NT steps (even: steps are processed in pairs); one 16-lane group per
     // run, the 4 groups of a wave = the same run of 4 neighbouring streams, 4 waves per block.  Every run re-computes ~20 warm-up

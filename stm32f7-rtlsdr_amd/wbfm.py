@@ -20,6 +20,7 @@ class WbfmConfig:
     device: int = 0
     force_generic: bool = False       # SDRFM_WBFM_CFG_FORCE_GENERIC (tests): never run the fused kernel
     run_steps: int = 0                # SDRFM_WBFM_CFG_RUN_STEPS (tests): fixed run length of the fused kernel, 0 = per call
+    branch_lanes: bool = False        # SDRFM_WBFM_CFG_BRANCH_LANES (tests): the one-lane-per-branch fused kernel instead of one lane per step
 
 
 class WbfmDemod:
@@ -35,7 +36,7 @@ class WbfmDemod:
         c.resamp_taps, c.resamp_coeffs = g.size, g.ctypes.data_as(C.POINTER(C.c_float))
         c.resamp_up, c.resamp_down = cfg.resamp_up, cfg.resamp_down
         c.max_bytes_per_call, c.device = cfg.max_bytes_per_call, cfg.device
-        c.flags = (1 if cfg.force_generic else 0) | (int(cfg.run_steps) << 8)
+        c.flags = (1 if cfg.force_generic else 0) | (2 if cfg.branch_lanes else 0) | (int(cfg.run_steps) << 8)
         self._h = C.c_void_p()
         st = self._lib.sdrfm_wbfm_create(C.byref(c), C.byref(self._h))
         if st != _l.OK:

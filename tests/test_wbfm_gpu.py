@@ -142,19 +142,22 @@ def test_fused_kernel_bitwise_equals_generic_kernels(pkg, n_streams, nsamp):
     chains: identical bits, for stream counts that do and do not fill a wave's 4 groups and an odd number of steps."""
     iq = pkg.make_iq(n_streams, nsamp, mode="fm", fs=3.2e6, first_id=70)
     nf, fused = _run(pkg, iq, n_streams)
+    nb, branch = _run(pkg, iq, n_streams, branch_lanes=True)
     ng, generic = _run(pkg, iq, n_streams, force_generic=True)
-    assert nf.startswith("wbfm-fused") and ng.startswith("wbfm-generic")
+    assert "k_wbfm_steps" in nf and "k_wbfm_fused" in nb and ng.startswith("wbfm-generic")
     assert np.array_equal(fused.view(np.uint32), generic.view(np.uint32))
+    assert np.array_equal(branch.view(np.uint32), generic.view(np.uint32))
 
 
 def test_fused_kernel_output_independent_of_run_length(pkg):
     iq = pkg.make_iq(4, 64000, mode="random", fs=3.2e6, first_id=80)
     ref = None
-    for nt in (64, 66, 130, 1000, 8000):
-        _, out = _run(pkg, iq, 4, run_steps=nt)
-        if ref is None:
-            ref = out
-        assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), nt
+    for branch_lanes in (False, True):
+        for nt in (64, 66, 130, 1000, 8000):
+            _, out = _run(pkg, iq, 4, run_steps=nt, branch_lanes=branch_lanes)
+            if ref is None:
+                ref = out
+            assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), (branch_lanes, nt)
 
 
 def test_degenerate_inputs_match_oracle_exactly_in_sign(pkg, oracle_mod):
@@ -164,11 +167,11 @@ def test_degenerate_inputs_match_oracle_exactly_in_sign(pkg, oracle_mod):
     n = 20000
     rows = [np.full(2 * n, 128, np.uint8), np.tile(np.array([255, 0], np.uint8), n), np.tile(np.array([127, 128, 128, 127], np.uint8), n // 2)]
     iq = np.stack(rows)
-    for force_generic in (False, True):
-        _, got = _run(pkg, iq, 3, force_generic=force_generic)
+    for flags in ({}, {"branch_lanes": True}, {"force_generic": True}):
+        _, got = _run(pkg, iq, 3, **flags)
         for s in range(3):
             want = oracle_mod.WbfmOracle(p, g).process(iq[s])
-            _check_all(got[s], want, "generic=%s stream %d" % (force_generic, s))
+            _check_all(got[s], want, "%s stream %d" % (flags, s))
 
 
 def test_golden_vector_on_gpu(pkg):

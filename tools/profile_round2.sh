@@ -30,7 +30,7 @@ for wl in $WLS; do case $wl in
   fm256)     run_wl fm256 k_stream ;;
   fm512)     run_wl fm512 k_stream --streams-per-gpu 512 ;;
   fm256_T16) run_wl fm256_T16 k_fastb --fir-taps 16 ;;
-  wbfm)      run_wl wbfm k_wbfm_fused --workload wbfm ;;
+  wbfm)      run_wl wbfm k_wbfm_ --workload wbfm ;;
   spectrum)  run_wl spectrum k_spectrum --workload spectrum ;;
 esac; done
 ls -la "$OUT"
