@@ -577,11 +577,13 @@ __device__ __forceinline__ void wbfly(wf2_t& ar, wf2_t& ai, wf2_t& br, wf2_t& bi
 template <int Q, int HDMAX>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_wbfm_steps(WParams w) {
   constexpr int GS = 144;                                       // bytes per step group in the tile: 16 re + 16 im floats + 16 pad
-  constexpr int RING = 72;                                      // tile slots: a ring over the step index (>= 64 + Q - 1)
-  constexpr int DROW = 64 + HDMAX + 2;                          // words per band row: [HDMAX history | 64 new | pad]
+  constexpr int RING = 80;                                      // tile slots: a ring over the step index (>= 64 + Q - 1; a multiple of 16
+                                                                // keeps a lane group's 16 slots on 16 different bank quads across the wrap)
+  constexpr int DRING = 96;                                     // d columns per band: a ring over the step index (>= 64 + HDMAX)
+  constexpr int DROW = HDMAX + DRING + 2;                       // words per band row: [mirror of the last HDMAX columns | DRING columns | pad]
   constexpr int GT = (HDMAX + 3) & ~3;                          // words per phase row of the tap table
   constexpr int rev[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
-  static_assert(RING >= 64 + Q - 1, "ring");
+  static_assert(RING >= 64 + Q - 1 && DRING >= 64 + HDMAX, "rings");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const xt = smem;                               // RING step groups
   float* const cslot = reinterpret_cast<float*>(xt + RING * GS);   // c of the step before the block: 16 re | 16 im (| pad)
@@ -599,7 +601,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int phi = i / GT, k = i % GT;
     gT[i] = (k < HDMAX && (uint32_t)(phi + L * k) < w.Tg) ? w.g[phi + L * k] : 0.0f;
   }
-  for (int i = lane; i < 16 * DROW; i += 64) drow[i] = 0.0f;
+  for (int i = lane; i < 16 * HDMAX; i += 64) drow[(i / HDMAX) * DROW + i % HDMAX] = 0.0f;   // columns -HDMAX .. -1: the d's before the run (zero taps
+                                                                                            // may meet them: no NaN bit patterns)
   if (lane < 32) cslot[lane] = 0.0f;                            // c[t0 - 1]: only d[t0] depends on it, which no audio sample reads
   __syncthreads();
   if (run == 0) {                                               // the call's carried state: d history and c[-1]
@@ -660,7 +663,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   wraw16 ra, rb;                                                // raw bytes of this lane's step of the CURRENT block
   int kind = group_kind(t0 + lane);
   if (kind == 0) fetch(t0 + lane, ra, rb);
-  // the Q - 1 groups before the first block
+  // the first block's groups and the Q - 1 groups before it -> tile; prefetch the second block
+  if (kind == 0) store_group((Q - 1 + lane) * GS, ra, rb);
+  else store_group_slow((Q - 1 + lane) * GS, t0 + lane, kind);
+  kind = group_kind(t0 + 64 + lane);
+  if (kind == 0 && t0 + 64 < tb) fetch(t0 + 64 + lane, ra, rb);
   if (lane < Q - 1) {
     const int st = t0 - (Q - 1) + lane, kd = group_kind(st);
     if (kd == 0) { wraw16 ha, hb; fetch(st, ha, hb); store_group(lane * GS, ha, hb); }
@@ -677,69 +684,93 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
   wf2_t cr[8], ci[8];
   int s0_last = t0;
+  // The audio samples of a block are evaluated one block later: their LDS reads (taps by phase, d windows) are issued before the
+  // next block's DFT and consumed after it, so their latency hides behind arithmetic instead of standing between a write and a
+  // read of the same rows.  Lane (band b = lane / 4, quarter o = lane % 4) evaluates up to 4 consecutive samples.
+  int dcb = 0;                                                  // d ring column of lane 0's step in the current block
+  int p_s0 = 0, p_dcb = 0, p_lo = 0, p_hi = 0;                  // previous block: first step, its column, audio range [p_lo, p_hi)
+  float rgt[4][GT], rdv[4][HDMAX];
+  bool rok[4];
+  float* const aout = w.audio + ((size_t)stream * NB + (lane >> 2)) * w.band_stride;
+  auto resample_issue = [&]() {
+    const float* const myrow = drow + (lane >> 2) * DROW + HDMAX;      // myrow[c] = column c, c in [-HDMAX, DRING)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int jl = p_lo + 4 * (lane & 3) + i;
+      const uint32_t loc = w.res_r0 + (uint32_t)jl * w.M;
+      const uint32_t qq = __umulhi(loc, w.inv_L32);
+      const int nrel = w.res_q0 + (int)qq;                        // call-relative step of the sample's newest d
+      const uint32_t phi = loc - qq * (uint32_t)L;
+      rok[i] = jl < p_hi;
+      int c = p_dcb + (nrel - p_s0);
+      if (c >= DRING) c -= DRING;
+      const float* dp = myrow + (rok[i] ? c : 0);                 // (inactive lanes read inside the row)
+      const wf4_t* tp = reinterpret_cast<const wf4_t*>(gT + (rok[i] ? phi : 0u) * GT);
+#pragma unroll
+      for (int m = 0; m < GT / 4; ++m) { const wf4_t t4 = tp[m]; rgt[i][4 * m] = t4.x; rgt[i][4 * m + 1] = t4.y; rgt[i][4 * m + 2] = t4.z; rgt[i][4 * m + 3] = t4.w; }
+#pragma unroll
+      for (int k = 0; k < HDMAX; ++k) rdv[i][k] = dp[-k];
+    }
+  };
+  auto resample_finish = [&]() {
+    float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int k = HDMAX - 1; k >= 0; --k)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = __builtin_fmaf(rgt[i][k], rdv[i][k], a[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (rok[i]) aout[p_lo + 4 * (lane & 3) + i] = a[i];
+  };
   int ring0 = Q - 1;                                            // ring slot of lane 0's step (the Q - 1 older groups sit below it)
   for (int s0 = t0; s0 < tb; s0 += 64) {
     s0_last = s0;
     const int s = s0 + lane;
-    if (s0 != t0) {                                             // d history: the last HDMAX columns become columns 0 .. HDMAX-1
-      for (int i = lane; i < 16 * HDMAX; i += 64) {
-        const int b = i / HDMAX, k = i % HDMAX;
-        drow[b * DROW + k] = drow[b * DROW + 64 + k];
-      }
-    }
     int tap0 = 0;                                               // (opaque zero: keeps the tap loads inside the block loop)
     asm volatile("" : "+s"(tap0));
     wf16_t th[4];                                               // taps of q = Q-1 .. Q-4 (SGPRs); the other half follows when these are spent
 #pragma unroll
     for (int j = 0; j < 4; ++j) th[j] = wbfm_s_buffer_load16(prsrc, tap0 + 64 * (Q - 1 - j), 0);
-    // ---- 1. this block's samples -> tile; prefetch the next block's
-    int off0 = (ring0 + lane) * GS;                             // byte offset of this lane's group in the ring
-    if (off0 >= RING * GS) off0 -= RING * GS;
-    if (kind == 0) store_group(off0, ra, rb);
-    else store_group_slow(off0, s, kind);
-    wfence();
-    kind = group_kind(s + 64);
-    if (kind == 0 && s0 + 64 < tb) fetch(s + 64, ra, rb);
-    __syncthreads();
+    int off0 = (ring0 + lane) * GS;                             // byte offset of this lane's group in the ring (stored by the previous
+    if (off0 >= RING * GS) off0 -= RING * GS;                   // iteration / the prologue)
     wfence();
 
     // ---- 2. polyphase FIR, oldest tap first
     wf2_t ar[8], ai[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { ar[k] = wf2_t{0.f, 0.f}; ai[k] = wf2_t{0.f, 0.f}; }
-    // software-pipelined: the group of q - 1 is read while q is accumulated (LDS returns in order, so the waits are exact); the
-    // fence after each q keeps the scheduler from issuing all 64 reads at once (256 VGPRs)
+    // software-pipelined: DEPTH groups are in flight while one is accumulated (the LDS serves eight waves, a read waits in its
+    // queue for hundreds of cycles; LDS returns in order, so the waits are exact); the fence after each q keeps the scheduler
+    // from issuing all 64 reads at once (256 VGPRs)
     auto group_of = [&](int q) -> const wf4_t* {                // the group of step s - q
       int o = off0 - q * GS;
       if (o < 0) o += RING * GS;
       return reinterpret_cast<const wf4_t*>(xt + o);
     };
-    wf4_t xr[4], xi[4];
-    {
-      const wf4_t* gp = group_of(Q - 1);
+    constexpr int DEPTH = 3;                                    // groups in flight ahead of the one being accumulated
+    wf4_t xr[DEPTH + 1][4], xi[DEPTH + 1][4];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) { xr[m] = gp[m]; xi[m] = gp[4 + m]; }
+    for (int d = 0; d < DEPTH; ++d) {
+      const wf4_t* gp = group_of(Q - 1 - d);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) { xr[d][m] = gp[m]; xi[d][m] = gp[4 + m]; }
     }
     wf16_t tl[4];
 #pragma unroll
     for (int q = Q - 1; q >= 0; --q) {
-      wf4_t nxr[4], nxi[4];
-      if (q > 0) {
-        const wf4_t* gp = group_of(q - 1);
+      if (q - DEPTH >= 0) {
+        const wf4_t* gp = group_of(q - DEPTH);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) { nxr[m] = gp[m]; nxi[m] = gp[4 + m]; }
-      } else {
-#pragma unroll
-        for (int m = 0; m < 4; ++m) { nxr[m] = xr[m]; nxi[m] = xi[m]; }
+        for (int m = 0; m < 4; ++m) { xr[DEPTH][m] = gp[m]; xi[DEPTH][m] = gp[4 + m]; }
       }
       const wf16_t tq = q >= 4 ? th[Q - 1 - q] : tl[3 - q];
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const wf2_t t0p = wf2_t{tq[4 * m], tq[4 * m + 1]}, t1p = wf2_t{tq[4 * m + 2], tq[4 * m + 3]};
-        ar[2 * m] = __builtin_elementwise_fma(t0p, wf2_t{xr[m].x, xr[m].y}, ar[2 * m]);
-        ar[2 * m + 1] = __builtin_elementwise_fma(t1p, wf2_t{xr[m].z, xr[m].w}, ar[2 * m + 1]);
-        ai[2 * m] = __builtin_elementwise_fma(t0p, wf2_t{xi[m].x, xi[m].y}, ai[2 * m]);
-        ai[2 * m + 1] = __builtin_elementwise_fma(t1p, wf2_t{xi[m].z, xi[m].w}, ai[2 * m + 1]);
+        ar[2 * m] = __builtin_elementwise_fma(t0p, wf2_t{xr[0][m].x, xr[0][m].y}, ar[2 * m]);
+        ar[2 * m + 1] = __builtin_elementwise_fma(t1p, wf2_t{xr[0][m].z, xr[0][m].w}, ar[2 * m + 1]);
+        ai[2 * m] = __builtin_elementwise_fma(t0p, wf2_t{xi[0][m].x, xi[0][m].y}, ai[2 * m]);
+        ai[2 * m + 1] = __builtin_elementwise_fma(t1p, wf2_t{xi[0][m].z, xi[0][m].w}, ai[2 * m + 1]);
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k) { asm volatile("" : "+v"(ar[k])); asm volatile("" : "+v"(ai[k])); }   // pins this q's FMAs before the fence
@@ -751,9 +782,25 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         for (int j = 0; j < 4; ++j) tl[j] = wbfm_s_buffer_load16(prsrc, tap1 + 64 * (3 - j), 0);
       }
 #pragma unroll
-      for (int m = 0; m < 4; ++m) { xr[m] = nxr[m]; xi[m] = nxi[m]; }
+      for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { xr[d][m] = xr[d + 1][m]; xi[d][m] = xi[d + 1][m]; }
     }
     wfence();
+    // ---- 1'. the NEXT block's samples -> tile (their slots hold steps that this block's FIR was the last to read), then the
+    //          prefetch of the block after it.  Placed here, the wait for the prefetched bytes does not also wait for the audio
+    //          stores of the resampler below (stores count in vmcnt too): those are a whole FIR old when the next wait comes.
+    if (s0 + 64 < tb) {
+      int offn = off0 + 64 * GS;
+      if (offn >= RING * GS) offn -= RING * GS;
+      if (kind == 0) store_group(offn, ra, rb);
+      else store_group_slow(offn, s + 64, kind);
+      wfence();
+      kind = group_kind(s + 128);
+      if (kind == 0 && s0 + 128 < tb) fetch(s + 128, ra, rb);
+    }
+    wfence();
+    resample_issue();                                           // previous block's audio (none before the first: empty range): reads in flight during the DFT
     // ---- 3. 16-point DFT on position pairs (2k', 2k'+1)
 #pragma unroll
     for (int k = 0; k < 8; ++k) {                               // stage m = 2: partner inside the pair, W = (1, 0)
@@ -776,6 +823,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
     for (int k = 0; k < 8; ++k) { cr[k] = ar[k]; ci[k] = ai[k]; }   // band pair k = (2k, 2k+1)
 
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { asm volatile("" : "+v"(cr[k])); asm volatile("" : "+v"(ci[k])); }   // pins the DFT before the fence
+    wfence();
+    resample_finish();
+    wfence();
     // ---- 4. c[s-1] from the left lane: one DPP move per component (wave_shr:1); lane 0 keeps the value handed over in LDS by
     //         lane 63 of the previous block (or the call's carried state / zeros)
     float dn[16];
@@ -804,48 +856,31 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         z[4 + m] = wf4_t{ci[2 * m].x, ci[2 * m].y, ci[2 * m + 1].x, ci[2 * m + 1].y};
       }
     }
-    // ---- 5. d rows and the block's audio samples
-#pragma unroll
-    for (int b = 0; b < 16; ++b) drow[b * DROW + HDMAX + lane] = dn[b];
-    __syncthreads();
-    const int hi = s0 + 64 < tb ? s0 + 64 : tb;
-    const int jl_hi = first_jl(hi);
+    // ---- 5. d rows (ring columns; the last HDMAX columns are mirrored below column 0, so a window never wraps)
     {
-      const int b = lane >> 2;
-      const float* const myrow = drow + b * DROW + HDMAX - s0;   // myrow[n] = d_b[n] (call-relative step n)
-      float* const aout = w.audio + ((size_t)stream * NB + b) * w.band_stride;
-      for (int base = jl_lo; base < jl_hi; base += 16) {
-        const float* dp[4];
-        float gt[4][GT], a[4];
-        bool ok[4];
+      int c = dcb + lane;
+      if (c >= DRING) c -= DRING;
+      float* const col = drow + HDMAX + c;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int jl = base + 4 * (lane & 3) + i;
-          const uint32_t loc = w.res_r0 + (uint32_t)jl * w.M;
-          const uint32_t qq = __umulhi(loc, w.inv_L32);
-          const int nrel = w.res_q0 + (int)qq;
-          const uint32_t phi = loc - qq * (uint32_t)L;
-          ok[i] = jl < jl_hi;
-          dp[i] = myrow + (ok[i] ? nrel : s0);                   // (inactive lanes read inside the row)
-          const wf4_t* tp = reinterpret_cast<const wf4_t*>(gT + (ok[i] ? phi : 0u) * GT);
+      for (int b = 0; b < 16; ++b) col[b * DROW] = dn[b];
+      if (c >= DRING - HDMAX) {
 #pragma unroll
-          for (int m = 0; m < GT / 4; ++m) { const wf4_t t4 = tp[m]; gt[i][4 * m] = t4.x; gt[i][4 * m + 1] = t4.y; gt[i][4 * m + 2] = t4.z; gt[i][4 * m + 3] = t4.w; }
-          a[i] = 0.0f;
-        }
-#pragma unroll
-        for (int k = HDMAX - 1; k >= 0; --k)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) a[i] = __builtin_fmaf(gt[i][k], dp[i][-k], a[i]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (ok[i]) aout[base + 4 * (lane & 3) + i] = a[i];
+        for (int b = 0; b < 16; ++b) col[b * DROW - DRING] = dn[b];
       }
     }
-    jl_lo = jl_hi;
+    const int hi = s0 + 64 < tb ? s0 + 64 : tb;
+    p_s0 = s0; p_dcb = dcb; p_lo = jl_lo; p_hi = first_jl(hi);
+    jl_lo = p_hi;
+    dcb += 64;
+    if (dcb >= DRING) dcb -= DRING;
     ring0 += 64;
     if (ring0 >= RING) ring0 -= RING;
     __syncthreads();
   }
+  resample_issue();                                             // the last block's audio
+  wfence();
+  resample_finish();
+  __syncthreads();
 
   // ---- state hand-over by the last run of the stream ----------------------------------------------------------------
   if (last_run) {
@@ -859,7 +894,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
     for (int i = lane; i < 16 * HD; i += 64) {
       const int b = i / HD, k = i % HD;
-      w.hist_d_out[((size_t)stream * NB + b) * HD + k] = drow[b * DROW + HDMAX + ((int)w.Tn - s0_last) - HD + k];
+      int c = p_dcb + ((int)w.Tn - s0_last) - HD + k;           // column of step Tn - HD + k (p_dcb: the last block's column base)
+      if (c >= DRING) c -= DRING;
+      w.hist_d_out[((size_t)stream * NB + b) * HD + k] = drow[b * DROW + HDMAX + c];
     }
     for (uint32_t i = (uint32_t)lane; i + 1 < w.P; i += 64)
       w.hist_x_out[(size_t)stream * (w.P - 1) + i] = wload_x(w, stream, (int)w.N - (int)(w.P - 1) + (int)i);
@@ -1066,7 +1103,7 @@ static int wenqueue(sdrfm_wbfm* h, const uint8_t* d_iq, size_t iq_stride, uint32
   w.res_r0 = (uint32_t)((h->n_a * c.resamp_down) % c.resamp_up);
   const uint64_t span = (uint64_t)(c.n_streams - 1) * iq_stride + nbytes;
   w.iq_span = (uint32_t)span;
-  if (h->steps_ok && Tn >= 64 && ((uint64_t)A + 16) * c.resamp_down + c.resamp_up < (1ull << 26) && ((uint64_t)Tn + 64) * c.resamp_up < (1ull << 31)) {
+  if (h->steps_ok && Tn >= 64 && 4u * c.resamp_up <= c.resamp_down && ((uint64_t)A + 16) * c.resamp_down + c.resamp_up < (1ull << 26) && ((uint64_t)Tn + 64) * c.resamp_up < (1ull << 31)) {
     // step kernel: one wave per run of NT steps of one stream; a run that does not start the call re-computes HD + 1 steps.
     // One round of two waves per SIMD (8 waves per CU) when the streams allow it, runs of at least 128 steps.
     uint64_t runs = (8ull * h->n_cu + c.n_streams - 1) / c.n_streams;
@@ -1076,7 +1113,7 @@ static int wenqueue(sdrfm_wbfm* h, const uint8_t* d_iq, size_t iq_stride, uint32
     if (h->force_nt) w.NT = h->force_nt;
     w.tiles_per_stream = (Tn + w.NT - 1) / w.NT;
     w.n_streams = c.n_streams;
-    const size_t lds = (size_t)72 * 144 + 144 + 16 * (64 + 10 + 2) * 4 + (size_t)c.resamp_up * 12 * 4;   // ring tile, c slot, d rows, tap table
+    const size_t lds = (size_t)80 * 144 + 144 + 16 * (10 + 96 + 2) * 4 + (size_t)c.resamp_up * 12 * 4;   // ring tile, c slot, d rows, tap table
     hipLaunchKernelGGL((k_wbfm_steps<8, 10>), dim3(c.n_streams * w.tiles_per_stream), dim3(64), lds, h->stream, w);
     WTRY(hipGetLastError(), SDRFM_FAIL);
     h->cur ^= 1;
