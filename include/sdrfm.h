@@ -193,7 +193,8 @@ int  sdrfm_wbfm_process_batch(sdrfm_wbfm_t* h, const uint8_t* iq, size_t iq_stri
                               float* audio, size_t band_stride, uint32_t* n_audio_per_band, uint32_t flags);
 int  sdrfm_wbfm_set_stream(sdrfm_wbfm_t* h, void* hip_stream);
 int  sdrfm_wbfm_synchronize(sdrfm_wbfm_t* h);
-/* starts with "wbfm-fused" (128-tap prototype, <= 10 resampler taps per phase) or "wbfm-generic" (any shape, two kernels) */
+/* starts with "wbfm-fused" (128-tap prototype, <= 10 resampler taps per phase; the kernel in use follows in brackets) or
+   "wbfm-generic" (any shape, two kernels) */
 const char* sdrfm_wbfm_kernel_name(const sdrfm_wbfm_t* h);
 
 /* ------------------------------------------------------------------------------------------------------------------

@@ -5,10 +5,13 @@
  * Same boundary as the narrow-band path: it consumes the RTL2832 bulk-IN buffer (RTLSDR_CommItfTypedef,
  * Middlewares/ST/STM32_USB_Host_Library/Class/RTLSDR/Inc/usbh_rtlsdr.h:165-173) from the hook the reference leaves empty
  * (usbh_rtlsdr.c:1094-1097).  Arithmetic: DESIGN.md "WBFM spec" — fp32 fmaf chains oldest-first, a fixed radix-2 DIT
- * 16-point DFT graph, the K3 discriminator of sdrfm_math.h.  Correctness-first kernels (not yet tuned):
- *   k_wbfm_chan : one block = NT channelizer steps of one stream: stage x (f32) in LDS, 16 polyphase branches per step,
- *                 16-point DFT per step, discriminator per band -> d scratch in HBM [stream][band][t]
- *   k_wbfm_res  : one thread = one audio sample of one band; extra blocks hand the d history over
+ * 16-point DFT graph, the K3 discriminator of sdrfm_math.h.  Three bit-identical implementations:
+ *   k_wbfm_steps : the product path for the BASELINE shape (P = 128, <= 10 resampler taps per phase, 4 L <= M): one lane per
+ *                  channelizer step, DFT in registers, everything in one kernel (see the comment above the kernel)
+ *   k_wbfm_fused : one lane per polyphase branch, DFT across 16 lanes by DPP (round 1; fallback for L = 1 or 4 L > M)
+ *   k_wbfm_chan + k_wbfm_res : any prototype length / ratio.  k_wbfm_chan: one block = NT channelizer steps of one stream, x (f32)
+ *                  staged in LDS, 16 polyphase branches per step, 16-point DFT per step, discriminator per band -> d scratch in
+ *                  HBM [stream][band][t];  k_wbfm_res: one thread = one audio sample of one band; extra blocks hand the d history over
  */
 #include <hip/hip_runtime.h>
 
