@@ -182,3 +182,34 @@ def test_golden_vector_on_gpu(pkg):
     assert got.shape == z["audio"].shape
     _check_all(got, z["audio"], "golden")                             # all 16 bands, every sample
     dm.close()
+
+
+@pytest.mark.parametrize("byte_off,pad", [(0, 0), (2, 6), (6, 2), (14, 10)])
+def test_device_path_with_unaligned_rows_matches_generic_bitwise(pkg, byte_off, pad):
+    """Device-resident rows that start at any even byte address and have any even stride (the step kernel fetches 32 bytes per
+    lane with plain 16-byte loads), fed in ragged chunks so that the step phase moves too; bitwise against the generic kernels."""
+    import torch
+    p, g = _taps(pkg)
+    ns, nsamp = 3, 52000
+    iq_host = pkg.make_iq(ns, nsamp, mode="fm", fs=3.2e6, first_id=900)
+    stride = 2 * nsamp + pad
+    buf = torch.zeros(ns * stride + 64, dtype=torch.uint8, device="cuda")
+    rows = buf[byte_off:byte_off + ns * stride].view(ns, stride)
+    rows[:, :2 * nsamp] = torch.from_numpy(iq_host).cuda()
+    outs = {}
+    for name, flags in (("steps", {}), ("generic", {"force_generic": True})):
+        dm = pkg.WbfmDemod(pkg.WbfmConfig(proto_coeffs=p, resamp_coeffs=g, n_streams=ns, max_bytes_per_call=1 << 17, **flags))
+        audio = torch.zeros((ns, 16, 4096), dtype=torch.float32, device="cuda")
+        got, pos = [], 0
+        for c in (2 * 5000, 2 * 5001, 2 * 17, 2 * 20000, 2 * 3, 2 * 21979):
+            n = dm.process_batch_device(rows[:, pos:pos + c], audio, nbytes=c)
+            dm.synchronize()
+            got.append(audio[:, :, :n].cpu().numpy().copy())
+            pos += c
+        assert pos == 2 * nsamp
+        outs[name] = np.concatenate(got, axis=2)
+        if name == "steps":
+            assert "k_wbfm_steps" in dm.kernel_name
+        dm.close()
+    assert outs["steps"].shape == outs["generic"].shape == (ns, 16, 780)
+    assert np.array_equal(outs["steps"].view(np.uint32), outs["generic"].view(np.uint32))
