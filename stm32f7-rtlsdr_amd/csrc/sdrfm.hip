@@ -1149,7 +1149,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // instruction: region 8 i + t / 8, piece t % 8, fetched from column piece ^ swizzle), so a class is refilled the moment its
   // lanes cross a line boundary.  Lanes whose segment lies outside the call fetch (and never use) the row's first line; no
   // instruction is ever skipped, so vmcnt counts DMA instructions exactly.  The line an even segment shares with its odd right
-  // neighbour is fetched half by each (64-byte requests): every byte of the row crosses the fabric once.
+  // neighbour is requested by both, half each; the L2 still fills whole 128-byte lines (TCC_EA0_RDREQ_128B did not move when the
+  // halves were introduced), so the row crosses the fabric 16/15 times: 133.5 MB read for 122.9 MB of input.
   const unsigned long long gaddr = (unsigned long long)(p.iq + (size_t)stream * p.iq_stride);
   const i4_t rsrc = {(int)(unsigned)gaddr, (int)(unsigned)(gaddr >> 32), (int)(2u * p.N), 0x00020000};
   const int g0odd = g0 & 1;
