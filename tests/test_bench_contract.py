@@ -1,0 +1,45 @@
+"""CPU checks of bench.py's bookkeeping: which committed PMC summary feeds `roofline.traffic`, and how many input batches the
+timed loop rotates over (cold-HBM rule).  The GPU side of the contract is exercised by the driver's own bench run."""
+import importlib.util
+import json
+import os
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_traffic_lookup_matches_kernel_and_workload_size():
+    b = _bench()
+    head = json.load(open(os.path.join(ROOT, "profiles", "traffic_r02.json")))
+    t = b.latest_traffic(head["kernel_name"], head["algorithmic_bytes_per_launch"])
+    assert t is not None and t["file"].startswith(("traffic_r02", "r02_")) and t["hbm_bytes_per_launch"] == head["hbm_bytes_per_launch"]
+    # same kernel, twice the streams: the 512-stream profile, not the 256-stream one
+    t512 = b.latest_traffic(head["kernel_name"], 2 * head["algorithmic_bytes_per_launch"])
+    assert t512 is not None and abs(t512["hbm_bytes_per_launch"] / t["hbm_bytes_per_launch"] - 2.0) < 0.02
+    # a workload size nobody profiled, or another kernel: no figure rather than a wrong one
+    assert b.latest_traffic(head["kernel_name"], 12345.0) is None
+    assert b.latest_traffic("no such kernel", head["algorithmic_bytes_per_launch"]) is None
+
+
+def test_traffic_never_below_algorithmic_bytes():
+    """A committed summary whose traffic is below the algorithmic bytes would mean a broken counter pass."""
+    import glob
+    for fn in glob.glob(os.path.join(ROOT, "profiles", "r02_*_pmc.json")):
+        d = json.load(open(fn))
+        assert d["hbm_bytes_per_launch"] >= 0.999 * d["algorithmic_bytes_per_launch"], fn
+        assert d.get("commit") and d["commit"] != "wip", fn
+
+
+def test_rotation_exceeds_the_infinity_cache():
+    b = _bench()
+    for bytes_per_batch in (256 * 480000, 512 * 480000, 128 * 640000, 64 * 480000):
+        nb = b.pick_batches(types.SimpleNamespace(batches=0), bytes_per_batch)
+        assert nb >= 3 and (nb - 1) * bytes_per_batch > 1.5 * b.L3_BYTES      # between two uses of a batch: more than the L3 holds
+    assert b.pick_batches(types.SimpleNamespace(batches=7), 1) == 7

@@ -138,8 +138,9 @@ def _run(pkg, iq, n_streams, **flags):
 
 @pytest.mark.parametrize("n_streams,nsamp", [(1, 100000), (5, 40007), (8, 25601)])
 def test_fused_kernel_bitwise_equals_generic_kernels(pkg, n_streams, nsamp):
-    """The fused kernel (lanes = branches, DFT across lanes) and the two-kernel generic path evaluate the same frozen
-    chains: identical bits, for stream counts that do and do not fill a wave's 4 groups and an odd number of steps."""
+    """The step kernel (one lane per channelizer step, DFT in registers), the one-lane-per-branch kernel (DFT across lanes by
+    DPP) and the two-kernel generic path evaluate the same frozen chains: identical bits, for stream counts that do and do not
+    fill a wave's 4 groups and an odd number of steps."""
     iq = pkg.make_iq(n_streams, nsamp, mode="fm", fs=3.2e6, first_id=70)
     nf, fused = _run(pkg, iq, n_streams)
     nb, branch = _run(pkg, iq, n_streams, branch_lanes=True)

@@ -55,12 +55,12 @@ def main(out):
             rep["cases"].append({"path": "fm single stream", "kernel": dm.kernel_name, "T": T, "input": mode, **stats(got, want)})
             dm.close()
     h, g = pkg.default_config(64)
-    ns, nsamp = 32, 240000
+    ns, nsamp = 128, 240000                                       # enough waves for design S (the headline kernel)
     dm = pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=ns, max_bytes_per_call=2 * nsamp))
     iq = pkg.make_iq(ns, nsamp, mode="fm", first_id=100)
     got = dm.process_batch(iq)
     want = np.stack([oracle_mod.Oracle(h, g).process(iq[s]) for s in range(ns)])
-    rep["cases"].append({"path": "fm batch (configs[2] shape, 32 streams)", "kernel": dm.kernel_name, "T": 64, "input": "fm", **stats(got, want)})
+    rep["cases"].append({"path": "fm batch (configs[2] shape, %d streams)" % ns, "kernel": dm.kernel_name, "T": 64, "input": "fm", **stats(got, want)})
     dm.close()
     # K3 alone: the device atan2 against libm over random complex pairs (the only non-bit-exact stage)
     rng = np.random.default_rng(5)
