@@ -105,7 +105,7 @@ __device__ __forceinline__ void fft_passes(float2* X, const float2* TW, int lane
 
 // waves per workgroup, one block of frames each: 8, or 4 for 4096 points (LDS: 160 KiB per CU); the short-frame kernels fit
 // 128 VGPRs without the prefetch registers and run 16 waves, which hide the load latency instead
-constexpr int spec_nwf(int logn) { return (logn <= 8 || logn == 10) ? 16 : (logn <= 11 ? 8 : 4); }
+constexpr int spec_nwf(int logn) { return logn <= 8 ? 16 : (logn <= 11 ? 8 : 4); }
 // points per wave and round: a frame, or for N < 1024 as many whole frames as make 1024 points (all 64 lanes stay busy)
 constexpr int spec_logb(int logn) { return logn < 10 ? 10 : logn; }
 
