@@ -57,6 +57,11 @@ struct WParams {
   const float* g;               // Tg resampler taps
   const float* pperm;           // step kernel: prototype taps in DFT input order, pperm[16 q + k] = p[bitrev4(k) + 16 q]
   uint32_t inv_L32;             // step kernel: floor(2^32 / L) + 1
+  uint32_t swap_pct;            // step kernel: share of a run after which the priority passes from the slot-0 to the slot-1 wave
+#ifdef SDRFM_DEV
+  unsigned long long* dbg;      // development build: 256 words per wave of phase time stamps (nullptr = off)
+  uint32_t dbg_light;           // ... only the entry / exit times (no per-phase waits: the kernel runs at full speed)
+#endif
   uint32_t P, Tg, L, M, HD, dcap;
   uint32_t N;                   // new IQ samples per stream
   uint32_t Tn;                  // channelizer steps this call
@@ -593,6 +598,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   float* const drow = cslot + GS / 4;
   float* const gT = drow + 16 * DROW;                           // [L][GT]: gT[phi][i] = g[phi + L i], zero beyond Tg / HDMAX
   const int lane = (int)threadIdx.x;
+#ifdef SDRFM_DEV   // development build: per-wave time stamps (shader cycles) at the phase boundaries of every block.  A stamp waits for
+  // everything outstanding first, so a phase's figure includes its own memory latency (and the kernel runs slower: diagnostic only)
+  unsigned long long* const tsp = w.dbg ? w.dbg + 256 * (size_t)blockIdx.x : nullptr;
+  int tsi = 0;
+#define WSTAMP() do { if (tsp && !w.dbg_light) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (lane == 0 && tsi < 250) tsp[tsi] = __builtin_readcyclecounter(); ++tsi; asm volatile("" ::: "memory"); } } while (0)
+  if (tsp && lane == 0) { tsp[254] = __builtin_amdgcn_s_memrealtime(); tsp[253] = __builtin_amdgcn_s_getreg((31 << 11) | 4); }
+#else
+#define WSTAMP() do { } while (0)
+#endif
+  WSTAMP();                                                     // 0: entry
   const uint32_t run = blockIdx.x / w.n_streams, stream = blockIdx.x % w.n_streams;
   const int HD = (int)w.HD, L = (int)w.L;
   const int ta = (int)(run * w.NT);
@@ -726,6 +741,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       if (rok[i]) aout[p_lo + 4 * (lane & 3) + i] = a[i];
   };
   int ring0 = Q - 1;                                            // ring slot of lane 0's step (the Q - 1 older groups sit below it)
+  // The two waves of a SIMD are arbitrated oldest-first: at equal priority the wave in hardware slot 0 takes every issue slot it can
+  // use and the other gets what is left; when the first is done the second finishes alone (measured: ends at 81 and 108 us).
+  // Strict turns (priority passed at every phase boundary) end the pair together but lower its joint throughput (105 us again):
+  // one wave running unimpeded plus one filling its gaps is the more efficient mode.  So the roles are swapped once, in the middle
+  // of the run: the slot-0 wave has the priority for the first 40 % of its steps, the slot-1 wave for the rest (both then end
+  // within 2 us of each other: 105 -> 100 us).
+  const uint32_t myslot = __builtin_amdgcn_s_getreg((31 << 11) | 4) & 1u;   // HW_ID.wave_id & 1
+  const int swap_at = t0 + (int)(((long long)(tb - t0) * (int)w.swap_pct) / 100);
+  WSTAMP();                                                     // 1: prologue done; then 7 stamps per block
   for (int s0 = t0; s0 < tb; s0 += 64) {
     s0_last = s0;
     const int s = s0 + lane;
@@ -738,6 +762,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     if (off0 >= RING * GS) off0 -= RING * GS;                   // iteration / the prologue)
     wfence();
 
+    WSTAMP();                                                   // block top (tap loads issued)
+    if ((s0 < swap_at) == (myslot == 0)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
     // ---- 2. polyphase FIR, oldest tap first
     wf2_t ar[8], ai[8];
 #pragma unroll
@@ -789,6 +815,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
         for (int m = 0; m < 4; ++m) { xr[d][m] = xr[d + 1][m]; xi[d][m] = xi[d + 1][m]; }
     }
+    WSTAMP();                                                   // FIR
     wfence();
     // ---- 1'. the NEXT block's samples -> tile (their slots hold steps that this block's FIR was the last to read), then the
     //          prefetch of the block after it.  Placed here, the wait for the prefetched bytes does not also wait for the audio
@@ -802,6 +829,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       kind = group_kind(s + 128);
       if (kind == 0 && s0 + 128 < tb) fetch(s + 128, ra, rb);
     }
+    WSTAMP();                                                   // next tile stored, prefetch issued (and, stamped, waited for)
     wfence();
     resample_issue();                                           // previous block's audio (none before the first: empty range): reads in flight during the DFT
     // ---- 3. 16-point DFT on position pairs (2k', 2k'+1)
@@ -828,9 +856,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
 #pragma unroll
     for (int k = 0; k < 8; ++k) { asm volatile("" : "+v"(cr[k])); asm volatile("" : "+v"(ci[k])); }   // pins the DFT before the fence
+    WSTAMP();                                                   // previous block's resampler reads issued + DFT
     wfence();
     resample_finish();
     wfence();
+    WSTAMP();                                                   // previous block's audio samples
     // ---- 4. c[s-1] from the left lane: one DPP move per component (wave_shr:1); lane 0 keeps the value handed over in LDS by
     //         lane 63 of the previous block (or the call's carried state / zeros)
     float dn[16];
@@ -859,6 +889,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         z[4 + m] = wf4_t{ci[2 * m].x, ci[2 * m].y, ci[2 * m + 1].x, ci[2 * m + 1].y};
       }
     }
+#ifdef SDRFM_DEV
+#pragma unroll
+    for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(dn[k]));   // (keeps the discriminator before its stamp)
+#endif
+    WSTAMP();                                                   // discriminator
     // ---- 5. d rows (ring columns; the last HDMAX columns are mirrored below column 0, so a window never wraps)
     {
       int c = dcb + lane;
@@ -879,11 +914,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     ring0 += 64;
     if (ring0 >= RING) ring0 -= RING;
     __syncthreads();
+    WSTAMP();                                                   // d rows, bookkeeping
   }
   resample_issue();                                             // the last block's audio
   wfence();
   resample_finish();
   __syncthreads();
+#ifdef SDRFM_DEV
+  if (tsp && lane == 0) tsp[255] = __builtin_amdgcn_s_memrealtime();
+#endif
+#undef WSTAMP
 
   // ---- state hand-over by the last run of the stream ----------------------------------------------------------------
   if (last_run) {
@@ -930,6 +970,10 @@ struct sdrfm_wbfm {
   uint32_t n_cu;          // compute units (fused kernel: run-length choice)
   uint32_t force_nt;      // SDRFM_WBFM_CFG_RUN_STEPS: fixed run length (tests)
   char kernel_name[48];
+#ifdef SDRFM_DEV
+  unsigned long long* d_dbg;   // development build: time stamps of the step kernel (SDRFM_WBFM_PROFILE=1)
+  uint32_t dbg_waves;
+#endif
 };
 
 #define WTRY(expr, code)                                                                                     \
@@ -947,6 +991,9 @@ static void wfree(sdrfm_wbfm* h) {
   void* ptrs[] = {h->d_p, h->d_g, h->d_pperm, h->d_hist_x[0], h->d_hist_x[1], h->d_cprev[0], h->d_cprev[1], h->d_hist_d[0], h->d_hist_d[1],
                   h->d_dbuf, h->d_iq, h->d_audio};
   for (void* q : ptrs) if (q) (void)hipFree(q);
+#ifdef SDRFM_DEV
+  if (h->d_dbg) (void)hipFree(h->d_dbg);
+#endif
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   free(const_cast<float*>(h->cfg.proto_coeffs));
   free(const_cast<float*>(h->cfg.resamp_coeffs));
@@ -1087,6 +1134,21 @@ int sdrfm_wbfm_synchronize(sdrfm_wbfm_t* h) {
 
 const char* sdrfm_wbfm_kernel_name(const sdrfm_wbfm_t* h) { return h ? h->kernel_name : ""; }
 
+#ifdef SDRFM_DEV
+/* Development library only (not in include/sdrfm.h): the step kernel's time stamps of the last stamped launch, 256 words per wave:
+ * [0] entry, [1] prologue done, then 7 per block (top, FIR, next tile, resampler issue + DFT, resampler finish, discriminator,
+ * d rows); [253] HW_ID, [254] / [255] s_memrealtime at entry / exit.  Returns the number of waves through *n_waves. */
+int sdrfm_wbfm_dev_read_debug(sdrfm_wbfm_t* h, unsigned long long* out, uint32_t max_waves, uint32_t* n_waves) {
+  if (!h || !out || !n_waves || !h->d_dbg) return SDRFM_EINVAL;
+  WTRY(hipSetDevice(h->device), SDRFM_FAIL);
+  WTRY(hipStreamSynchronize(h->stream), SDRFM_FAIL);
+  const uint32_t n = h->dbg_waves < max_waves ? h->dbg_waves : max_waves;
+  WTRY(hipMemcpy(out, h->d_dbg, sizeof(unsigned long long) * 256 * (size_t)n, hipMemcpyDeviceToHost), SDRFM_FAIL);
+  *n_waves = n;
+  return SDRFM_OK;
+}
+#endif
+
 static int wenqueue(sdrfm_wbfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nbytes, float* d_audio, size_t band_stride) {
   const sdrfm_wbfm_config& c = h->cfg;
   uint32_t Tn, A;
@@ -1099,6 +1161,10 @@ static int wenqueue(sdrfm_wbfm* h, const uint8_t* d_iq, size_t iq_stride, uint32
   w.cprev_in = h->d_cprev[h->cur]; w.cprev_out = h->d_cprev[h->cur ^ 1];
   w.hist_d_in = h->d_hist_d[h->cur]; w.hist_d_out = h->d_hist_d[h->cur ^ 1];
   w.dbuf = h->d_dbuf; w.p = h->d_p; w.g = h->d_g; w.pperm = h->d_pperm;
+#ifdef SDRFM_DEV
+  w.dbg = nullptr; w.dbg_light = 0;
+#endif
+  w.swap_pct = 40u;   // measured on configs[4]: swap at 0 / 30 / 35 / 40 / 45 / 50 / 60 / 100 % -> 106 / 102 / 101 / 100 / 100.6 / 101 / 104 / 104.5 us
   w.inv_L32 = c.resamp_up >= 2 ? (uint32_t)((1ull << 32) / c.resamp_up) + 1u : 0u;
   w.P = c.proto_taps; w.Tg = c.resamp_taps; w.L = c.resamp_up; w.M = c.resamp_down; w.HD = h->HD; w.dcap = h->dcap;
   w.N = N; w.Tn = Tn; w.A = A; w.phase_x = h->phase_x; w.n_d = h->n_d; w.n_a = h->n_a;
@@ -1117,6 +1183,14 @@ static int wenqueue(sdrfm_wbfm* h, const uint8_t* d_iq, size_t iq_stride, uint32
     w.tiles_per_stream = (Tn + w.NT - 1) / w.NT;
     w.n_streams = c.n_streams;
     const size_t lds = (size_t)80 * 144 + 144 + 16 * (10 + 96 + 2) * 4 + (size_t)c.resamp_up * 12 * 4;   // ring tile, c slot, d rows, tap table
+#ifdef SDRFM_DEV
+    if (getenv("SDRFM_WBFM_PROFILE") && c.n_streams * w.tiles_per_stream <= 16384u) {   // development build: stamp this launch
+      if (!h->d_dbg) WTRY(hipMalloc(&h->d_dbg, sizeof(unsigned long long) * 256 * 16384), SDRFM_ENOMEM);
+      w.dbg = h->d_dbg;
+      w.dbg_light = atoi(getenv("SDRFM_WBFM_PROFILE")) == 2;
+      h->dbg_waves = c.n_streams * w.tiles_per_stream;
+    }
+#endif
     hipLaunchKernelGGL((k_wbfm_steps<8, 10>), dim3(c.n_streams * w.tiles_per_stream), dim3(64), lds, h->stream, w);
     WTRY(hipGetLastError(), SDRFM_FAIL);
     h->cur ^= 1;

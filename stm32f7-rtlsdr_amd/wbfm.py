@@ -21,11 +21,12 @@ class WbfmConfig:
     force_generic: bool = False       # SDRFM_WBFM_CFG_FORCE_GENERIC (tests): never run the fused kernel
     run_steps: int = 0                # SDRFM_WBFM_CFG_RUN_STEPS (tests): fixed run length of the fused kernel, 0 = per call
     branch_lanes: bool = False        # SDRFM_WBFM_CFG_BRANCH_LANES (tests): the one-lane-per-branch fused kernel instead of one lane per step
+    dev_library: bool = False         # load csrc/libsdrfm_dev.so (instrumented build; tools only)
 
 
 class WbfmDemod:
     def __init__(self, cfg: WbfmConfig):
-        self._lib = _l.load_library()
+        self._lib = _l.load_library(dev=cfg.dev_library)
         self.cfg = cfg
         p = np.ascontiguousarray(cfg.proto_coeffs, dtype=np.float32)
         g = np.ascontiguousarray(cfg.resamp_coeffs, dtype=np.float32)

@@ -111,7 +111,7 @@ def test_product_library_holds_no_development_kernels_or_environment_knobs(pkg):
     blob = open(path, "rb").read()
     for knob in (b"SDRFM_ABLATE", b"SDRFM_PHASE_PROFILE", b"SDRFM_FAST_KIND", b"SDRFM_FAST_R", b"SDRFM_AUDIO_BATCH", b"SDRFM_WARM_AHEAD",
                  b"SDRFM_WAVES_PER_CU", b"SDRFM_MIN_SUBTILES", b"SDRFM_NO_PRIO", b"SDRFM_NO_FOLD", b"SDRFM_NO_ZEROCOPY",
-                 b"SDRFM_WBFM_GENERIC", b"SDRFM_WBFM_NT", b"SDRFM_END_PRIO", b"SDRFM_NO_STREAM", b"SDRFM_STREAM_PROFILE"):
+                 b"SDRFM_WBFM_GENERIC", b"SDRFM_WBFM_NT", b"SDRFM_END_PRIO", b"SDRFM_NO_STREAM", b"SDRFM_STREAM_PROFILE", b"SDRFM_WBFM_PROFILE"):
         assert knob not in blob, knob
     dev = pkg.library_path(dev=True)
     if os.path.exists(dev):
