@@ -582,16 +582,24 @@ __device__ __forceinline__ void wbfly(wf2_t& ar, wf2_t& ai, wf2_t& br, wf2_t& bi
   ar = ar + tr; ai = ai + ti;
 }
 
+// LDS geometry of the step kernel (one definition for the kernel and for the launch)
+template <int Q, int HDMAX>
+struct WStepsLds {
+  static constexpr int GS = 144;                                // bytes per step group in the tile: 16 re + 16 im floats + 16 pad
+  static constexpr int RING = 80;                               // tile slots: a ring over the step index (>= 64 + Q - 1; a multiple of 16
+                                                                // keeps a lane group's 16 slots on 16 different bank quads across the wrap)
+  static constexpr int DRING = 96;                              // d columns per band: a ring over the step index (>= 64 + HDMAX)
+  static constexpr int DROW = HDMAX + DRING + 2;                // words per band row: [mirror of the last HDMAX columns | DRING columns | pad]
+  static constexpr int GT = (HDMAX + 3) & ~3;                   // words per phase row of the tap table
+  static_assert(RING >= 64 + Q - 1 && DRING >= 64 + HDMAX, "rings");
+  static constexpr size_t bytes(uint32_t L) { return (size_t)RING * GS + GS + (size_t)16 * DROW * 4 + (size_t)L * GT * 4; }   // tile, c slot, d rows, tap table
+};
+
 template <int Q, int HDMAX>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_wbfm_steps(WParams w) {
-  constexpr int GS = 144;                                       // bytes per step group in the tile: 16 re + 16 im floats + 16 pad
-  constexpr int RING = 80;                                      // tile slots: a ring over the step index (>= 64 + Q - 1; a multiple of 16
-                                                                // keeps a lane group's 16 slots on 16 different bank quads across the wrap)
-  constexpr int DRING = 96;                                     // d columns per band: a ring over the step index (>= 64 + HDMAX)
-  constexpr int DROW = HDMAX + DRING + 2;                       // words per band row: [mirror of the last HDMAX columns | DRING columns | pad]
-  constexpr int GT = (HDMAX + 3) & ~3;                          // words per phase row of the tap table
+  using G_ = WStepsLds<Q, HDMAX>;
+  constexpr int GS = G_::GS, RING = G_::RING, DRING = G_::DRING, DROW = G_::DROW, GT = G_::GT;
   constexpr int rev[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
-  static_assert(RING >= 64 + Q - 1 && DRING >= 64 + HDMAX, "rings");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const xt = smem;                               // RING step groups
   float* const cslot = reinterpret_cast<float*>(xt + RING * GS);   // c of the step before the block: 16 re | 16 im (| pad)
@@ -1182,7 +1190,7 @@ static int wenqueue(sdrfm_wbfm* h, const uint8_t* d_iq, size_t iq_stride, uint32
     if (h->force_nt) w.NT = h->force_nt;
     w.tiles_per_stream = (Tn + w.NT - 1) / w.NT;
     w.n_streams = c.n_streams;
-    const size_t lds = (size_t)80 * 144 + 144 + 16 * (10 + 96 + 2) * 4 + (size_t)c.resamp_up * 12 * 4;   // ring tile, c slot, d rows, tap table
+    const size_t lds = WStepsLds<8, 10>::bytes(c.resamp_up);
 #ifdef SDRFM_DEV
     if (getenv("SDRFM_WBFM_PROFILE") && c.n_streams * w.tiles_per_stream <= 16384u) {   // development build: stamp this launch
       if (!h->d_dbg) WTRY(hipMalloc(&h->d_dbg, sizeof(unsigned long long) * 256 * 16384), SDRFM_ENOMEM);
