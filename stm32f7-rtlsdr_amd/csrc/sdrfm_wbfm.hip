@@ -503,23 +503,27 @@ __global__ void __launch_bounds__(256) k_wbfm_fused(WParams w) {
 //  WBFM step kernel: ONE LANE = ONE CHANNELIZER STEP (P = 128, HD <= HDMAX).
 //
 //  A wave owns a run of consecutive steps of one stream and walks it in blocks of 64 steps, lane l = step s0 + l.  Per block
-//    1. every lane converts the 16 new input samples of its step (32 bytes, prefetched one block ahead) and stores them in an LDS
-//       tile as two 16-float planes (re | im) in DFT INPUT ORDER: plane position k holds the sample of branch r = bitrev4(k).
-//       The tile keeps 64 + Q - 1 step groups (the Q - 1 oldest are carried from the previous block): every input byte is
-//       fetched and converted once (the kernel with one lane per branch re-computed ~20 warm-up steps per run);
-//    2. polyphase FIR: for q = Q-1 .. 0 (oldest first, the spec's order) the lane reads the group of step s - q (8 x 16 bytes,
-//       lane stride 144 bytes: conflict-free) and feeds all 16 branches, two per v_pk_fma_f32: accumulator pair k' holds the
-//       branches at DFT positions (2k', 2k'+1), the tap pair comes straight from SGPRs (taps are stored pre-permuted);
+//    1. polyphase FIR: for q = Q-1 .. 0 (oldest first, the spec's order) the lane reads the group of step s - q from an LDS tile
+//       (8 x 16 bytes, lane stride 144 bytes: conflict-free; three groups in flight) and feeds all 16 branches, two per
+//       v_pk_fma_f32: accumulator pair k' holds the branches at DFT positions (2k', 2k'+1), the tap pair is an SGPR pair
+//       (s_buffer_load_dwordx16 of taps stored pre-permuted, half of the 128 taps at a time).  The tile is a ring of 80 step
+//       groups, each two 16-float planes (re | im) in DFT INPUT ORDER (plane position k = branch bitrev4(k));
+//    2. right after the FIR the NEXT block's 16 samples per lane (32 bytes, fetched two blocks ahead) are converted and stored
+//       into the ring slots this block's FIR was the last to read: every input byte is fetched and converted once (the kernel
+//       with one lane per branch re-computed ~20 warm-up steps per run);
 //    3. the 16-point DFT runs in the lane's registers on (position 2k', 2k'+1) pairs: stage m = 2 is an add/sub inside each
 //       pair (its twiddle is (1, 0) and its inputs are FIR outputs, which are never -0: multiplying by (1, 0) is then the
 //       identity, bit for bit), stages 4, 8, 16 are the spec's butterflies on whole pairs with packed twiddle constants —
 //       no cross-lane traffic, no selects;  band pairs (2i, 2i+1) come out as (re, re) / (im, im) register pairs, exactly
 //       the packing the two-at-a-time discriminator wants;
-//    4. c[s-1] comes from the left lane through LDS (the tile is free by then), K3 runs packed on band pairs;
-//    5. the 16 d's of the step go to per-band rows in LDS ([HDMAX history | 64 new]) and the block's audio samples (about
-//       64 L / M per band) are evaluated by lane (band, 4 consecutive samples) from those rows and a [phase][tap] table.
+//    4. c[s-1] comes from the lane below by DPP (wave_shr:1; lane 0 takes what lane 63 left in LDS a block earlier), K3 runs
+//       packed on band pairs, stage by stage over the 8 pairs;
+//    5. the 16 d's of the step go to per-band rows in LDS (a ring of 96 columns, the last HDMAX mirrored below column 0); the
+//       audio samples of a block (about 64 L / M per band) are evaluated ONE BLOCK LATER by lane (band, 4 consecutive samples)
+//       from those rows and a [phase][tap] table: their LDS reads are issued before the DFT of the next block and consumed
+//       after it.
 //  A run that does not start the call warms up HD + 1 steps (the FIR has no memory beyond its window); the last run of a
-//  stream hands the streaming state over.
+//  stream hands the streaming state over.  The two waves of a SIMD swap priority roles once per run (see the kernel).
 // =================================================================================================================
 // scalar (SGPR) load of 16 consecutive floats through a buffer descriptor: wave-uniform taps without spending VGPRs or LDS cycles
 typedef float wf16_t __attribute__((ext_vector_type(16)));
