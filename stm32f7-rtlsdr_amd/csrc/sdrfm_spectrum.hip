@@ -66,7 +66,7 @@ __host__ __device__ constexpr int spad(int i) { return i + (i >> 4) + (i >> 8); 
 // LOGB >= LOGN: the wave's block holds 2^(LOGB-LOGN) independent frames side by side; stages <= LOGN never couple points of
 // different frames, so the same pass transforms all of them at once (index arithmetic over the block, twiddles of N).
 template <int LOGB, int LOGN, int S, int K>
-__device__ __forceinline__ void fft_pass(float2* X, const float2* TW, int lane) {
+__device__ __forceinline__ void fft_pass(float2* X, const float2* TW, const float2 (&W1)[8], int lane) {
   constexpr int H = 1 << (S - 1), G = 1 << K, NG = (1 << LOGB) >> K;
   constexpr int UNR = LOGB >= 12 ? 1 : 4;                      // (4096 points: 16 points x 4 groups unrolled would not fit in VGPRs)
 #pragma unroll UNR
@@ -83,7 +83,8 @@ __device__ __forceinline__ void fft_pass(float2* X, const float2* TW, int lane) 
         for (int c = 0; c < G; ++c) {
           if ((c >> t) & 1) continue;
           const int pos_t = pos + (c & ((1 << t) - 1)) * H;    // position of the pair within its stage-(S+t) block
-          butterfly(v[c], v[c + (1 << t)], TW[spad(pos_t << (LOGN - S - t))]);
+          if constexpr (S == 1 && K == 4) butterfly(v[c], v[c + (1 << t)], W1[(c & ((1 << t) - 1)) << (3 - t)]);   // first pass: the 8 twiddles W16^k, wave-uniform registers
+          else butterfly(v[c], v[c + (1 << t)], TW[spad(pos_t << (LOGN - S - t))]);
         }
       }
 #pragma unroll
@@ -93,13 +94,13 @@ __device__ __forceinline__ void fft_pass(float2* X, const float2* TW, int lane) 
   wave_sync();
 }
 template <int LOGB, int LOGN, int S>
-__device__ __forceinline__ void fft_passes(float2* X, const float2* TW, int lane) {
+__device__ __forceinline__ void fft_passes(float2* X, const float2* TW, const float2 (&W1)[8], int lane) {
   if constexpr (S <= LOGN) {
     // up to 4 stages per pass, but no more than leaves a group (2^K points) for each of the 64 lanes
     constexpr int KMAX = (LOGB - 6) >= 4 ? 4 : ((LOGB - 6) >= 2 ? (LOGB - 6) : 2);
     constexpr int K = (LOGN - S + 1) >= KMAX ? KMAX : (LOGN - S + 1);
-    fft_pass<LOGB, LOGN, S, K>(X, TW, lane);
-    fft_passes<LOGB, LOGN, S + K>(X, TW, lane);
+    fft_pass<LOGB, LOGN, S, K>(X, TW, W1, lane);
+    fft_passes<LOGB, LOGN, S + K>(X, TW, W1, lane);
   }
 }
 
@@ -123,6 +124,9 @@ __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
   const float* PW = reinterpret_cast<const float*>(reinterpret_cast<float2*>(spec_smem) + NPT);   // wave w's powers at PW[2 NPX w + i]
   const uint32_t stream = blockIdx.x;
   for (int i = tid; i < N / 2; i += NT) TW[spad(i)] = p.tw[i];
+  float2 W1[8];                                                // the first pass's twiddles W16^k = tw[k N/16] (wave-uniform)
+#pragma unroll
+  for (int k = 0; k < 8; ++k) W1[k] = N >= 16 ? p.tw[k * (N / 16)] : make_float2(1.f, 0.f);
   // up to 1024 points the lane keeps its window values and the next round's samples in registers; longer frames would
   // need > 256 VGPRs for that, so they read the window through the cache and load their samples when they need them
   constexpr bool REGS = (LOGB <= 10) && (NWF <= 8);
@@ -169,7 +173,7 @@ __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
       if (f + FPR < p.F) fetch(f + FPR);                       // next round's bytes: in flight during this block's FFTs
       wave_sync();
       // DIT stages in passes of up to 4 stages, each pass entirely in registers (see fft_pass)
-      fft_passes<LOGB, LOGN, 1>(X, TW, lane);
+      fft_passes<LOGB, LOGN, 1>(X, TW, W1, lane);
       // powers of this block, written over the start of its own region (PW[2 NPX wv + i]) in blocks of 16 points per lane:
       // block b overwrites float slots [1024 b, 1024 b + 1024), i.e. float2 slots below 512 (b + 1) — points already consumed
       // (a point's padded slot is never below its index)
