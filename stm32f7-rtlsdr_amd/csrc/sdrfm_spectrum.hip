@@ -65,8 +65,10 @@ __host__ __device__ constexpr int spad(int i) { return i + (i >> 4) + (i >> 8); 
 // tw[position_in_stage * N/m]); only the order of independent butterflies differs from the oracle's loops.
 // LOGB >= LOGN: the wave's block holds 2^(LOGB-LOGN) independent frames side by side; stages <= LOGN never couple points of
 // different frames, so the same pass transforms all of them at once (index arithmetic over the block, twiddles of N).
+// PWO != nullptr (last pass only, kernels with a separate power region): the pass stores |point|^2 at PWO[point index] instead of
+// writing the points back — the power phase's LDS round trip (16 writes + 16 reads of 8 bytes per lane and frame) disappears.
 template <int LOGB, int LOGN, int S, int K>
-__device__ __forceinline__ void fft_pass(float2* X, const float2* TW, const float2 (&W1)[8], int lane) {
+__device__ __forceinline__ void fft_pass(float2* X, const float2* TW, const float2 (&W1)[8], float* PWO, int lane) {
   constexpr int H = 1 << (S - 1), G = 1 << K, NG = (1 << LOGB) >> K;
   constexpr int UNR = LOGB >= 12 ? 1 : 4;                      // (4096 points: 16 points x 4 groups unrolled would not fit in VGPRs)
 #pragma unroll UNR
@@ -87,21 +89,43 @@ __device__ __forceinline__ void fft_pass(float2* X, const float2* TW, const floa
           else butterfly(v[c], v[c + (1 << t)], TW[spad(pos_t << (LOGN - S - t))]);
         }
       }
+      if (S + K - 1 == LOGN && PWO) {
 #pragma unroll
-      for (int c = 0; c < G; ++c) X[spad(base + c * H)] = v[c];
+        for (int c = 0; c < G; ++c) PWO[base + c * H] = __builtin_fmaf(v[c].x, v[c].x, v[c].y * v[c].y);
+      } else {
+#pragma unroll
+        for (int c = 0; c < G; ++c) X[spad(base + c * H)] = v[c];
+      }
     }
   }
   wave_sync();
 }
 template <int LOGB, int LOGN, int S>
-__device__ __forceinline__ void fft_passes(float2* X, const float2* TW, const float2 (&W1)[8], int lane) {
+__device__ __forceinline__ void fft_passes(float2* X, const float2* TW, const float2 (&W1)[8], float* PWO, int lane) {
   if constexpr (S <= LOGN) {
     // up to 4 stages per pass, but no more than leaves a group (2^K points) for each of the 64 lanes
     constexpr int KMAX = (LOGB - 6) >= 4 ? 4 : ((LOGB - 6) >= 2 ? (LOGB - 6) : 2);
     constexpr int K = (LOGN - S + 1) >= KMAX ? KMAX : (LOGN - S + 1);
-    fft_pass<LOGB, LOGN, S, K>(X, TW, W1, lane);
-    fft_passes<LOGB, LOGN, S + K>(X, TW, W1, lane);
+    fft_pass<LOGB, LOGN, S, K>(X, TW, W1, PWO, lane);
+    fft_passes<LOGB, LOGN, S + K>(X, TW, W1, PWO, lane);
   }
+}
+
+// First pass (stages 1..4) straight from registers: lane l holds the 16 points at bit-reversed-order positions 16 l .. 16 l + 15 of the
+// wave's 1024-point block (loaded from global memory in exactly that pattern: for a fixed register the 64 lanes read a permutation of
+// 64 consecutive samples, so the loads coalesce as before).  Saves the scatter store and the first pass's reads (16 + 16 LDS accesses
+// of 8 bytes per lane and frame).
+__device__ __forceinline__ void fft_first_pass_from_regs(float2 (&v)[16], float2* X, const float2 (&W1)[8], int lane) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      if ((c >> t) & 1) continue;
+      butterfly(v[c], v[c + (1 << t)], W1[(c & ((1 << t) - 1)) << (3 - t)]);
+    }
+#pragma unroll
+  for (int c = 0; c < 16; ++c) X[spad(16 * lane + c)] = v[c];
+  wave_sync();
 }
 
 // waves per workgroup, one block of frames each: 8, or 4 for 4096 points (LDS: 160 KiB per CU); the short-frame kernels fit
@@ -109,6 +133,8 @@ __device__ __forceinline__ void fft_passes(float2* X, const float2* TW, const fl
 constexpr int spec_nwf(int logn) { return logn <= 8 ? 16 : (logn <= 11 ? 8 : 4); }
 // points per wave and round: a frame, or for N < 1024 as many whole frames as make 1024 points (all 64 lanes stay busy)
 constexpr int spec_logb(int logn) { return logn < 10 ? 10 : logn; }
+// kernels whose LDS has room for a separate power region (NWF blocks of floats) fuse the power into the last FFT pass
+constexpr bool spec_fusep(int logn) { return logn == 9 || logn == 10; }
 
 template <int LOGN>
 __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
@@ -121,7 +147,10 @@ __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
   float2* TW = reinterpret_cast<float2*>(spec_smem);           // N/2 twiddles at TW[spad(t)]
   const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
   float2* X = reinterpret_cast<float2*>(spec_smem) + NPT + wv * NPX;   // this wave's block: point i at X[spad(i)]
-  const float* PW = reinterpret_cast<const float*>(reinterpret_cast<float2*>(spec_smem) + NPT);   // wave w's powers at PW[2 NPX w + i]
+  constexpr bool FUSEP = spec_fusep(LOGN);
+  constexpr int PWS = FUSEP ? B : 2 * NPX;                     // floats between the power blocks of consecutive waves
+  float* const PWsep = reinterpret_cast<float*>(reinterpret_cast<float2*>(spec_smem) + NPT + NWF * NPX);   // (FUSEP) separate region
+  const float* PW = FUSEP ? PWsep : reinterpret_cast<const float*>(reinterpret_cast<float2*>(spec_smem) + NPT);   // wave w's powers at PW[PWS w + i]
   const uint32_t stream = blockIdx.x;
   for (int i = tid; i < N / 2; i += NT) TW[spad(i)] = p.tw[i];
   float2 W1[8];                                                // the first pass's twiddles W16^k = tw[k N/16] (wave-uniform)
@@ -130,11 +159,17 @@ __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
   // up to 1024 points the lane keeps its window values and the next round's samples in registers; longer frames would
   // need > 256 VGPRs for that, so they read the window through the cache and load their samples when they need them
   constexpr bool REGS = (LOGB <= 10) && (NWF <= 8);
+  static_assert(!REGS || PPL == 16, "the register path holds one 16-point first-pass group per lane");
+  // (REGS) register q of a lane holds the point at bit-reversed-order position u = 16 lane + q of the block = sample regs_sample(q)
+  auto regs_sample = [&](int q) -> int {
+    const uint32_t u = (uint32_t)(16 * lane + q);
+    return (int)((u & ~(uint32_t)(N - 1)) | (__brev(u & (uint32_t)(N - 1)) >> (32 - LOGN)));
+  };
   constexpr int PR = REGS ? PPL : 1;
   float wv_win[PR], S[PPT];
   if constexpr (REGS) {
 #pragma unroll
-    for (int q = 0; q < PPL; ++q) wv_win[q] = p.win[(lane + 64 * q) & (N - 1)];
+    for (int q = 0; q < PPL; ++q) wv_win[q] = p.win[regs_sample(q) & (N - 1)];
   }
 #pragma unroll
   for (int q = 0; q < PPT; ++q) S[q] = 0.0f;
@@ -146,7 +181,7 @@ __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
     if constexpr (REGS) {
 #pragma unroll
       for (int q = 0; q < PPL; ++q)
-        cur[q] = spec_typed_load_xy(rsrc, (int)(sbase + 2u * (f * (uint32_t)N + (uint32_t)(lane + 64 * q))), 0, 0);
+        cur[q] = spec_typed_load_xy(rsrc, (int)(sbase + 2u * (f * (uint32_t)N + (uint32_t)regs_sample(q))), 0, 0);
     }
   };
   if ((uint32_t)(wv * FPW) < p.F) fetch((uint32_t)(wv * FPW));
@@ -154,13 +189,10 @@ __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
   for (uint32_t f0 = 0; f0 < p.F; f0 += FPR) {                 // a round: frames f0 .. f0+FPR-1, FPW consecutive ones per wave
     const uint32_t f = f0 + (uint32_t)(wv * FPW);
     if (f < p.F) {                                             // (wave-uniform; frames past F in the block are computed, not summed)
+      float2 v1[16];
       if constexpr (REGS) {
 #pragma unroll
-        for (int q = 0; q < PPL; ++q) {
-          const int n = lane + 64 * q;                         // sample n of the block = sample n mod N of frame n / N
-          const uint32_t u = (uint32_t)(n & ~(N - 1)) | (__brev((uint32_t)(n & (N - 1))) >> (32 - LOGN));
-          X[spad((int)u)] = make_float2((cur[q].x - 127.5f) * wv_win[q], (cur[q].y - 127.5f) * wv_win[q]);
-        }
+        for (int q = 0; q < 16; ++q) v1[q] = make_float2((cur[q].x - 127.5f) * wv_win[q], (cur[q].y - 127.5f) * wv_win[q]);
       } else {
 #pragma unroll 8
         for (int q = 0; q < PPL; ++q) {
@@ -171,24 +203,31 @@ __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
         }
       }
       if (f + FPR < p.F) fetch(f + FPR);                       // next round's bytes: in flight during this block's FFTs
-      wave_sync();
       // DIT stages in passes of up to 4 stages, each pass entirely in registers (see fft_pass)
-      fft_passes<LOGB, LOGN, 1>(X, TW, W1, lane);
-      // powers of this block, written over the start of its own region (PW[2 NPX wv + i]) in blocks of 16 points per lane:
-      // block b overwrites float slots [1024 b, 1024 b + 1024), i.e. float2 slots below 512 (b + 1) — points already consumed
-      // (a point's padded slot is never below its index)
-      constexpr int PB = PPL < 16 ? PPL : 16;
-      for (int q0 = 0; q0 < PPL; q0 += PB) {
-        float pw[PB];
+      if constexpr (REGS) {
+        fft_first_pass_from_regs(v1, X, W1, lane);
+        fft_passes<LOGB, LOGN, 5>(X, TW, W1, FUSEP ? PWsep + wv * B : nullptr, lane);
+      } else {
+        wave_sync();
+        fft_passes<LOGB, LOGN, 1>(X, TW, W1, FUSEP ? PWsep + wv * B : nullptr, lane);
+      }
+      if constexpr (!FUSEP) {
+        // powers of this block, written over the start of its own region (PW[2 NPX wv + i]) in blocks of 16 points per lane:
+        // block b overwrites float slots [1024 b, 1024 b + 1024), i.e. float2 slots below 512 (b + 1) — points already consumed
+        // (a point's padded slot is never below its index)
+        constexpr int PB = PPL < 16 ? PPL : 16;
+        for (int q0 = 0; q0 < PPL; q0 += PB) {
+          float pw[PB];
 #pragma unroll
-        for (int q = 0; q < PB; ++q) {
-          const float2 v = X[spad(lane + 64 * (q0 + q))];
-          pw[q] = __builtin_fmaf(v.x, v.x, v.y * v.y);
+          for (int q = 0; q < PB; ++q) {
+            const float2 v = X[spad(lane + 64 * (q0 + q))];
+            pw[q] = __builtin_fmaf(v.x, v.x, v.y * v.y);
+          }
+          wave_sync();
+#pragma unroll
+          for (int q = 0; q < PB; ++q) reinterpret_cast<float*>(X)[lane + 64 * (q0 + q)] = pw[q];
+          wave_sync();
         }
-        wave_sync();
-#pragma unroll
-        for (int q = 0; q < PB; ++q) reinterpret_cast<float*>(X)[lane + 64 * (q0 + q)] = pw[q];
-        wave_sync();
       }
     }
     __syncthreads();
@@ -199,7 +238,7 @@ __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
     for (int q = 0; q < PPT; ++q) {
       const int k = tid + NT * q;
       if (k < N)
-        for (uint32_t o = 0; o < nfr; ++o) S[q] = S[q] + PW[2 * NPX * (o / FPW) + (o % FPW) * N + k];
+        for (uint32_t o = 0; o < nfr; ++o) S[q] = S[q] + PW[PWS * (o / FPW) + (o % FPW) * N + k];
     }
     __syncthreads();                                           // the blocks are rewritten by the next round
   }
@@ -277,7 +316,8 @@ int sdrfm_spectrum_create(const sdrfm_spectrum_config* cfg, sdrfm_spectrum_t** o
   h->device = cfg->device; h->logn = logn;
   h->max_bytes = cfg->max_bytes_per_call ? cfg->max_bytes_per_call : (1u << 20);
   h->kernel = pick_kernel(logn);
-  h->lds_bytes = ((size_t)(spad((int)cfg->nfft / 2 - 1) + 1) + (size_t)spec_nwf((int)logn) * (size_t)(spad((1 << spec_logb((int)logn)) - 1) + 1)) * sizeof(float2);
+  h->lds_bytes = ((size_t)(spad((int)cfg->nfft / 2 - 1) + 1) + (size_t)spec_nwf((int)logn) * (size_t)(spad((1 << spec_logb((int)logn)) - 1) + 1)) * sizeof(float2) +
+                 (spec_fusep((int)logn) ? (size_t)spec_nwf((int)logn) * ((size_t)1 << spec_logb((int)logn)) * sizeof(float) : 0);
 #define CR(expr) do { if ((expr) != hipSuccess) { sfree(h); return SDRFM_ENOMEM; } } while (0)
   CR(hipSetDevice(h->device));
   if (h->lds_bytes > 64 * 1024 &&
