@@ -133,7 +133,8 @@ __device__ __forceinline__ void fft_first_pass_from_regs(float2 (&v)[16], float2
 constexpr int spec_nwf(int logn) { return logn <= 8 ? 16 : (logn <= 11 ? 8 : 4); }
 // points per wave and round: a frame, or for N < 1024 as many whole frames as make 1024 points (all 64 lanes stay busy)
 constexpr int spec_logb(int logn) { return logn < 10 ? 10 : logn; }
-// kernels whose LDS has room for a separate power region (NWF blocks of floats) fuse the power into the last FFT pass
+// kernels whose LDS has room for two separate power regions (NWF blocks of floats each, written alternately) fuse the power into the
+// last FFT pass and need one workgroup barrier per round instead of two
 constexpr bool spec_fusep(int logn) { return logn == 9 || logn == 10; }
 
 template <int LOGN>
@@ -186,7 +187,8 @@ __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
   };
   if ((uint32_t)(wv * FPW) < p.F) fetch((uint32_t)(wv * FPW));
   __syncthreads();                                             // TW visible
-  for (uint32_t f0 = 0; f0 < p.F; f0 += FPR) {                 // a round: frames f0 .. f0+FPR-1, FPW consecutive ones per wave
+  uint32_t par = 0;                                            // (FUSEP) which of the two power regions this round writes
+  for (uint32_t f0 = 0; f0 < p.F; f0 += FPR, par ^= 1u) {      // a round: frames f0 .. f0+FPR-1, FPW consecutive ones per wave
     const uint32_t f = f0 + (uint32_t)(wv * FPW);
     if (f < p.F) {                                             // (wave-uniform; frames past F in the block are computed, not summed)
       float2 v1[16];
@@ -206,7 +208,7 @@ __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
       // DIT stages in passes of up to 4 stages, each pass entirely in registers (see fft_pass)
       if constexpr (REGS) {
         fft_first_pass_from_regs(v1, X, W1, lane);
-        fft_passes<LOGB, LOGN, 5>(X, TW, W1, FUSEP ? PWsep + wv * B : nullptr, lane);
+        fft_passes<LOGB, LOGN, 5>(X, TW, W1, FUSEP ? PWsep + par * (NWF * B) + wv * B : nullptr, lane);
       } else {
         wave_sync();
         fft_passes<LOGB, LOGN, 1>(X, TW, W1, FUSEP ? PWsep + wv * B : nullptr, lane);
@@ -238,9 +240,10 @@ __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
     for (int q = 0; q < PPT; ++q) {
       const int k = tid + NT * q;
       if (k < N)
-        for (uint32_t o = 0; o < nfr; ++o) S[q] = S[q] + PW[PWS * (o / FPW) + (o % FPW) * N + k];
+        for (uint32_t o = 0; o < nfr; ++o) S[q] = S[q] + PW[(FUSEP ? par * (NWF * B) : 0u) + PWS * (o / FPW) + (o % FPW) * N + k];
     }
-    __syncthreads();                                           // the blocks are rewritten by the next round
+    if constexpr (!FUSEP) __syncthreads();                     // the blocks are rewritten by the next round (FUSEP: the next round writes
+                                                               // the OTHER power region; the barrier above orders this sum before the round after)
   }
 #pragma unroll
   for (int q = 0; q < PPT; ++q) {
@@ -317,7 +320,7 @@ int sdrfm_spectrum_create(const sdrfm_spectrum_config* cfg, sdrfm_spectrum_t** o
   h->max_bytes = cfg->max_bytes_per_call ? cfg->max_bytes_per_call : (1u << 20);
   h->kernel = pick_kernel(logn);
   h->lds_bytes = ((size_t)(spad((int)cfg->nfft / 2 - 1) + 1) + (size_t)spec_nwf((int)logn) * (size_t)(spad((1 << spec_logb((int)logn)) - 1) + 1)) * sizeof(float2) +
-                 (spec_fusep((int)logn) ? (size_t)spec_nwf((int)logn) * ((size_t)1 << spec_logb((int)logn)) * sizeof(float) : 0);
+                 (spec_fusep((int)logn) ? 2 * (size_t)spec_nwf((int)logn) * ((size_t)1 << spec_logb((int)logn)) * sizeof(float) : 0);   // two power regions
 #define CR(expr) do { if ((expr) != hipSuccess) { sfree(h); return SDRFM_ENOMEM; } } while (0)
   CR(hipSetDevice(h->device));
   if (h->lds_bytes > 64 * 1024 &&
