@@ -1400,17 +1400,17 @@ struct FastVariant {
   uint32_t seg;                      // design S: samples per lane segment (0 otherwise)
 };
 #ifdef SDRFM_DEV
-#define SDRFM_FAST(T_, D_, R_) { 'a', T_, D_, R_, 0, 0, {k_fast<T_, D_, R_, 0>, k_fast<T_, D_, R_, 1>, k_fast<T_, D_, R_, 2>, k_fast<T_, D_, R_, 3>, k_fast<T_, D_, R_, 4>, k_fast<T_, D_, R_, 5>, k_fast<T_, D_, R_, 6>, k_fast<T_, D_, R_, 7>}, (uint32_t)fast_xbytes(T_, D_, R_) }
-#define SDRFM_FAST_LITE(T_, D_, R_) { 'a', T_, D_, R_, 0, 0, {k_fast<T_, D_, R_, 0>, k_fast<T_, D_, R_, 1>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, (uint32_t)fast_xbytes(T_, D_, R_) }
-#define SDRFM_FASTB2(T_, D_, R_, TA_, DA_) { 'b', T_, D_, R_, TA_, DA_, {k_fastb<T_, D_, R_, TA_, DA_, 0>, k_fastb<T_, D_, R_, TA_, DA_, 1>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, (uint32_t)fastb_xbytes(T_, D_, R_) }
+#define SDRFM_FAST(T_, D_, R_) { 'a', T_, D_, R_, 0, 0, {k_fast<T_, D_, R_, 0>, k_fast<T_, D_, R_, 1>, k_fast<T_, D_, R_, 2>, k_fast<T_, D_, R_, 3>, k_fast<T_, D_, R_, 4>, k_fast<T_, D_, R_, 5>, k_fast<T_, D_, R_, 6>, k_fast<T_, D_, R_, 7>}, (uint32_t)fast_xbytes(T_, D_, R_), 0 }
+#define SDRFM_FAST_LITE(T_, D_, R_) { 'a', T_, D_, R_, 0, 0, {k_fast<T_, D_, R_, 0>, k_fast<T_, D_, R_, 1>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, (uint32_t)fast_xbytes(T_, D_, R_), 0 }
+#define SDRFM_FASTB2(T_, D_, R_, TA_, DA_) { 'b', T_, D_, R_, TA_, DA_, {k_fastb<T_, D_, R_, TA_, DA_, 0>, k_fastb<T_, D_, R_, TA_, DA_, 1>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, (uint32_t)fastb_xbytes(T_, D_, R_), 0 }
 // headline shape only, timing ablations with wrong results (SDRFM_ABLATE=2..5): [2] halo samples not converted, [3] no sample
 // converted, [4] no discriminator, [5] no conversion, no FIR, no discriminator (staging, LDS window reads and audio stage remain)
-#define SDRFM_FASTB2_ABL(T_, D_, R_, TA_, DA_) { 'b', T_, D_, R_, TA_, DA_, {k_fastb<T_, D_, R_, TA_, DA_, 0>, k_fastb<T_, D_, R_, TA_, DA_, 1>, k_fastb<T_, D_, R_, TA_, DA_, 2>, k_fastb<T_, D_, R_, TA_, DA_, 3>, k_fastb<T_, D_, R_, TA_, DA_, 4>, k_fastb<T_, D_, R_, TA_, DA_, 5>, nullptr, nullptr}, (uint32_t)fastb_xbytes(T_, D_, R_) }
+#define SDRFM_FASTB2_ABL(T_, D_, R_, TA_, DA_) { 'b', T_, D_, R_, TA_, DA_, {k_fastb<T_, D_, R_, TA_, DA_, 0>, k_fastb<T_, D_, R_, TA_, DA_, 1>, k_fastb<T_, D_, R_, TA_, DA_, 2>, k_fastb<T_, D_, R_, TA_, DA_, 3>, k_fastb<T_, D_, R_, TA_, DA_, 4>, k_fastb<T_, D_, R_, TA_, DA_, 5>, nullptr, nullptr}, (uint32_t)fastb_xbytes(T_, D_, R_), 0 }
 #else   // product library: the result-correct kernel of every shape and nothing else
 #define SDRFM_FASTB2(T_, D_, R_, TA_, DA_) SDRFM_FASTB2_LITE(T_, D_, R_, TA_, DA_)
 #define SDRFM_FASTB2_ABL(T_, D_, R_, TA_, DA_) SDRFM_FASTB2_LITE(T_, D_, R_, TA_, DA_)
 #endif
-#define SDRFM_FASTB2_LITE(T_, D_, R_, TA_, DA_) { 'b', T_, D_, R_, TA_, DA_, {k_fastb<T_, D_, R_, TA_, DA_, 0>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, (uint32_t)fastb_xbytes(T_, D_, R_) }
+#define SDRFM_FASTB2_LITE(T_, D_, R_, TA_, DA_) { 'b', T_, D_, R_, TA_, DA_, {k_fastb<T_, D_, R_, TA_, DA_, 0>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, (uint32_t)fastb_xbytes(T_, D_, R_), 0 }
 #define SDRFM_FASTB(T_, D_, R_) SDRFM_FASTB2(T_, D_, R_, 32, 5)
 #define SDRFM_STREAM(T_, D_, S_, NB_, TA_, DA_) { 's', T_, D_, S_, TA_, DA_, {k_stream<T_, D_, S_, NB_, TA_, DA_>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, 2u * 64u * 128u, (uint32_t)(NB_) * (S_) * (D_) }
 const FastVariant kFastVariants[] = {
