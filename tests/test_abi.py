@@ -113,6 +113,11 @@ def test_product_library_holds_no_development_kernels_or_environment_knobs(pkg):
                  b"SDRFM_WAVES_PER_CU", b"SDRFM_MIN_SUBTILES", b"SDRFM_NO_PRIO", b"SDRFM_NO_FOLD", b"SDRFM_NO_ZEROCOPY",
                  b"SDRFM_WBFM_GENERIC", b"SDRFM_WBFM_NT", b"SDRFM_END_PRIO", b"SDRFM_NO_STREAM", b"SDRFM_STREAM_PROFILE", b"SDRFM_WBFM_PROFILE"):
         assert knob not in blob, knob
+    # no development export, no getenv at all
+    dyn = subprocess.run(["nm", "-D", path], capture_output=True, text=True, check=True).stdout
+    assert "dev_read_debug" not in dyn and " getenv" not in dyn and "secure_getenv" not in dyn, "the product library reads no environment variable"
     dev = pkg.library_path(dev=True)
     if os.path.exists(dev):
         assert b"SDRFM_PHASE_PROFILE" in open(dev, "rb").read()
+        ddyn = subprocess.run(["nm", "-D", dev], capture_output=True, text=True, check=True).stdout
+        assert "sdrfm_dev_read_debug" in ddyn and "sdrfm_wbfm_dev_read_debug" in ddyn
