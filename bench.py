@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--nfft", type=int, default=1024, help="spectrum workload: FFT length")
     ap.add_argument("--dev-library", action="store_true", help="fm workload: load csrc/libsdrfm_dev.so (honours the SDRFM_* development "
                     "knobs, e.g. SDRFM_NO_STREAM=1 for design B); the reported line then says so and is not a product figure")
+    ap.add_argument("--bit-exact", action="store_true", help="fm workload: SDRFM_CFG_BIT_EXACT handle — the fmaf-chain kernels only (design S "
+                    "instead of the matrix-pipe design Q); a comparison figure, labelled as such")
     ap.add_argument("--end-to-end", action="store_true",
                     help="fm workload: every step also scatters the IQ batch from rank 0 to all ranks and gathers the audio back "
                          "over RCCL (SURVEY 8e C1/C2); reported separately from the compute-only default")
@@ -132,7 +134,18 @@ def cpu_baseline(pkg, h, g, iq_host, seconds, threads):
         return done * nsamp / dt / 1e6, done
 
     v1, n1 = run(1, seconds)
-    out = {"value": round(v1, 3), "unit": "MSamples/s", "cores": 1, "kind": "port",
+    cpu_model, compiler = "unknown", "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next(ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name"))
+    except Exception:
+        pass
+    try:
+        compiler = subprocess.run(["gcc", "--version"], capture_output=True, text=True).stdout.splitlines()[0].strip()
+    except Exception:
+        pass
+    out = {"value": round(v1, 3), "unit": "MSamples/s", "cores": 1, "kind": "port", "cpu_model": cpu_model,
+           "host_cores": os.cpu_count() or 1, "compiler": compiler, "compiler_flags": "-O2 -std=c99 -ffp-contract=off -mfma (oracle/Makefile)",
            "sample": "%d stream-chunks of the workload (%.1f s x 2.4 MS/s each), scalar-C oracle, 1 thread, %.0f s" % (n1, nsamp / 2.4e6, seconds)}
     if threads > 1:
         vn, nn = run(threads, max(3.0, seconds / 2))
@@ -239,7 +252,7 @@ def main():
     D, Da = 10, 5
 
     dm = pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, fir_decim=D, audio_decim=Da, n_streams=ns, device=local_rank,
-                                  dev_library=args.dev_library))
+                                  dev_library=args.dev_library, bit_exact=args.bit_exact))
     stream = torch.cuda.Stream()
     dm.set_stream(stream.cuda_stream)
     nb = pick_batches(args, ns * nbytes)
@@ -282,6 +295,12 @@ def main():
     elapsed, kernel_ms_avg = timed(torch, dist, use_dist, stream, step_rot, args.steps)
     n_audio = last["n"]
     kernel_ms = per_launch_events(torch, stream, step_rot, min(args.steps, 20))
+    # sustained figure: at least 300 back-to-back steps (a short timed region runs at the boost clock)
+    if args.steps >= 300 or e2e is not None:
+        kernel_ms_sus, sus_steps = kernel_ms_avg, args.steps
+    else:
+        sus_steps = 300
+        _, kernel_ms_sus = timed(torch, dist, use_dist, stream, step_rot, sus_steps)
     # second, labelled figure: ONE resident input batch (fits the 256 MiB Infinity Cache) — what round 1 reported as `value`
     res_steps = min(args.steps, 100)
     for i in range(min(args.warmup, 10)):
@@ -326,6 +345,8 @@ def main():
                        "GB_per_s_input": round(value * 2e6 / 1e9, 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "frac_sustained": round(alg_bytes / (kernel_ms_sus * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                         "sustained_steps": sus_steps, "kernel_ms_sustained": round(kernel_ms_sus, 4),
                          "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
                          "traffic_source": ("profiles/%s (rocprofv3 --pmc TCC_EA0 read/write request passes at commit %s; same kernel, same workload size)" % (traffic["file"], traffic.get("commit", "?"))) if traffic else None,
                          "kernel": dm.kernel_name, "kernel_ms_avg": round(kernel_ms_avg, 4),
@@ -334,6 +355,8 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes},
             "gen_seconds": round(t_gen, 2),
         }
+        if args.bit_exact:
+            res["handle"] = "SDRFM_CFG_BIT_EXACT (fmaf-chain kernels only: NOT the default path)"
         if args.dev_library:
             res["library"] = "libsdrfm_dev.so (development build: NOT the product figure)"
         if elapsed_res is not None:

@@ -1,0 +1,69 @@
+/*
+ * qtaps.c — design Q, host side: the channel FIR's taps as i8 matrix-pipe operands (plain C, no GPU).
+ *
+ * Design Q evaluates stage K2 (DESIGN.md "Frozen spec"; FIR convention: CMSIS/core/arm_math.h:3291-3331 of the reference, byte
+ * format: Class/RTLSDR/Inc/usbh_rtlsdr.h:165-173) on the i8 matrix pipe of gfx950 (v_mfma_i32_16x16x64_i8):
+ *
+ *   y[m] = q * (S0 + 2^8 S1 + 2^16 S2) + 0.5 * sum(h),     S_t = sum_k digit_t(H[k]) * (byte - 128),   H[k] = round(h[k] / q)
+ *
+ * The input bytes are the B operand as they are (byte XOR 0x80 = byte - 128 as i8; the spec's x = byte - 127.5 is that plus 0.5,
+ * which the constant restores); interleaved I/Q stays the K dimension.  The A operand is a Toeplitz slice of the taps: one MFMA
+ * tile computes a BLOCK of 8 consecutive outputs (16 rows: row 2 o + comp, comp 0 = I, 1 = Q) for 16 blocks (columns) at once,
+ * from each block's WINDOW of 32 D bytes = the block's own 16 D bytes and the 16 D bytes before them, K-chunked 64 bytes at a
+ * time.  Window sample w (0 .. 16 D - 1, byte pair 2 w, 2 w + 1) meets output o through tap k = 8 D + D o + D - 1 - w.
+ *
+ * Operand layout (verified on the device by tools/ubench/ubench11.hip): lane l supplies row (l & 15), bytes K = 16 (l >> 4) .. +15.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "sdrfm_q_host.h"
+
+int sdrfm_q_build(const float* h, uint32_t T, uint32_t D, int8_t* A, float* q_out, float* cst_out, uint32_t* first_chunk) {
+  if (!h || !A || !q_out || !cst_out || !first_chunk) return -1;
+  if (D < 2 || (D & 1u) || D > SDRFM_Q_MAX_D || T < 1 || T > 9 * D) return -1;
+  const uint32_t nch = D / 2;
+  double hmax = 0.0, hsum = 0.0;
+  for (uint32_t k = 0; k < T; ++k) {
+    if (!isfinite(h[k])) return -1;
+    if (fabs((double)h[k]) > hmax) hmax = fabs((double)h[k]);
+    hsum += (double)h[k];
+  }
+  if (hmax == 0.0) return -1;
+  const double q = hmax / (double)SDRFM_Q_HMAX;
+  const float qf = (float)q;
+  if (!(qf > 0.0f) || !isfinite(65536.0f * qf)) return -1;        /* taps so small / large that the scale leaves fp32 */
+  int8_t dig[SDRFM_Q_DIGITS][9 * SDRFM_Q_MAX_D];
+  for (uint32_t k = 0; k < T; ++k) {
+    /* quantise against the fp32 scale the device multiplies with, so that q_f32 * H is the best fixed-point image of h[k] */
+    long long H = llround((double)h[k] / (double)qf);
+    if (H > SDRFM_Q_HMAX) H = SDRFM_Q_HMAX;
+    if (H < -SDRFM_Q_HMAX) H = -SDRFM_Q_HMAX;
+    for (int t = 0; t < SDRFM_Q_DIGITS; ++t) {                     /* balanced base-256 digits, each in [-128, 127] */
+      long long d = ((H + 128) % 256 + 256) % 256 - 128;
+      dig[t][k] = (int8_t)d;
+      H = (H - d) / 256;
+    }
+    if (H != 0) return -1;
+  }
+  memset(A, 0, (size_t)nch * SDRFM_Q_DIGITS * 64 * 16);
+  uint32_t c0 = nch;
+  for (uint32_t c = 0; c < nch; ++c)
+    for (uint32_t l = 0; l < 64; ++l)
+      for (uint32_t p = 0; p < 16; ++p) {
+        const uint32_t row = l & 15u, kb = 64 * c + 16 * (l >> 4) + p;   /* window byte */
+        const uint32_t o = row >> 1, comp = row & 1u;
+        if ((kb & 1u) != comp) continue;
+        const int k = (int)(8 * D + D * o + D - 1) - (int)(kb >> 1);
+        if (k < 0 || k >= (int)T) continue;
+        for (int t = 0; t < SDRFM_Q_DIGITS; ++t) {
+          A[(((size_t)c * SDRFM_Q_DIGITS + t) * 64 + l) * 16 + p] = dig[t][k];
+          if (dig[t][k] != 0 && c < c0) c0 = c;
+        }
+      }
+  *q_out = qf;
+  *cst_out = (float)(0.5 * hsum);
+  *first_chunk = c0;
+  return 0;
+}

@@ -31,6 +31,7 @@
 
 #include "../../include/sdrfm.h"
 #include "sdrfm_math.h"
+#include "sdrfm_q.h"
 
 typedef float f2_t __attribute__((ext_vector_type(2)));
 typedef float f4_t __attribute__((ext_vector_type(4)));
@@ -1087,12 +1088,8 @@ __device__ __forceinline__ void stream_body(RD&& read, int ub, FW&& wait, FR&& r
           dn[s1] = d2.y;
           ysave = acc[s0];
           prev = acc[s1];
-        } else if constexpr (MODE == SBODY_HEADB && s1 > NH) {
-        } else if constexpr (MODE == SBODY_HEADB && s1 == NH) {    // (NH odd): the pair (y[NH-1], y[NH] kept by FIRST)
-          const f2_t d2 = discriminate_pair(acc[s0], prev, ysave);
-          dn[s0] = d2.x;
-          dn[s1] = d2.y;
-        } else {
+        } else if constexpr (MODE == SBODY_HEADB && s1 >= NH) {    // (the pair that closes at output NH lies beyond HEADB's last
+        } else {                                                   // chunk: it is evaluated after the loop, below)
           const f2_t d2 = discriminate_pair(acc[s0], prev, acc[s1]);
           dn[s0] = d2.x;
           dn[s1] = d2.y;
@@ -1106,6 +1103,11 @@ __device__ __forceinline__ void stream_body(RD&& read, int ub, FW&& wait, FR&& r
   if constexpr (MODE == SBODY_HEADB && (NH % 2) == 0) {        // d[NH] = K3(y[NH] kept by FIRST | y[NH-1])
     const f2_t d2 = discriminate_pair(ysave, prev, ysave);
     dn[NH] = d2.x;
+  }
+  if constexpr (MODE == SBODY_HEADB && (NH % 2) == 1) {        // NH odd (T = 32: NH = 3): the loop ends before the phase that would close
+    const f2_t d2 = discriminate_pair(acc[NH - 1], prev, ysave);   // the pair (y[NH-1], y[NH]): prev is y[NH-2] (y[-1] when NH = 1), ysave is
+    dn[NH - 1] = d2.x;                                          // y[NH], kept by FIRST
+    dn[NH] = d2.y;
   }
 }
 
@@ -1477,6 +1479,11 @@ struct sdrfm {
   char kernel_name[64];
   char generic_name[64];
   char fast_name[64];
+  // design Q (matrix-pipe FIR, sdrfm_q.hip): operand tables on the device, scale / offset, first K-chunk that holds taps
+  int8_t* d_qA;
+  float q_scale, q_cst;
+  uint32_t q_c0, q_nslot, q_waves_per_cu;
+  char fast_q_name[64];
 };
 
 static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nbytes, float* d_audio, size_t audio_stride,
@@ -1513,6 +1520,7 @@ static void free_handle(sdrfm* h) {
   if (h->zc_audio) (void)hipHostFree(h->zc_audio);
   if (h->d_audio) (void)hipFree(h->d_audio);
   if (h->d_dbg) (void)hipFree(h->d_dbg);
+  if (h->d_qA) (void)hipFree(h->d_qA);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   free(const_cast<float*>(h->cfg.fir_coeffs));
   free(const_cast<float*>(h->cfg.audio_coeffs));
@@ -1567,7 +1575,7 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
   if (!out) return SDRFM_EINVAL;
   *out = nullptr;
   if (!cfg || cfg->struct_size != sizeof(sdrfm_config)) return SDRFM_EINVAL;
-  if (!cfg->n_streams || !cfg->fir_coeffs || !cfg->audio_coeffs || (cfg->flags & ~(SDRFM_CFG_FORCE_GENERIC | SDRFM_CFG_NO_ZEROCOPY))) return SDRFM_EINVAL;
+  if (!cfg->n_streams || !cfg->fir_coeffs || !cfg->audio_coeffs || (cfg->flags & ~(SDRFM_CFG_FORCE_GENERIC | SDRFM_CFG_NO_ZEROCOPY | SDRFM_CFG_BIT_EXACT))) return SDRFM_EINVAL;
   if (!cfg->fir_taps || cfg->fir_taps > SDRFM_MAX_TAPS || !cfg->audio_taps || cfg->audio_taps > SDRFM_MAX_TAPS)
     return SDRFM_EINVAL;
   if (!cfg->fir_decim || cfg->fir_decim > SDRFM_MAX_DECIM || !cfg->audio_decim || cfg->audio_decim > SDRFM_MAX_DECIM)
@@ -1665,6 +1673,29 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
       h->fast_s = &v;
       h->n_cu = (uint32_t)prop.multiProcessorCount;
       snprintf(h->fast_s_name, sizeof(h->fast_s_name), "fast-s T%u D%u S%u L%u Ta%u Da%u", v.T, v.D, v.R, v.seg, v.Ta, v.Da);
+    }
+    // design Q: K2 on the i8 matrix pipe (sdrfm_q.hip).  Not bit-identical to the fmaf-chain kernels (within 7e-7 of the
+    // oracle, tolerance 1e-5), so a handle created with SDRFM_CFG_BIT_EXACT never selects it.
+    if (!(cfg->flags & SDRFM_CFG_BIT_EXACT) && cfg->fir_decim == SDRFM_Q_D && cfg->audio_taps == SDRFM_Q_TA &&
+        cfg->audio_decim == SDRFM_Q_DA && cfg->fir_taps <= 9 * SDRFM_Q_D) {
+      int8_t* tab = (int8_t*)malloc((SDRFM_Q_D / 2) * SDRFM_Q_DIGITS * 64 * 16);
+      float qs = 0.f, qc = 0.f;
+      uint32_t c0 = 0;
+      if (tab && sdrfm_q_build(hc, cfg->fir_taps, cfg->fir_decim, tab, &qs, &qc, &c0) == 0 &&
+          hipMalloc(&h->d_qA, (SDRFM_Q_D / 2) * SDRFM_Q_DIGITS * 64 * 16) == hipSuccess &&
+          hipMemcpy(h->d_qA, tab, (SDRFM_Q_D / 2) * SDRFM_Q_DIGITS * 64 * 16, hipMemcpyHostToDevice) == hipSuccess) {
+        h->q_scale = qs; h->q_cst = qc; h->q_c0 = c0 > 2 ? 2 : c0;
+        h->q_nslot = 5; h->q_waves_per_cu = 12;
+#ifdef SDRFM_DEV
+        if (const char* e = getenv("SDRFM_Q_NSLOT")) h->q_nslot = (uint32_t)atoi(e);
+        if (const char* e = getenv("SDRFM_Q_WAVES_PER_CU")) h->q_waves_per_cu = (uint32_t)atoi(e);
+        if (getenv("SDRFM_NO_Q")) { (void)hipFree(h->d_qA); h->d_qA = nullptr; }
+#endif
+        h->n_cu = (uint32_t)prop.multiProcessorCount;
+        snprintf(h->fast_q_name, sizeof(h->fast_q_name), "fast-q T%u D%u Ta%u Da%u %s", cfg->fir_taps, cfg->fir_decim, cfg->audio_taps,
+                 cfg->audio_decim, sdrfm_q_kernel_symbol(h->q_c0, h->q_nslot));
+      } else if (h->d_qA) { (void)hipFree(h->d_qA); h->d_qA = nullptr; }
+      free(tab);
     }
     for (int pass = 0; pass < 3 && !h->fast; ++pass)
     for (const FastVariant& v : kFastVariants) {
@@ -1814,7 +1845,29 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
                          // the call fills the machine (>= one wave per SIMD); a single dongle's call is served faster by design B,
                          // which cuts its segments as short as the call needs
                          (uint64_t)c.n_streams * ((N / h->fast_s->seg + 62) / 63) >= 4ull * h->n_cu;
-  if (stream_ok) {
+  // Design Q serves whole numbers of audio periods at decimator phase 0 on 16-byte aligned rows, when the call holds enough steps
+  // (128 outputs each) to give every resident wave a run of at least four; the first call after a reset must be long enough
+  // that the state it hands over holds no output computed from the (inexpressible in bytes) zero history.
+  const uint32_t q_steps = (M + SDRFM_Q_STEP_OUT - 1) / SDRFM_Q_STEP_OUT;
+  const bool q_ok = h->d_qA && A > 0 && h->phase_x == 0 && h->phase_d == 0 && (N % (SDRFM_Q_D * SDRFM_Q_DA * 8u)) == 0 &&
+                    ((uintptr_t)d_iq % 16 == 0) && (iq_stride % 16 == 0) && N < (1u << 30) && M >= c.audio_taps &&
+                    (h->n_seen + 1 >= c.fir_taps || M >= y_aff + c.audio_taps) &&
+                    (uint64_t)c.n_streams * q_steps >= 8ull * h->n_cu;
+  if (q_ok) {
+    SdrfmQParams q;
+    q.iq = d_iq; q.iq_stride = iq_stride; q.audio = d_audio; q.audio_stride = audio_stride;
+    q.yprev_in = p.yprev_in; q.yprev_out = p.yprev_out; q.hist_d_in = p.hist_d_in; q.hist_d_out = p.hist_d_out;
+    q.hist_b_in = p.hist_b_in; q.hist_b_out = p.hist_b_out; q.hist_x_out = p.hist_x_out;
+    q.A = h->d_qA; q.g = h->d_g; q.q0 = h->q_scale; q.q2 = 65536.0f * h->q_scale; q.cst = h->q_cst;
+    q.T = c.fir_taps; q.N = N; q.M = M; q.A_out = A; q.steps_total = q_steps; q.n_streams = c.n_streams; q.dbg = nullptr;
+    // runs (waves) per stream: fill the machine once, every run at least four owned steps
+    uint32_t runs = (h->q_waves_per_cu * h->n_cu) / c.n_streams;
+    if (runs > q_steps / 4) runs = q_steps / 4;
+    if (runs < 1) runs = 1;
+    q.runs = runs;
+    HIP_TRY(sdrfm_q_launch(q, h->q_c0, h->q_nslot, h->stream), SDRFM_FAIL);
+    snprintf(h->kernel_name, sizeof(h->kernel_name), "%s", h->fast_q_name);
+  } else if (stream_ok) {
     const uint32_t segs = N / h->fast_s->seg;
     p.tiles_per_stream = (segs + 62) / 63;                      // waves per stream: 63 useful lane segments each
     p.fold_state = 1;
@@ -1849,7 +1902,7 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
     hipLaunchKernelGGL(k_generic, dim3(grid), dim3(256), h->lds_bytes, h->stream, p);
     snprintf(h->kernel_name, sizeof(h->kernel_name), "%s", h->generic_name);
   }
-  if ((stream_ok || (fast_ok && h->fast->kind == 'b')) && h->n_seen + 1 < c.fir_taps) {
+  if ((q_ok || stream_ok || (fast_ok && h->fast->kind == 'b')) && h->n_seen + 1 < c.fir_taps) {
     // Designs B and S read their halo as bytes, which cannot express the zero history at the start of a stream: the few audio
     // outputs that depend on inputs before the first real sample are recomputed by the generic kernel (tile 0..k only).
     const uint32_t a_aff = (y_aff + c.audio_taps + c.audio_decim - 1) / c.audio_decim;  // audio outputs touching them

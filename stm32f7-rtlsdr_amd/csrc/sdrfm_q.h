@@ -1,0 +1,50 @@
+/*
+ * sdrfm_q.h — design Q ("matrix-pipe FIR"): launch interface between the C-ABI host code (sdrfm.hip) and the kernel's own
+ * translation unit (sdrfm_q.hip).  Internal to the library; the drop-in boundary is include/sdrfm.h.
+ */
+#ifndef SDRFM_Q_H
+#define SDRFM_Q_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sdrfm_q_host.h"
+
+struct SdrfmQParams {
+  const uint8_t* iq;            // [n_streams][iq_stride] interleaved u8 I/Q (device), rows 16-byte aligned
+  size_t iq_stride;             // bytes
+  float* audio;                 // [n_streams][audio_stride]
+  size_t audio_stride;          // floats
+  const float2* yprev_in;       // streaming state, as the other kernels keep it (sdrfm.hip: CallParams)
+  float2* yprev_out;
+  const float* hist_d_in;       // [n_streams][31]
+  float* hist_d_out;
+  const uint8_t* hist_b_in;     // [n_streams][T-1] raw I/Q byte pairs
+  uint8_t* hist_b_out;
+  float2* hist_x_out;           // [n_streams][T-1] the same samples DC-shifted (the generic kernel's history format)
+  const int8_t* A;              // operand tables [5][3][64][16] (qtaps.c)
+  const float* g;               // audio taps g[0..32)
+  float q0, q2, cst;            // y = q0 * (S0 + 256 S1) + q2 * S2 + cst
+  uint32_t T;                   // channel taps (for the history hand-over only; the arithmetic is in the tables)
+  uint32_t N, M, A_out;         // per stream and call: IQ samples, decimated outputs, audio outputs
+  uint32_t steps_total;         // ceil(M / 128)
+  uint32_t runs;                // runs (waves) per stream
+  uint32_t n_streams;
+  unsigned long long* dbg;      // development build: per-wave time stamps (else nullptr)
+};
+
+// geometry the host needs
+#define SDRFM_Q_D 10u            /* FIR decimation this kernel is built for */
+#define SDRFM_Q_TA 32u           /* audio taps */
+#define SDRFM_Q_DA 5u            /* audio decimation */
+#define SDRFM_Q_STEP_OUT 128u    /* decimated outputs per wave step (16 columns x 8 outputs) */
+
+// LDS bytes of one wave for a ring of `nslot` KiB (nslot = 5, 10 or 15)
+uint32_t sdrfm_q_lds_bytes(uint32_t nslot);
+// Enqueue one call: grid = n_streams * runs one-wave workgroups.  first_chunk = 0, 1 or 2 (from sdrfm_q_build).
+// Returns hipSuccess or the launch error.
+hipError_t sdrfm_q_launch(const SdrfmQParams& p, uint32_t first_chunk, uint32_t nslot, hipStream_t stream);
+// One-time per-process kernel attribute set-up (dynamic LDS above 64 KiB is never needed; kept for symmetry): returns 0.
+const char* sdrfm_q_kernel_symbol(uint32_t first_chunk, uint32_t nslot);
+
+#endif

@@ -1,0 +1,309 @@
+/*
+ * sdrfm_q.hip — design Q: stage K2 (the decimating channel FIR) on the i8 matrix pipe of gfx950, fused with K1, K3, K4.
+ *
+ * What it fills in the reference: the same empty consumer hook as the rest of the library (RTLSDR_XFER_COMPLETE,
+ * Middlewares/ST/STM32_USB_Host_Library/Class/RTLSDR/Src/usbh_rtlsdr.c:1094-1097); byte format usbh_rtlsdr.h:165-173; FIR
+ * convention CMSIS/core/arm_math.h:3291-3331.  Arithmetic: qtaps.c / DESIGN.md §4.0 — NOT bit-identical to the fp32 fmaf
+ * chain of the oracle (designs S / B / generic are): K2 is evaluated exactly in integers from taps rounded to 24-bit fixed
+ * point, which lands within 7e-7 of the oracle's audio on every input class (tolerance 1e-5; tools/q_emulate.py).
+ *
+ * Why: designs S / B are VALU-issue-bound at 14.7 vector instructions per sample and lane, 6.4 of them the FIR's FMAs and 3.4
+ * the u8 -> f32 conversion (profiles/r02_*).  The i8 matrix pipe takes the raw bytes as they are (one v_xor per 4 bytes) and
+ * runs beside the vector pipe (profiles/ubench_r03): the vector pipe is left with the digit recombination (1.2 instructions per
+ * sample and lane), the discriminator and the audio FIR.
+ *
+ * One WAVE per workgroup (no barriers).  A wave owns a RUN of consecutive STEPS of one stream; a step is 16 BLOCKS (the MFMA's
+ * 16 columns) of 8 outputs = 128 outputs = 1280 samples = 2560 bytes:
+ *
+ *   HBM --buffer_load_dwordx4 ... lds (LDS-DMA, 1 KiB of consecutive bytes per instruction, whole 128-byte lines)-->
+ *       LDS ring of NSLOT KiB, filled NSLOT KiB ahead of the step being computed
+ *   LDS --ds_read_b128: lane (column n, K-group g) reads bytes [160 (n-1) + 64 c + 16 g, +16) of the step for chunk c = the
+ *       B operand as the MFMA wants it (conflict-free: lane stride 160 B)--> v_xor 0x80808080
+ *   5 chunks x 3 digits v_mfma_i32_16x16x64_i8 (A = tap tables, wave-constant, 60 VGPRs) --> S0, S1, S2 exact in i32
+ *   --> y = fma(f32(S0 + (S1 << 8)), q, fma(f32(S2), 65536 q, 0.5 sum h)): lane (n, g) holds (I, Q) of outputs 8 n + 2 g, +1
+ *   --> y[m-1] of the lane's first output from lane - 16 (ds_bpermute) --> K3 twice (scalar code: packed f32 instructions stall
+ *       the matrix pipe, profiles/ubench_r03) --> d's into an LDS buffer
+ *   every 5 steps (640 d's = 128 audio outputs): K4, two consecutive outputs per lane from 19 aligned 8-byte reads --> HBM
+ *
+ * A run that does not start its stream first recomputes the step before it ("warm-up": only its last four blocks are fetched
+ * and matter) for the 31 d's and the y[m-1] its first audio outputs need; the stream's first run takes them from the carried
+ * state.  The wave that holds the end of the stream's chunk hands the state over.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <type_traits>
+
+#include "sdrfm_math.h"
+#include "sdrfm_q.h"
+
+typedef int qi4_t __attribute__((ext_vector_type(4)));
+typedef float qf2_t __attribute__((ext_vector_type(2)));   // (LDS reads use ext vectors: a HIP float2 struct load makes the compiler drain vmcnt)
+__device__ void q_raw_buffer_load_lds(qi4_t rsrc, __attribute__((address_space(3))) void* lds, int size, int voffset, int soffset,
+                                      int offset, int aux) __asm("llvm.amdgcn.raw.buffer.load.lds");
+
+namespace {
+
+constexpr int QD = (int)SDRFM_Q_D, QTA = (int)SDRFM_Q_TA, QDA = (int)SDRFM_Q_DA;
+constexpr int NCH = QD / 2;                     // K-chunks of 64 bytes per window (two blocks of 16 D bytes)
+constexpr int BLKB = 16 * QD;                   // bytes per block of 8 outputs
+constexpr int STEPB = 16 * BLKB;                // bytes per step
+constexpr int PRE = BLKB;                       // pre-halo: the block before the ring's first byte
+constexpr int DB0 = 128;                        // d buffer: word DB0 + sigma = first d of the current audio stage
+constexpr int DBW = DB0 + 656;                  // words
+#ifndef SDRFM_Q_AUX
+#define SDRFM_Q_AUX 0   // cache policy of the ring's fetches (2 = nt)
+#endif
+constexpr int OOBV = (int)0x80000000;           // a voffset that is out of range for every row (num_records < 2^31)
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N < 16, "vmcnt immediate");
+  __builtin_amdgcn_s_waitcnt(0x0f70 | N);
+}
+
+template <int C0, int NSLOT>
+__global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
+  constexpr int RINGB = NSLOT * 1024;
+  static_assert(RINGB % (2 * STEPB) == 0 && NSLOT >= 5 && NSLOT - 4 < 16, "ring: whole pairs of steps");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* const db = reinterpret_cast<float*>(smem + PRE + RINGB);
+  const int lane = (int)threadIdx.x, n = lane & 15, g = lane >> 4;
+  const uint32_t stream = blockIdx.x / p.runs, run = blockIdx.x - stream * p.runs;
+  const int s0 = (int)(((uint64_t)run * p.steps_total) / p.runs), s1 = (int)(((uint64_t)(run + 1) * p.steps_total) / p.runs);
+  if (s0 >= s1) return;
+#ifdef SDRFM_Q_STAMPS   // development harness (tools/qbench): per-wave time stamps, 8 words per wave
+  unsigned long long* const tsp = p.dbg ? p.dbg + 8 * (size_t)blockIdx.x : nullptr;
+  unsigned long long t_wait = 0, t_first = 0;
+  const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
+#endif
+  const bool warm = s0 > 0, last_run = (uint32_t)s1 == p.steps_total;
+  const int ks = warm ? s0 - 1 : s0, nsteps = s1 - ks;
+  const int j0 = (128 * s0) / QDA;                              // first audio output whose newest d lies in an owned step
+  int j1 = (128 * s1) / QDA;
+  if (j1 > (int)p.A_out) j1 = (int)p.A_out;
+  const int phi = QDA * j0 + QDA - 1 - 128 * s0;                // its newest d, relative to the first owned output (0..4)
+  const int sigma = (phi + 1) & 1;                              // shifts the d buffer so that every lane's window starts on an even word
+
+  // ---- carried state (the stream's first run) -----------------------------------------------------------------------------
+  float cr = 0.0f, ci = 0.0f;                                   // y[m-1] of the step's first output (lane 0)
+  if (!warm) {
+    const float2 yp = p.yprev_in[stream];
+    cr = yp.x; ci = yp.y;
+    const int HT = (int)p.T - 1;
+    for (int k = lane; k < HT; k += 64)                         // the last T-1 samples before the call -> end of the pre-halo
+      *reinterpret_cast<unsigned short*>(smem + PRE - 2 * HT + 2 * k) =
+          reinterpret_cast<const unsigned short*>(p.hist_b_in)[(size_t)stream * HT + k];
+    if (lane < QTA - 1) db[DB0 + sigma - (QTA - 1) + lane] = p.hist_d_in[(size_t)stream * (QTA - 1) + lane];
+  }
+
+  // ---- the ring --------------------------------------------------------------------------------------------------------------
+  const unsigned long long gaddr = (unsigned long long)(p.iq + (size_t)stream * p.iq_stride);
+  uint32_t hi = (uint32_t)STEPB * (uint32_t)s1;                 // bytes of the row this run may touch: [.., hi)
+  if (hi > 2u * p.N) hi = 2u * p.N;
+  const qi4_t rsrc = {(int)(unsigned)gaddr, (int)(unsigned)(gaddr >> 32), (int)hi, 0x00020000};
+  int vpos = STEPB * ks + 16 * lane;                            // this lane's byte offset in the row for the next chunk
+  auto slot_ptr = [&](int slot) { return (__attribute__((address_space(3))) void*)(smem + PRE + 1024 * slot); };
+  {
+    // prologue: NSLOT chunks.  A warm-up step needs only its last four blocks and the block before them (bytes >= 1664 of the
+    // step, rounded to a line): the pieces before that are switched off by an out-of-range offset (the instruction still counts).
+    const int v0 = warm ? OOBV : vpos;
+    const int v1 = (warm && lane < 40) ? OOBV : vpos + 1024;
+    q_raw_buffer_load_lds(rsrc, slot_ptr(0), 16, v0, 0, 0, SDRFM_Q_AUX);
+    q_raw_buffer_load_lds(rsrc, slot_ptr(1), 16, v1, 0, 0, SDRFM_Q_AUX);
+#pragma unroll
+    // (the instruction's immediate offset moves BOTH the memory address and the LDS address: a group of up to four chunks shares
+    // one voffset register and one LDS base)
+    for (int q = 2; q < NSLOT; ++q) q_raw_buffer_load_lds(rsrc, slot_ptr(q & ~3), 16, vpos + 1024 * (q & ~3), 0, 1024 * (q & 3), SDRFM_Q_AUX);
+    vpos += 1024 * NSLOT;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("" ::: "memory");   // the ring's first requests leave the CU before the (L2-resident) tables are fetched
+  // ---- wave constants: tap tables (A operands), audio taps.  15 KiB per wave out of L2: issued AFTER the ring's prologue so that
+  // the HBM requests are not queued behind them in the CU's texture path (they come back in order, right after the first bytes)
+  qi4_t At[NCH - C0][SDRFM_Q_DIGITS];
+#pragma unroll
+  for (int c = C0; c < NCH; ++c)
+#pragma unroll
+    for (int t = 0; t < SDRFM_Q_DIGITS; ++t)
+#if defined(SDRFM_Q_ABLATE) && (SDRFM_Q_ABLATE & 4)
+      At[c - C0][t] = qi4_t{lane + c, lane * t, c - t, lane};
+#else
+      At[c - C0][t] = *reinterpret_cast<const qi4_t*>(p.A + ((size_t)((c * SDRFM_Q_DIGITS + t) * 64 + lane)) * 16);
+#endif
+  float gr[QTA];                                                // gr[k] multiplies the k-th oldest d of a window
+#pragma unroll
+  for (int k = 0; k < QTA; ++k) gr[k] = p.g[QTA - 1 - k];
+
+  int slot = 0;                                                 // ring slot of the next chunk
+  int ringoff = 0;                                              // ring byte offset of the current step
+  int osm = warm ? -1 : 0;                                      // owned steps in the d buffer since the last audio stage
+  int jst = j0;                                                 // first audio output of the current stage
+  int mbase = 128 * s0;                                         // output index of d-buffer word DB0 + sigma
+  const int baddr = BLKB * n + 16 * g;                          // window of block n starts at PRE + ringoff - BLKB + BLKB n
+  const int srcaddr = 4 * (g > 0 ? lane - 16 : ((lane + 47) & 63));   // lane holding y[m-1] of this lane's first output
+  const int dlane = 8 * n + 2 * g;
+  const int ylast_step = ((int)p.M - 1) >> 7, ylast_lane = ((((int)p.M - 1) & 127) >> 3) + 16 * ((((int)p.M - 1) & 7) >> 1);
+
+  for (int kk = 0; kk < nsteps; ++kk) {
+    // ---- this step's bytes have landed: everything but the NSLOT-4 youngest chunks --------------------------------------------
+#ifdef SDRFM_Q_STAMPS
+    const unsigned long long tw0 = __builtin_readcyclecounter();
+#endif
+    wait_vmcnt<NSLOT - 4>();
+    asm volatile("" ::: "memory");
+#ifdef SDRFM_Q_STAMPS
+    t_wait += __builtin_readcyclecounter() - tw0;
+    if (kk == 0) t_first = __builtin_amdgcn_s_memrealtime();
+#endif
+    qi4_t B[NCH - C0];
+    const unsigned char* wb = smem + baddr + ringoff;
+#pragma unroll
+    for (int c = C0; c < NCH; ++c) B[c - C0] = *reinterpret_cast<const qi4_t*>(wb + 64 * c);
+    if (ringoff + STEPB == RINGB) {                             // the next step starts the ring over: its pre-halo = the ring's last block
+      if (lane < BLKB / 16) {
+        const qi4_t hcp = *reinterpret_cast<const qi4_t*>(smem + PRE + RINGB - BLKB + 16 * lane);
+        *reinterpret_cast<qi4_t*>(smem + 16 * lane) = hcp;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the slots this step read are free now: refill them
+    if (kk > 0 && !(kk & 1)) {
+      q_raw_buffer_load_lds(rsrc, slot_ptr(slot), 16, vpos, 0, 0, SDRFM_Q_AUX);
+      vpos += 1024;
+      slot = (slot + 1 == NSLOT) ? 0 : slot + 1;
+    }
+    q_raw_buffer_load_lds(rsrc, slot_ptr(slot), 16, vpos, 0, 0, SDRFM_Q_AUX);      // a pair never straddles the ring's end (pairs start at
+    q_raw_buffer_load_lds(rsrc, slot_ptr(slot), 16, vpos, 0, 1024, SDRFM_Q_AUX);   // chunk numbers = 0 or 2 mod 5); offset:1024 moves both addresses
+    slot = (slot + 2 >= NSLOT) ? slot + 2 - NSLOT : slot + 2;
+    vpos += 2048;
+
+    // ---- K2 on the matrix pipe ------------------------------------------------------------------------------------------------
+    qi4_t acc[SDRFM_Q_DIGITS];
+#pragma unroll
+    for (int t = 0; t < SDRFM_Q_DIGITS; ++t) acc[t] = qi4_t{0, 0, 0, 0};
+#pragma unroll
+    for (int c = C0; c < NCH; ++c) {
+      const qi4_t b = B[c - C0] ^ qi4_t{(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};   // byte - 128 as i8
+#pragma unroll
+      for (int t = 0; t < SDRFM_Q_DIGITS; ++t) {
+#if defined(SDRFM_Q_ABLATE) && (SDRFM_Q_ABLATE & 2)
+        acc[t] += At[c - C0][t] & b;
+#else
+        acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(At[c - C0][t], b, acc[t], 0, 0, 0);
+#endif
+      }
+    }
+    // ---- digits -> y: rows 4 g + {0, 1, 2, 3} = (I, Q) of output 2 g, (I, Q) of output 2 g + 1 of block n -------------------------
+    float y[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int s01 = acc[0][r] + acc[1][r] * 256;              // exact: |S0| <= 2^20, |S1 << 8| <= 2^28
+      y[r] = __builtin_fmaf((float)s01, p.q0, __builtin_fmaf((float)acc[2][r], p.q2, p.cst));
+    }
+    // ---- K3: y[m-1] of the lane's first output sits in lane - 16 (or is the previous step's last output) -------------------------
+    float pr = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(srcaddr, __builtin_bit_cast(int, y[2])));
+    float pi = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(srcaddr, __builtin_bit_cast(int, y[3])));
+    if (lane == 0) { pr = cr; pi = ci; }
+    cr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y[2]), 63));
+    ci = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y[3]), 63));
+#if defined(SDRFM_Q_ABLATE) && (SDRFM_Q_ABLATE & 1)   // timing experiments of the development harness only (wrong results)
+    const float d0 = y[0] + pr + y[1] * pi, d1 = y[2] + y[3] * y[1] + y[0];
+#else
+    const float d0 = sdrfm_discriminate(y[0], y[1], pr, pi);
+    const float d1 = sdrfm_discriminate(y[2], y[3], y[0], y[1]);
+#endif
+    {
+      float* dst = db + DB0 + sigma + 128 * osm + dlane;
+      dst[0] = d0;
+      dst[1] = d1;
+    }
+    if (last_run && ks + kk == ylast_step && lane == ylast_lane) p.yprev_out[stream] = make_float2(y[2], y[3]);
+    // the stream's last 31 d's, taken before the audio stage below may move the buffer on (the call's last step need not be full)
+    if (last_run && kk == nsteps - 1 && lane < QTA - 1)
+      p.hist_d_out[(size_t)stream * (QTA - 1) + lane] = db[DB0 + sigma + ((int)p.M - (QTA - 1) + lane - mbase)];
+    ++osm;
+    ringoff = (ringoff + STEPB == RINGB) ? 0 : ringoff + STEPB;
+
+    // ---- K4: 128 audio outputs per five owned steps, two consecutive outputs per lane -------------------------------------------
+    if (osm == 5 || (kk == nsteps - 1 && osm > 0)) {
+      int jend = jst + 128;
+      if (jend > j1) jend = j1;
+      const float* w = db + DB0 + sigma + phi + 10 * lane - (QTA - 1);   // oldest d of output jst + 2 lane: an even word
+      float dw[QTA + QDA + 1];
+#pragma unroll
+      for (int i = 0; i < (QTA + QDA + 1) / 2; ++i) {
+        const qf2_t v = *reinterpret_cast<const qf2_t*>(w + 2 * i);
+        dw[2 * i] = v.x;
+        dw[2 * i + 1] = v.y;
+      }
+      float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+      for (int k = 0; k < QTA; ++k) {                          // the oracle's chain order: oldest d first
+        a0 = __builtin_fmaf(gr[k], dw[k], a0);
+        a1 = __builtin_fmaf(gr[k], dw[QDA + k], a1);
+      }
+      float* out = p.audio + (size_t)stream * p.audio_stride;
+      const int j = jst + 2 * lane;
+      if (j < jend) __builtin_nontemporal_store(a0, out + j);
+      if (j + 1 < jend) __builtin_nontemporal_store(a1, out + j + 1);
+      if (osm == 5) {                                           // the stage's last 32 d's become the next stage's history
+        if (lane < QTA) {
+          const float hv = db[DB0 + sigma + 640 - QTA + lane];
+          db[DB0 + sigma - QTA + lane] = hv;
+        }
+        osm = 0;
+        jst += 128;
+        mbase += 640;
+      }
+    }
+  }
+#ifdef SDRFM_Q_STAMPS
+  const unsigned long long t_loop = __builtin_amdgcn_s_memrealtime();
+#endif
+  wait_vmcnt<0>();                                              // nothing may still be in flight towards this wave's LDS when it ends
+
+  // ---- state hand-over by the wave that holds the end of the stream's chunk --------------------------------------------------
+  if (last_run) {
+    const int HT = (int)p.T - 1;
+    const unsigned char* row = p.iq + (size_t)stream * p.iq_stride;
+    for (int k = lane; k < HT; k += 64) {
+      const unsigned raw = *reinterpret_cast<const unsigned short*>(row + 2 * ((size_t)p.N - HT + k));
+      reinterpret_cast<unsigned short*>(p.hist_b_out)[(size_t)stream * HT + k] = (unsigned short)raw;
+      p.hist_x_out[(size_t)stream * HT + k] = make_float2((float)(raw & 0xffu) - 127.5f, (float)(raw >> 8) - 127.5f);
+    }
+  }
+#ifdef SDRFM_Q_STAMPS
+  if (tsp && lane == 0) {
+    tsp[0] = t_entry; tsp[1] = t_first; tsp[2] = t_loop; tsp[3] = __builtin_amdgcn_s_memrealtime(); tsp[4] = t_wait;
+    tsp[5] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7; tsp[6] = (unsigned long long)nsteps;
+  }
+#endif
+}
+
+typedef void (*QKernel)(SdrfmQParams);
+struct QVariant { uint32_t c0, nslot; QKernel k; const char* name; };
+#define QV(C0_, NS_) { C0_, NS_, k_mfir<C0_, NS_>, "k_mfir<" #C0_ "," #NS_ ">" }
+const QVariant kQVariants[] = {QV(0, 5), QV(0, 10), QV(0, 15), QV(1, 5), QV(1, 10), QV(1, 15), QV(2, 5), QV(2, 10), QV(2, 15)};
+
+const QVariant* q_find(uint32_t c0, uint32_t nslot) {
+  if (c0 > 2) c0 = 2;
+  for (const QVariant& v : kQVariants)
+    if (v.c0 == c0 && v.nslot == nslot) return &v;
+  return nullptr;
+}
+
+}  // namespace
+
+uint32_t sdrfm_q_lds_bytes(uint32_t nslot) { return (uint32_t)(PRE + 1024 * (int)nslot + 4 * DBW); }
+
+const char* sdrfm_q_kernel_symbol(uint32_t first_chunk, uint32_t nslot) {
+  const QVariant* v = q_find(first_chunk, nslot);
+  return v ? v->name : "";
+}
+
+hipError_t sdrfm_q_launch(const SdrfmQParams& p, uint32_t first_chunk, uint32_t nslot, hipStream_t stream) {
+  const QVariant* v = q_find(first_chunk, nslot);
+  if (!v) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(v->k, dim3(p.n_streams * p.runs), dim3(64), sdrfm_q_lds_bytes(nslot), stream, p);
+  return hipGetLastError();
+}

@@ -1,0 +1,176 @@
+// Development harness of design Q (csrc/sdrfm_q.hip): runs the kernel on its own — no Python, no library — checks it against a
+// float64 restatement of the frozen spec on the host (every audio sample of a few streams, and the state it hands over), and times
+// it on cold inputs (rotating over > 256 MiB).  usage: qbench [ns] [nsamp] [T] [nslot] [runs] [iters] [mode: fm|random]
+// Prints one JSON line.  Test infrastructure only.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../stm32f7-rtlsdr_amd/csrc/sdrfm_q.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+static unsigned long long rng_state = 88172645463325252ull;
+static inline unsigned long long rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return rng_state; }
+
+static void lowpass(std::vector<float>& h, int T, double fc) {
+  std::vector<double> t(T);
+  double s = 0;
+  for (int k = 0; k < T; ++k) {
+    const double x = k - (T - 1) / 2.0, w = 0.54 - 0.46 * cos(2 * M_PI * k / (T - 1));
+    t[k] = (x == 0 ? 2 * fc : sin(2 * M_PI * fc * x) / (M_PI * x)) * w;
+    s += t[k];
+  }
+  h.resize(T);
+  for (int k = 0; k < T; ++k) h[k] = (float)(t[k] / s);
+}
+
+static void fill_row(uint8_t* row, int nsamp, int mode, unsigned id) {
+  if (mode == 1) { for (int i = 0; i < 2 * nsamp; ++i) row[i] = (uint8_t)(rnd() >> 40); return; }
+  double ph = 0.1 * id, fcar = ((int)(id % 41) - 20) * 1000.0;
+  for (int n = 0; n < nsamp; ++n) {
+    const double tt = n / 2.4e6, a = 0.5 * sin(2 * M_PI * 1000 * tt) + 0.3 * sin(2 * M_PI * 3100 * tt) + 0.2 * sin(2 * M_PI * 7300 * tt);
+    ph += 2 * M_PI * (fcar + 75e3 * a) / 2.4e6;
+    const double ni = ((double)(rnd() >> 40) / 16777216.0 - 0.5) * 8, nq = ((double)(rnd() >> 40) / 16777216.0 - 0.5) * 8;
+    double vi = 127.5 + 100 * cos(ph) + ni, vq = 127.5 + 100 * sin(ph) + nq;
+    vi = vi < 0 ? 0 : (vi > 255 ? 255 : vi); vq = vq < 0 ? 0 : (vq > 255 ? 255 : vq);
+    row[2 * n] = (uint8_t)lrint(vi); row[2 * n + 1] = (uint8_t)lrint(vq);
+  }
+}
+
+int main(int argc, char** argv) {
+  const int ns = argc > 1 ? atoi(argv[1]) : 256, nsamp = argc > 2 ? atoi(argv[2]) : 240000, T = argc > 3 ? atoi(argv[3]) : 64;
+  const int nslot = argc > 4 ? atoi(argv[4]) : 10, runs = argc > 5 ? atoi(argv[5]) : 12, iters = argc > 6 ? atoi(argv[6]) : 40;
+  const int mode = (argc > 7 && !strcmp(argv[7], "random")) ? 1 : 0;
+  const int D = 10, Ta = 32, Da = 5, HT = T - 1;
+  if (nsamp % 400) { fprintf(stderr, "nsamp must be a multiple of 400\n"); return 2; }
+  const int M = nsamp / D, A = M / Da;
+  std::vector<float> h, g;
+  lowpass(h, T, 100e3 / 2.4e6); lowpass(g, Ta, 15e3 / 240e3);
+  std::vector<int8_t> At(5 * 3 * 64 * 16);
+  float q, cst; uint32_t c0;
+  if (sdrfm_q_build(h.data(), T, D, At.data(), &q, &cst, &c0)) { fprintf(stderr, "sdrfm_q_build failed\n"); return 2; }
+
+  // inputs: NB batches so that the timed loop reads cold HBM; only batch 0 is checked
+  const size_t stride = 2 * (size_t)nsamp, batch = stride * ns;
+  int NB = (int)((300ull << 20) / batch) + 1;
+  if (NB < 2) NB = 2;
+  if (NB > 8) NB = 8;
+  if (getenv("QBENCH_NB")) NB = atoi(getenv("QBENCH_NB"));   // 1 = resident input (Infinity Cache), for compute-bound estimates
+  std::vector<uint8_t> hiq(batch);
+  const int ncheck = ns < 6 ? ns : 6;
+  for (int s = 0; s < ns; ++s) {
+    if (s < ncheck || s == ns - 1) fill_row(hiq.data() + s * stride, nsamp, mode, s);
+    else memcpy(hiq.data() + s * stride, hiq.data() + (s % ncheck) * stride, stride);
+  }
+  std::vector<uint8_t> hhb((size_t)ns * HT * 2);
+  std::vector<float> hhd((size_t)ns * 31), hyp((size_t)ns * 2);
+  for (auto& v : hhb) v = (uint8_t)(rnd() >> 40);
+  for (auto& v : hhd) v = (float)((double)(rnd() >> 40) / 16777216.0 - 0.5);
+  for (auto& v : hyp) v = (float)(((double)(rnd() >> 40) / 16777216.0 - 0.5) * 100);
+
+  uint8_t* d_iq; float* d_audio; float2 *d_ypi, *d_ypo, *d_hxo; float *d_hdi, *d_hdo, *d_g; uint8_t *d_hbi, *d_hbo; int8_t* d_A;
+  const size_t astride = (A + 63) & ~63;
+  CK(hipMalloc(&d_iq, batch * NB)); CK(hipMalloc(&d_audio, astride * ns * 4));
+  CK(hipMalloc(&d_ypi, ns * 8)); CK(hipMalloc(&d_ypo, ns * 8)); CK(hipMalloc(&d_hxo, (size_t)ns * HT * 8));
+  CK(hipMalloc(&d_hdi, ns * 31 * 4)); CK(hipMalloc(&d_hdo, ns * 31 * 4)); CK(hipMalloc(&d_g, Ta * 4));
+  CK(hipMalloc(&d_hbi, (size_t)ns * HT * 2)); CK(hipMalloc(&d_hbo, (size_t)ns * HT * 2)); CK(hipMalloc(&d_A, At.size()));
+  for (int b = 0; b < NB; ++b) CK(hipMemcpy(d_iq + b * batch, hiq.data(), batch, hipMemcpyHostToDevice));
+  CK(hipMemcpy(d_ypi, hyp.data(), ns * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(d_hdi, hhd.data(), ns * 31 * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(d_hbi, hhb.data(), hhb.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(d_g, g.data(), Ta * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(d_A, At.data(), At.size(), hipMemcpyHostToDevice));
+  CK(hipMemset(d_audio, 0xff, astride * ns * 4));
+
+  SdrfmQParams p;
+  memset(&p, 0, sizeof(p));
+  p.iq = d_iq; p.iq_stride = stride; p.audio = d_audio; p.audio_stride = astride;
+  p.yprev_in = d_ypi; p.yprev_out = d_ypo; p.hist_d_in = d_hdi; p.hist_d_out = d_hdo; p.hist_b_in = d_hbi; p.hist_b_out = d_hbo; p.hist_x_out = d_hxo;
+  p.A = d_A; p.g = d_g; p.q0 = q; p.q2 = 65536.0f * q; p.cst = cst;
+  p.T = T; p.N = nsamp; p.M = M; p.A_out = A; p.steps_total = (M + 127) / 128; p.runs = runs; p.n_streams = ns; p.dbg = nullptr;
+  hipStream_t st; CK(hipStreamCreate(&st));
+  CK(sdrfm_q_launch(p, c0, nslot, st));
+  CK(hipStreamSynchronize(st));
+
+  // ---- check against a float64 restatement of the spec -----------------------------------------------------------------------
+  std::vector<float> ha(astride * ns), ohd(ns * 31), oyp(ns * 2);
+  std::vector<uint8_t> ohb(hhb.size());
+  CK(hipMemcpy(ha.data(), d_audio, ha.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(ohd.data(), d_hdo, ohd.size() * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(oyp.data(), d_ypo, oyp.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(ohb.data(), d_hbo, ohb.size(), hipMemcpyDeviceToHost));
+  double worst = 0, worst_state = 0; long bad = 0, nonfinite = 0; int worst_s = -1, worst_j = -1;
+  std::vector<int> chk;
+  for (int s = 0; s < ncheck; ++s) chk.push_back(s);
+  if (ns - 1 >= ncheck) chk.push_back(ns - 1);
+  for (int s : chk) {
+    const uint8_t* row = hiq.data() + s * stride;
+    std::vector<double> xr(HT + nsamp), xi(HT + nsamp), dd(31 + M);
+    for (int k = 0; k < HT; ++k) { xr[k] = hhb[((size_t)s * HT + k) * 2] - 127.5; xi[k] = hhb[((size_t)s * HT + k) * 2 + 1] - 127.5; }
+    for (int n = 0; n < nsamp; ++n) { xr[HT + n] = row[2 * n] - 127.5; xi[HT + n] = row[2 * n + 1] - 127.5; }
+    for (int k = 0; k < 31; ++k) dd[k] = hhd[s * 31 + k];
+    double pr = hyp[2 * s], pi = hyp[2 * s + 1];
+    for (int m = 0; m < M; ++m) {
+      const int e = (m + 1) * D - 1;          // newest sample; window xr[e .. e + T - 1] oldest first in the [history | chunk] array
+      double ar = 0, ai = 0;
+      for (int j = 0; j < T; ++j) { ar += (double)h[T - 1 - j] * xr[e + j]; ai += (double)h[T - 1 - j] * xi[e + j]; }
+      const double re = ar * pr + ai * pi, im = ai * pr - ar * pi;
+      dd[31 + m] = (re == 0 && im == 0) ? 0 : atan2(im, re);
+      pr = ar; pi = ai;
+    }
+    for (int j = 0; j < A; ++j) {
+      double acc = 0;
+      for (int k = 0; k < Ta; ++k) acc += (double)g[Ta - 1 - k] * dd[(j + 1) * Da - 1 + k];
+      const double got = ha[s * astride + j];
+      if (!std::isfinite(got)) { ++nonfinite; continue; }
+      const double e = fabs(got - acc) / fmax(fabs(acc), 1.0);
+      if (e > worst) { worst = e; worst_s = s; worst_j = j; }
+      if (e > 1e-5) ++bad;
+    }
+    for (int k = 0; k < 31; ++k) worst_state = fmax(worst_state, fabs(ohd[s * 31 + k] - dd[31 + M - 31 + k]));
+    worst_state = fmax(worst_state, fmax(fabs(oyp[2 * s] - pr), fabs(oyp[2 * s + 1] - pi)) / fmax(1.0, hypot(pr, pi)));
+    for (int k = 0; k < HT; ++k)
+      if (ohb[((size_t)s * HT + k) * 2] != row[2 * (nsamp - HT + k)] || ohb[((size_t)s * HT + k) * 2 + 1] != row[2 * (nsamp - HT + k) + 1]) worst_state = 1e9;
+  }
+
+  // ---- timing: back-to-back launches over rotating batches, one pair of events ---------------------------------------------------
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 5; ++i) { p.iq = d_iq + (size_t)(i % NB) * batch; CK(sdrfm_q_launch(p, c0, nslot, st)); }
+  CK(hipStreamSynchronize(st));
+  CK(hipEventRecord(e0, st));
+  for (int i = 0; i < iters; ++i) { p.iq = d_iq + (size_t)(i % NB) * batch; CK(sdrfm_q_launch(p, c0, nslot, st)); }
+  CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  if (getenv("QBENCH_STAMPS")) {   // one more launch with per-wave stamps (kernel built with -DSDRFM_Q_STAMPS), summarised per XCC 0
+    const size_t nw = (size_t)ns * runs;
+    unsigned long long* d_dbg; CK(hipMalloc(&d_dbg, nw * 64)); CK(hipMemset(d_dbg, 0, nw * 64));
+    p.dbg = d_dbg; p.iq = d_iq + (size_t)(iters % NB) * batch;
+    CK(sdrfm_q_launch(p, c0, nslot, st)); CK(hipStreamSynchronize(st));
+    std::vector<unsigned long long> hd(nw * 8);
+    CK(hipMemcpy(hd.data(), d_dbg, nw * 64, hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull;
+    for (size_t w = 0; w < nw; ++w) if (hd[8 * w + 6] && hd[8 * w + 5] == 0 && hd[8 * w] < t0) t0 = hd[8 * w];
+    double sum[4] = {0, 0, 0, 0}, mx[4] = {0, 0, 0, 0}, mn[4] = {1e30, 1e30, 1e30, 1e30}, waitc = 0, steps = 0; size_t cnt = 0;
+    for (size_t w = 0; w < nw; ++w) {
+      if (!hd[8 * w + 6] || hd[8 * w + 5] != 0) continue;
+      for (int i = 0; i < 4; ++i) { const double v = (double)(hd[8 * w + i] - t0) * 0.01; sum[i] += v; if (v > mx[i]) mx[i] = v; if (v < mn[i]) mn[i] = v; }
+      waitc += (double)hd[8 * w + 4]; steps += (double)hd[8 * w + 6]; ++cnt;
+    }
+    if (getenv("QBENCH_DUMP")) {   // raw per-wave stamps (all XCCs) for offline analysis: block, xcc, entry, first, loop_end, exit (ticks), wait, steps
+      FILE* f = fopen(getenv("QBENCH_DUMP"), "w");
+      for (size_t w = 0; w < nw; ++w) if (hd[8 * w + 6]) fprintf(f, "%zu %llu %llu %llu %llu %llu %llu %llu\n", w, hd[8 * w + 5], hd[8 * w], hd[8 * w + 1], hd[8 * w + 2], hd[8 * w + 3], hd[8 * w + 4], hd[8 * w + 6]);
+      fclose(f);
+    }
+    printf("{\"stamps_us_xcc0\":{\"waves\":%zu,\"entry\":[%.2f,%.2f,%.2f],\"first_data\":[%.2f,%.2f,%.2f],\"loop_end\":[%.2f,%.2f,%.2f],\"exit\":[%.2f,%.2f,%.2f],"
+           "\"wait_cycles_per_step\":%.0f,\"steps_per_wave\":%.2f}}\n", cnt, mn[0], sum[0] / cnt, mx[0], mn[1], sum[1] / cnt, mx[1], mn[2], sum[2] / cnt, mx[2],
+           mn[3], sum[3] / cnt, mx[3], waitc / steps, steps / cnt);
+  }
+  const double us = ms * 1e3 / iters, bytes = (double)ns * nsamp * 2.08;
+  printf("{\"kernel\":\"%s\",\"ns\":%d,\"nsamp\":%d,\"T\":%d,\"nslot\":%d,\"runs\":%d,\"mode\":\"%s\",\"first_chunk\":%u,\"checked_streams\":%zu,"
+         "\"max_scaled_err\":%.3g,\"worst_at\":[%d,%d],\"n_over_tol\":%ld,\"nonfinite\":%ld,\"state_err\":%.3g,\"us_per_launch\":%.2f,\"frac_of_8TBs\":%.4f,\"batches\":%d}\n",
+         sdrfm_q_kernel_symbol(c0, nslot), ns, nsamp, T, nslot, runs, mode ? "random" : "fm", c0, chk.size(), worst, worst_s, worst_j, bad, nonfinite,
+         worst_state, us, bytes / (us * 1e-6) / 8e12, NB);
+  return (bad || nonfinite || worst_state > 1e-4) ? 1 : 0;
+}
