@@ -125,25 +125,6 @@ const char* sdrfm_kernel_name(const sdrfm_t* h);
 uint32_t    sdrfm_abi_version(void);
 const char* sdrfm_strerror(int status);
 
-/* Test hooks: HOST evaluation of the exact arithmetic the device uses for stage K3 (same source, same rounding), so
- * that its accuracy against libm can be checked without a GPU.  No compute path calls these. */
-float sdrfm_host_atan2f(float y, float x);
-float sdrfm_host_discriminate(float yr, float yi, float pr, float pi);
-
-/* Profiling aid of the development build (libsdrfm_dev.so, built with -DSDRFM_DEV; SDRFM_PHASE_PROFILE=1 at create time):
- * cumulative shader cycles per phase summed over waves: out[0..4] = stage, FIR, discriminator, audio, carry; out[5] =
- * sub-tiles; out[6] = waves; and resets them.  The product library holds no instrumented kernel and no environment
- * knob: it always answers SDRFM_NOT_SUPPORTED. */
-int sdrfm_debug_phase_cycles(sdrfm_t* h, unsigned long long* out8);
-
-/* Profiling aid: raw dump of the 560 debug words of the instrumented build. */
-int sdrfm_debug_raw(sdrfm_t* h, unsigned long long* out560);
-
-/* Test hook: stage K3 evaluated ON THE DEVICE for n operand sets (host arrays): out_scalar = the scalar routine of the
- * generic kernel / state hand-over, out_pair = the packed two-at-a-time routine of the specialised kernels. */
-int sdrfm_debug_discriminate(int device, const float* yr, const float* yi, const float* pr, const float* pi,
-                             float* out_scalar, float* out_pair, uint32_t n);
-
 /* ------------------------------------------------------------------------------------------------------------------
  * Streaming front-end adapter: a ring of n_buffers pinned host buffers of buffer_bytes each — the multi-buffer scheme the
  * reference declares but never uses (DEFAULT_BUF_NUMBER 15 x DEFAULT_BUF_LENGTH 16*32*512, usbh_rtlsdr.h:277-278).

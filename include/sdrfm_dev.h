@@ -1,0 +1,47 @@
+/*
+ * sdrfm_dev.h — test hooks and development aids of libsdrfm.  NOT part of the drop-in boundary (that is include/sdrfm.h): nothing a
+ * front end binds lives here.  Only tests/ and tools/ include or bind these.
+ *
+ *   exported by the product library libsdrfm.so (they compute nothing on behalf of a caller; tests use them to check the
+ *   arithmetic the kernels are built from):
+ *     sdrfm_host_atan2f, sdrfm_host_discriminate   HOST evaluation of the device's K3 arithmetic (same source, same rounding)
+ *     sdrfm_debug_discriminate                     K3 evaluated ON THE DEVICE for n operand sets, both code forms
+ *     sdrfm_q_build                                design Q: the channel taps as i8 matrix-pipe operand tables (csrc/qtaps.c)
+ *   exported by the development library libsdrfm_dev.so only (built with -DSDRFM_DEV):
+ *     sdrfm_debug_phase_cycles, sdrfm_debug_raw    instrumented kernels' counters (SDRFM_PHASE_PROFILE=1 at create)
+ *     sdrfm_dev_read_debug                         per-wave time stamps of design S (SDRFM_STREAM_PROFILE=1)
+ */
+#ifndef SDRFM_DEV_H
+#define SDRFM_DEV_H
+
+#include "sdrfm.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* HOST evaluation of the exact arithmetic the device uses for stage K3 (same source, same rounding), so that its accuracy against
+ * libm can be checked without a GPU.  No compute path calls these. */
+float sdrfm_host_atan2f(float y, float x);
+float sdrfm_host_discriminate(float yr, float yi, float pr, float pi);
+
+/* Stage K3 evaluated ON THE DEVICE for n operand sets (host arrays): out_scalar = the scalar routine of the generic kernel / state
+ * hand-over, out_pair = the packed two-at-a-time routine of the specialised kernels. */
+int sdrfm_debug_discriminate(int device, const float* yr, const float* yi, const float* pr, const float* pi,
+                             float* out_scalar, float* out_pair, uint32_t n);
+
+/* Design Q (csrc/qtaps.c): h[0..T) -> A[D/2][3][64][16] (K-chunk, digit, lane, byte) i8 operand tables, the fp32 scale q with
+ * y = q (S0 + 256 S1 + 65536 S2) + cst, cst = 0.5 sum(h), and the first K-chunk holding a non-zero tap.  0 on success. */
+int sdrfm_q_build(const float* h, uint32_t T, uint32_t D, int8_t* A, float* q, float* cst, uint32_t* first_chunk);
+
+/* Development library only: cumulative shader cycles per phase of the instrumented design-B kernel summed over waves (out[0..4] =
+ * stage, FIR, discriminator, audio, carry; out[5] = sub-tiles; out[6] = waves), reset on read; raw dump of its 560 debug words;
+ * per-wave time stamps of design S. */
+int sdrfm_debug_phase_cycles(sdrfm_t* h, unsigned long long* out8);
+int sdrfm_debug_raw(sdrfm_t* h, unsigned long long* out560);
+int sdrfm_dev_read_debug(sdrfm_t* h, unsigned long long* out, uint32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDRFM_DEV_H */

@@ -17,6 +17,7 @@ from .taps import RTLSDR_FIR, rtlsdr_fir16, lowpass_taps, default_config
 from .siggen import make_iq, MODES
 from .frontend import ReplayFrontEnd, XferState
 from . import fanout
+from . import lib
 
 __all__ = [
     "SdrfmError", "load_library", "library_path", "STATUS", "ABI_SYMBOLS", "FmDemod", "FmConfig", "WbfmDemod", "WbfmConfig", "SpectrumView", "SpectrumConfig", "power_db", "PcmSink", "pcm_deemph_s16_host", "RTLSDR_FIR",

@@ -12,7 +12,15 @@
  * from each block's WINDOW of 32 D bytes = the block's own 16 D bytes and the 16 D bytes before them, K-chunked 64 bytes at a
  * time.  Window sample w (0 .. 16 D - 1, byte pair 2 w, 2 w + 1) meets output o through tap k = 8 D + D o + D - 1 - w.
  *
- * Operand layout (verified on the device by tools/ubench/ubench11.hip): lane l supplies row (l & 15), bytes K = 16 (l >> 4) .. +15.
+ * The A operand is exactly 2:4 sparse — an I row holds taps at even K positions only, a Q row at odd ones — so the kernel issues the
+ * SPARSE instruction v_smfmac_i32_16x16x128_i8: 128 window bytes per issue at the cost of a dense 64 (tools/ubench/ubench13.hip),
+ * ceil(D / 4) issues per digit instead of D / 2.  Operand layout (found by one-hot probing on the device, tools/ubench/ubench14.hip):
+ *   A (sparse): lane l = row (l & 15), K group gA = l >> 4; its 16 bytes are slots s = 8 h + 2 q + j (h = 0, 1; q = 0..3; j = 0, 1) =
+ *               the j-th kept value of the group of four dense positions K = 32 gA + 16 h + 4 q .. + 3;
+ *   idx:        one VGPR; bits [4 (4 h + q) + 1 : 4 (4 h + q)] = position of the first kept value in its group, the next two bits the
+ *               second: 0x88888888 for an I row (positions 0, 2), 0xDDDDDDDD for a Q row (1, 3);
+ *   B (dense):  lane l = column (l & 15), gB = l >> 4; bytes 0..15 are K = 16 gB .. + 15, bytes 16..31 are K = 64 + 16 gB .. + 15 — the
+ *               same two 16-byte pieces a lane holds for two consecutive dense v_mfma_i32_16x16x64_i8 issues.
  */
 #include <math.h>
 #include <stdint.h>
@@ -23,7 +31,6 @@
 int sdrfm_q_build(const float* h, uint32_t T, uint32_t D, int8_t* A, float* q_out, float* cst_out, uint32_t* first_chunk) {
   if (!h || !A || !q_out || !cst_out || !first_chunk) return -1;
   if (D < 2 || (D & 1u) || D > SDRFM_Q_MAX_D || T < 1 || T > 9 * D) return -1;
-  const uint32_t nch = D / 2;
   double hmax = 0.0, hsum = 0.0;
   for (uint32_t k = 0; k < T; ++k) {
     if (!isfinite(h[k])) return -1;
@@ -47,18 +54,19 @@ int sdrfm_q_build(const float* h, uint32_t T, uint32_t D, int8_t* A, float* q_ou
     }
     if (H != 0) return -1;
   }
-  memset(A, 0, (size_t)nch * SDRFM_Q_DIGITS * 64 * 16);
-  uint32_t c0 = nch;
-  for (uint32_t c = 0; c < nch; ++c)
+  const uint32_t nsc = (D + 3) / 4;                                /* sparse K-chunks of 128 window bytes */
+  memset(A, 0, (size_t)nsc * SDRFM_Q_DIGITS * 64 * 16);
+  uint32_t c0 = nsc;
+  for (uint32_t c = 0; c < nsc; ++c)
     for (uint32_t l = 0; l < 64; ++l)
-      for (uint32_t p = 0; p < 16; ++p) {
-        const uint32_t row = l & 15u, kb = 64 * c + 16 * (l >> 4) + p;   /* window byte */
-        const uint32_t o = row >> 1, comp = row & 1u;
-        if ((kb & 1u) != comp) continue;
+      for (uint32_t sl = 0; sl < 16; ++sl) {
+        const uint32_t row = l & 15u, o = row >> 1, comp = row & 1u;
+        const uint32_t h2 = sl >> 3, q4 = (sl >> 1) & 3u, j = sl & 1u;
+        const uint32_t kb = 128 * c + 32 * (l >> 4) + 16 * h2 + 4 * q4 + comp + 2 * j;   /* window byte of this kept slot */
         const int k = (int)(8 * D + D * o + D - 1) - (int)(kb >> 1);
-        if (k < 0 || k >= (int)T) continue;
+        if (kb >= 32 * D || k < 0 || k >= (int)T) continue;
         for (int t = 0; t < SDRFM_Q_DIGITS; ++t) {
-          A[(((size_t)c * SDRFM_Q_DIGITS + t) * 64 + l) * 16 + p] = dig[t][k];
+          A[(((size_t)c * SDRFM_Q_DIGITS + t) * 64 + l) * 16 + sl] = dig[t][k];
           if (dig[t][k] != 0 && c < c0) c0 = c;
         }
       }

@@ -30,6 +30,7 @@
 #include <type_traits>
 
 #include "../../include/sdrfm.h"
+#include "../../include/sdrfm_dev.h"
 #include "sdrfm_math.h"
 #include "sdrfm_q.h"
 
@@ -1678,13 +1679,13 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
     // oracle, tolerance 1e-5), so a handle created with SDRFM_CFG_BIT_EXACT never selects it.
     if (!(cfg->flags & SDRFM_CFG_BIT_EXACT) && cfg->fir_decim == SDRFM_Q_D && cfg->audio_taps == SDRFM_Q_TA &&
         cfg->audio_decim == SDRFM_Q_DA && cfg->fir_taps <= 9 * SDRFM_Q_D) {
-      int8_t* tab = (int8_t*)malloc((SDRFM_Q_D / 2) * SDRFM_Q_DIGITS * 64 * 16);
+      int8_t* tab = (int8_t*)malloc(SDRFM_Q_SPARSE_CHUNKS(SDRFM_Q_D) * SDRFM_Q_DIGITS * 64 * 16);
       float qs = 0.f, qc = 0.f;
       uint32_t c0 = 0;
       if (tab && sdrfm_q_build(hc, cfg->fir_taps, cfg->fir_decim, tab, &qs, &qc, &c0) == 0 &&
-          hipMalloc(&h->d_qA, (SDRFM_Q_D / 2) * SDRFM_Q_DIGITS * 64 * 16) == hipSuccess &&
-          hipMemcpy(h->d_qA, tab, (SDRFM_Q_D / 2) * SDRFM_Q_DIGITS * 64 * 16, hipMemcpyHostToDevice) == hipSuccess) {
-        h->q_scale = qs; h->q_cst = qc; h->q_c0 = c0 > 2 ? 2 : c0;
+          hipMalloc(&h->d_qA, SDRFM_Q_SPARSE_CHUNKS(SDRFM_Q_D) * SDRFM_Q_DIGITS * 64 * 16) == hipSuccess &&
+          hipMemcpy(h->d_qA, tab, SDRFM_Q_SPARSE_CHUNKS(SDRFM_Q_D) * SDRFM_Q_DIGITS * 64 * 16, hipMemcpyHostToDevice) == hipSuccess) {
+        h->q_scale = qs; h->q_cst = qc; h->q_c0 = c0 > 1 ? 1 : c0;
         h->q_nslot = 5; h->q_waves_per_cu = 12;
 #ifdef SDRFM_DEV
         if (const char* e = getenv("SDRFM_Q_NSLOT")) h->q_nslot = (uint32_t)atoi(e);
@@ -2098,6 +2099,7 @@ int sdrfm_ring_collect(sdrfm_ring_t* r, float* audio, uint32_t audio_cap, uint32
   return SDRFM_OK;
 }
 
+#ifdef SDRFM_DEV   // counters of the instrumented kernels: development library only
 /* Profiling aid (SDRFM_PHASE_PROFILE=1 at create): cumulative shader cycles per phase of the fast kernel, summed over
  * waves: out[0..4] = stage, FIR, discriminator, audio, carry; out[5] = sub-tiles; out[6] = waves. Resets the counters. */
 int sdrfm_debug_phase_cycles(sdrfm_t* h, unsigned long long* out8) {
@@ -2116,6 +2118,8 @@ int sdrfm_debug_phase_cycles(sdrfm_t* h, unsigned long long* out8) {
     for (int i = 0; i < 8; ++i) out8[i] += tmp[8 * g + i];
   return SDRFM_OK;
 }
+
+#endif
 
 /* Test hook: K3 evaluated ON THE DEVICE for n operand sets (host arrays in, host arrays out): out_scalar uses the scalar
  * routine of the generic kernel / state hand-over, out_pair the packed two-at-a-time routine of the fast kernels. */
@@ -2140,6 +2144,7 @@ int sdrfm_debug_discriminate(int device, const float* yr, const float* yi, const
   return rc;
 }
 
+#ifdef SDRFM_DEV
 /* Profiling aid: raw dump of the 560 debug words (slots 520+4x.. = per-XCC min/max wave start, min/max wave end in 100 MHz ticks). */
 int sdrfm_debug_raw(sdrfm_t* h, unsigned long long* out512) {
   if (!h || !out512) return SDRFM_EINVAL;
@@ -2150,8 +2155,10 @@ int sdrfm_debug_raw(sdrfm_t* h, unsigned long long* out512) {
   return SDRFM_OK;
 }
 
+#endif
+
 #ifdef SDRFM_DEV
-/* Development library only (not in include/sdrfm.h): copy of the first n debug words (design S: 16 time stamps per wave of the
+/* Development library only (include/sdrfm_dev.h): copy of the first n debug words (design S: 16 time stamps per wave of the
  * launch tagged by the 16th call after create / after the last read). */
 int sdrfm_dev_read_debug(sdrfm_t* h, unsigned long long* out, uint32_t n) {
   if (!h || !out || !h->d_dbg || !h->stream_profile || n > 32u * 16384u) return SDRFM_EINVAL;

@@ -22,7 +22,7 @@ struct SdrfmQParams {
   const uint8_t* hist_b_in;     // [n_streams][T-1] raw I/Q byte pairs
   uint8_t* hist_b_out;
   float2* hist_x_out;           // [n_streams][T-1] the same samples DC-shifted (the generic kernel's history format)
-  const int8_t* A;              // operand tables [5][3][64][16] (qtaps.c)
+  const int8_t* A;              // operand tables [3][3][64][16]: sparse K-chunk, digit, lane, kept slot (qtaps.c)
   const float* g;               // audio taps g[0..32)
   float q0, q2, cst;            // y = q0 * (S0 + 256 S1) + q2 * S2 + cst
   uint32_t T;                   // channel taps (for the history hand-over only; the arithmetic is in the tables)
@@ -41,7 +41,9 @@ struct SdrfmQParams {
 
 // LDS bytes of one wave for a ring of `nslot` KiB (nslot = 5, 10 or 15)
 uint32_t sdrfm_q_lds_bytes(uint32_t nslot);
-// Enqueue one call: grid = n_streams * runs one-wave workgroups.  first_chunk = 0, 1 or 2 (from sdrfm_q_build).
+// one-wave workgroups of this variant the runtime says a CU can hold at once (0 = unknown)
+int sdrfm_q_blocks_per_cu(uint32_t first_chunk, uint32_t nslot);
+// Enqueue one call: grid = n_streams * runs one-wave workgroups.  first_chunk = 0 or 1 (from sdrfm_q_build).
 // Returns hipSuccess or the launch error.
 hipError_t sdrfm_q_launch(const SdrfmQParams& p, uint32_t first_chunk, uint32_t nslot, hipStream_t stream);
 // One-time per-process kernel attribute set-up (dynamic LDS above 64 KiB is never needed; kept for symmetry): returns 0.

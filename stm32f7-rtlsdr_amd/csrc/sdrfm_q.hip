@@ -19,7 +19,8 @@
  *       LDS ring of NSLOT KiB, filled NSLOT KiB ahead of the step being computed
  *   LDS --ds_read_b128: lane (column n, K-group g) reads bytes [160 (n-1) + 64 c + 16 g, +16) of the step for chunk c = the
  *       B operand as the MFMA wants it (conflict-free: lane stride 160 B)--> v_xor 0x80808080
- *   5 chunks x 3 digits v_mfma_i32_16x16x64_i8 (A = tap tables, wave-constant, 60 VGPRs) --> S0, S1, S2 exact in i32
+ *   3 K-chunks of 128 bytes x 3 digits v_smfmac_i32_16x16x128_i8 (A = tap tables, exactly 2:4 sparse: I rows hold taps at even
+ *   bytes, Q rows at odd ones; wave-constant, 36 VGPRs + one index word) --> S0, S1, S2 exact in i32
  *   --> y = fma(f32(S0 + (S1 << 8)), q, fma(f32(S2), 65536 q, 0.5 sum h)): lane (n, g) holds (I, Q) of outputs 8 n + 2 g, +1
  *   --> y[m-1] of the lane's first output from lane - 16 (ds_bpermute) --> K3 twice (scalar code: packed f32 instructions stall
  *       the matrix pipe, profiles/ubench_r03) --> d's into an LDS buffer
@@ -38,6 +39,7 @@
 #include "sdrfm_q.h"
 
 typedef int qi4_t __attribute__((ext_vector_type(4)));
+typedef int qi8_t __attribute__((ext_vector_type(8)));
 typedef float qf2_t __attribute__((ext_vector_type(2)));   // (LDS reads use ext vectors: a HIP float2 struct load makes the compiler drain vmcnt)
 __device__ void q_raw_buffer_load_lds(qi4_t rsrc, __attribute__((address_space(3))) void* lds, int size, int voffset, int soffset,
                                       int offset, int aux) __asm("llvm.amdgcn.raw.buffer.load.lds");
@@ -45,22 +47,53 @@ __device__ void q_raw_buffer_load_lds(qi4_t rsrc, __attribute__((address_space(3
 namespace {
 
 constexpr int QD = (int)SDRFM_Q_D, QTA = (int)SDRFM_Q_TA, QDA = (int)SDRFM_Q_DA;
-constexpr int NCH = QD / 2;                     // K-chunks of 64 bytes per window (two blocks of 16 D bytes)
+constexpr int NCH = QD / 2;                     // 64-byte pieces of a window (two blocks of 16 D bytes): one ds_read_b128 per lane each
+constexpr int NSC = (int)SDRFM_Q_SPARSE_CHUNKS(SDRFM_Q_D);   // K-chunks of 128 window bytes: one v_smfmac_i32_16x16x128_i8 per digit each
 constexpr int BLKB = 16 * QD;                   // bytes per block of 8 outputs
 constexpr int STEPB = 16 * BLKB;                // bytes per step
 constexpr int PRE = BLKB;                       // pre-halo: the block before the ring's first byte
 constexpr int DB0 = 128;                        // d buffer: word DB0 + sigma = first d of the current audio stage
 constexpr int DBW = DB0 + 656;                  // words
 #ifndef SDRFM_Q_AUX
-#define SDRFM_Q_AUX 0   // cache policy of the ring's fetches (2 = nt)
+#define SDRFM_Q_AUX 2   // cache policy of the ring's fetches: 2 = nt (streamed once; measured 0.4-1 us per launch better than the default policy)
 #endif
 constexpr int OOBV = (int)0x80000000;           // a voffset that is out of range for every row (num_records < 2^31)
+
+// K3 for design Q: the spec's conjugate product (sdrfm_math.h: one fused, two rounded products) and this kernel's own atan2 — the
+// same range reduction as sdrfm_atan2f with a shorter minimax polynomial (6 coefficients in s = v^2, |error| <= 3.9e-7 rad
+// evaluated in fp32; sdrfm_atan2f: 8 coefficients, 6.5e-8), written for the fewest vector instructions: the vector pipe is what
+// bounds this kernel, and the audio stays within 1e-6 of the oracle (tolerance 1e-5).  (0, 0) -> 0 through the clamp of the
+// larger magnitude (no select); scalar code on purpose (packed f32 instructions stall the matrix pipe: profiles/ubench_r03).
+__device__ __forceinline__ float q_discriminate(float yr, float yi, float pr, float pi) {
+  const float re = __builtin_fmaf(yr, pr, yi * pi);
+  const float im = yi * pr - yr * pi;
+  const float ax = __builtin_fabsf(re), ay = __builtin_fabsf(im);
+  const float mx = __builtin_fmaxf(__builtin_fmaxf(ax, ay), 0x1p-120f), mn = __builtin_fminf(ax, ay);   // v_max3_f32, v_min_f32
+  const float v = mn * __builtin_amdgcn_rcpf(mx);
+  const float s2 = v * v;
+  float q = 0x1.e34882p-8f;
+  q = __builtin_fmaf(q, s2, -0x1.22fc74p-5f);
+  q = __builtin_fmaf(q, s2, 0x1.509024p-4f);
+  q = __builtin_fmaf(q, s2, -0x1.12688cp-3f);
+  q = __builtin_fmaf(q, s2, 0x1.96c562p-3f);
+  q = __builtin_fmaf(q, s2, -0x1.554086p-2f);
+  float a = __builtin_fmaf(v, s2 * q, v);
+  if (ay > ax) a = 0x1.921fb6p+0f - a;
+  if (re < 0.0f) a = 0x1.921fb6p+1f - a;
+  return __builtin_copysignf(a, im);
+}
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   static_assert(N >= 0 && N < 16, "vmcnt immediate");
   __builtin_amdgcn_s_waitcnt(0x0f70 | N);
 }
+
+#ifdef SDRFM_Q_PHASES   // development harness: shader cycles per phase of a step, summed per wave (words 8..15 of the wave's 16 debug words)
+#define Q_PHASE(i) do { const unsigned long long tn_ = __builtin_readcyclecounter(); t_ph[i] += tn_ - t_last; t_last = tn_; } while (0)
+#else
+#define Q_PHASE(i) do { } while (0)
+#endif
 
 template <int C0, int NSLOT>
 __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
@@ -73,9 +106,13 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
   const int s0 = (int)(((uint64_t)run * p.steps_total) / p.runs), s1 = (int)(((uint64_t)(run + 1) * p.steps_total) / p.runs);
   if (s0 >= s1) return;
 #ifdef SDRFM_Q_STAMPS   // development harness (tools/qbench): per-wave time stamps, 8 words per wave
-  unsigned long long* const tsp = p.dbg ? p.dbg + 8 * (size_t)blockIdx.x : nullptr;
+  unsigned long long* const tsp = p.dbg ? p.dbg + 16 * (size_t)blockIdx.x : nullptr;
   unsigned long long t_wait = 0, t_first = 0;
   const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long c_entry = __builtin_readcyclecounter();
+#endif
+#ifdef SDRFM_Q_PHASES
+  unsigned long long t_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = 0;
 #endif
   const bool warm = s0 > 0, last_run = (uint32_t)s1 == p.steps_total;
   const int ks = warm ? s0 - 1 : s0, nsteps = s1 - ks;
@@ -121,9 +158,9 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
   asm volatile("" ::: "memory");   // the ring's first requests leave the CU before the (L2-resident) tables are fetched
   // ---- wave constants: tap tables (A operands), audio taps.  15 KiB per wave out of L2: issued AFTER the ring's prologue so that
   // the HBM requests are not queued behind them in the CU's texture path (they come back in order, right after the first bytes)
-  qi4_t At[NCH - C0][SDRFM_Q_DIGITS];
+  qi4_t At[NSC - C0][SDRFM_Q_DIGITS];
 #pragma unroll
-  for (int c = C0; c < NCH; ++c)
+  for (int c = C0; c < NSC; ++c)
 #pragma unroll
     for (int t = 0; t < SDRFM_Q_DIGITS; ++t)
 #if defined(SDRFM_Q_ABLATE) && (SDRFM_Q_ABLATE & 4)
@@ -131,9 +168,11 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
 #else
       At[c - C0][t] = *reinterpret_cast<const qi4_t*>(p.A + ((size_t)((c * SDRFM_Q_DIGITS + t) * 64 + lane)) * 16);
 #endif
+  const int sidx = (lane & 1) ? (int)0xDDDDDDDD : (int)0x88888888;   // 2:4 index word: a Q row keeps positions 1, 3 of every four, an I row 0, 2
   float gr[QTA];                                                // gr[k] multiplies the k-th oldest d of a window
 #pragma unroll
-  for (int k = 0; k < QTA; ++k) gr[k] = p.g[QTA - 1 - k];
+  for (int k = 0; k < QTA; ++k)                                 // wave-uniform: kept in SGPRs (the tap tables take 60 VGPRs; four waves per SIMD need the rest)
+    gr[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.g[QTA - 1 - k])));
 
   int slot = 0;                                                 // ring slot of the next chunk
   int ringoff = 0;                                              // ring byte offset of the current step
@@ -145,29 +184,36 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
   const int dlane = 8 * n + 2 * g;
   const int ylast_step = ((int)p.M - 1) >> 7, ylast_lane = ((((int)p.M - 1) & 127) >> 3) + 16 * ((((int)p.M - 1) & 7) >> 1);
 
-  for (int kk = 0; kk < nsteps; ++kk) {
-    // ---- this step's bytes have landed: everything but the NSLOT-4 youngest chunks --------------------------------------------
+  // (A version software-pipelined by one stage — the window of step kk + 1 read, and the ring refilled, while the discriminators of
+  // step kk run — measured 33.4 us against 30.5 us for this straight order on the same box: the earlier wait for the next step's bytes
+  // costs more than the hidden LDS round trip saves.  Not kept.)
+  constexpr int NB = 2 * NSC - 2 * C0;                          // 64-byte pieces a lane reads per step: 2 NSC, the last one (when D / 2 is odd)
+  qi4_t B[NB];                                                  // lies beyond the window — the tables hold no tap there, it only completes
+                                                                // the last issue's B operand
+  auto read_step = [&](qi4_t (&dst)[NB]) {                      // wait for the step at `ringoff`, read its window, park the halo at a wrap
 #ifdef SDRFM_Q_STAMPS
     const unsigned long long tw0 = __builtin_readcyclecounter();
 #endif
-    wait_vmcnt<NSLOT - 4>();
+    wait_vmcnt<NSLOT - 4>();                                    // this step's bytes have landed: everything but the NSLOT-4 youngest chunks
     asm volatile("" ::: "memory");
 #ifdef SDRFM_Q_STAMPS
     t_wait += __builtin_readcyclecounter() - tw0;
-    if (kk == 0) t_first = __builtin_amdgcn_s_memrealtime();
+    if (t_first == 0) t_first = __builtin_amdgcn_s_memrealtime();
 #endif
-    qi4_t B[NCH - C0];
     const unsigned char* wb = smem + baddr + ringoff;
 #pragma unroll
-    for (int c = C0; c < NCH; ++c) B[c - C0] = *reinterpret_cast<const qi4_t*>(wb + 64 * c);
+    for (int c = 2 * C0; c < 2 * NSC; ++c) dst[c - 2 * C0] = *reinterpret_cast<const qi4_t*>(wb + 64 * c);
     if (ringoff + STEPB == RINGB) {                             // the next step starts the ring over: its pre-halo = the ring's last block
       if (lane < BLKB / 16) {
         const qi4_t hcp = *reinterpret_cast<const qi4_t*>(smem + PRE + RINGB - BLKB + 16 * lane);
         *reinterpret_cast<qi4_t*>(smem + 16 * lane) = hcp;
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the slots this step read are free now: refill them
-    if (kk > 0 && !(kk & 1)) {
+    ringoff = (ringoff + STEPB == RINGB) ? 0 : ringoff + STEPB;
+  };
+  auto refill_step = [&](int k) {                               // step k's window is in registers: its slots are free, refill them
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (k > 0 && !(k & 1)) {
       q_raw_buffer_load_lds(rsrc, slot_ptr(slot), 16, vpos, 0, 0, SDRFM_Q_AUX);
       vpos += 1024;
       slot = (slot + 1 == NSLOT) ? 0 : slot + 1;
@@ -176,20 +222,33 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
     q_raw_buffer_load_lds(rsrc, slot_ptr(slot), 16, vpos, 0, 1024, SDRFM_Q_AUX);   // chunk numbers = 0 or 2 mod 5); offset:1024 moves both addresses
     slot = (slot + 2 >= NSLOT) ? slot + 2 - NSLOT : slot + 2;
     vpos += 2048;
-
+  };
+  for (int kk = 0; kk < nsteps; ++kk) {
+#ifdef SDRFM_Q_PHASES
+    t_last = __builtin_readcyclecounter();
+#endif
+    read_step(B);
+    Q_PHASE(1);                                                 // wait for the step's bytes, window reads issued
+    refill_step(kk);
+    Q_PHASE(2);                                                 // LDS round trip of the window, refill issue
     // ---- K2 on the matrix pipe ------------------------------------------------------------------------------------------------
     qi4_t acc[SDRFM_Q_DIGITS];
 #pragma unroll
     for (int t = 0; t < SDRFM_Q_DIGITS; ++t) acc[t] = qi4_t{0, 0, 0, 0};
+    constexpr int XM = (int)0x80808080;
 #pragma unroll
-    for (int c = C0; c < NCH; ++c) {
-      const qi4_t b = B[c - C0] ^ qi4_t{(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};   // byte - 128 as i8
+    for (int c = 0; c < NB - 1 + (NCH & 1 ? 0 : 1); ++c) B[c] = B[c] ^ qi4_t{XM, XM, XM, XM};   // byte - 128 as i8 (not the piece beyond the window)
+#pragma unroll
+    for (int c = C0; c < NSC; ++c) {
+      // 128 window bytes per issue: the lane's two 16-byte pieces 64 bytes apart
+      const qi4_t lo = B[2 * c - 2 * C0], hi = B[2 * c + 1 - 2 * C0];
+      const qi8_t b = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
       for (int t = 0; t < SDRFM_Q_DIGITS; ++t) {
 #if defined(SDRFM_Q_ABLATE) && (SDRFM_Q_ABLATE & 2)
-        acc[t] += At[c - C0][t] & b;
+        acc[t] += At[c - C0][t] & lo;
 #else
-        acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(At[c - C0][t], b, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_smfmac_i32_16x16x128_i8(At[c - C0][t], b, acc[t], sidx, 0, 0);
 #endif
       }
     }
@@ -200,17 +259,25 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
       const int s01 = acc[0][r] + acc[1][r] * 256;              // exact: |S0| <= 2^20, |S1 << 8| <= 2^28
       y[r] = __builtin_fmaf((float)s01, p.q0, __builtin_fmaf((float)acc[2][r], p.q2, p.cst));
     }
+#ifdef SDRFM_Q_PHASES
+    asm volatile("" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
+#endif
+    Q_PHASE(3);                                                 // xor, MFMAs, recombination
     // ---- K3: y[m-1] of the lane's first output sits in lane - 16 (or is the previous step's last output) -------------------------
     float pr = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(srcaddr, __builtin_bit_cast(int, y[2])));
     float pi = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(srcaddr, __builtin_bit_cast(int, y[3])));
     if (lane == 0) { pr = cr; pi = ci; }
+#ifdef SDRFM_Q_PHASES
+    asm volatile("" : "+v"(pr), "+v"(pi));
+#endif
+    Q_PHASE(4);                                                 // neighbour exchange
     cr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y[2]), 63));
     ci = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y[3]), 63));
 #if defined(SDRFM_Q_ABLATE) && (SDRFM_Q_ABLATE & 1)   // timing experiments of the development harness only (wrong results)
     const float d0 = y[0] + pr + y[1] * pi, d1 = y[2] + y[3] * y[1] + y[0];
 #else
-    const float d0 = sdrfm_discriminate(y[0], y[1], pr, pi);
-    const float d1 = sdrfm_discriminate(y[2], y[3], y[0], y[1]);
+    const float d0 = q_discriminate(y[0], y[1], pr, pi);
+    const float d1 = q_discriminate(y[2], y[3], y[0], y[1]);
 #endif
     {
       float* dst = db + DB0 + sigma + 128 * osm + dlane;
@@ -222,25 +289,34 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
     if (last_run && kk == nsteps - 1 && lane < QTA - 1)
       p.hist_d_out[(size_t)stream * (QTA - 1) + lane] = db[DB0 + sigma + ((int)p.M - (QTA - 1) + lane - mbase)];
     ++osm;
-    ringoff = (ringoff + STEPB == RINGB) ? 0 : ringoff + STEPB;
+#ifdef SDRFM_Q_PHASES
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    Q_PHASE(5);                                                 // discriminators, d write
 
     // ---- K4: 128 audio outputs per five owned steps, two consecutive outputs per lane -------------------------------------------
     if (osm == 5 || (kk == nsteps - 1 && osm > 0)) {
       int jend = jst + 128;
       if (jend > j1) jend = j1;
       const float* w = db + DB0 + sigma + phi + 10 * lane - (QTA - 1);   // oldest d of output jst + 2 lane: an even word
-      float dw[QTA + QDA + 1];
-#pragma unroll
-      for (int i = 0; i < (QTA + QDA + 1) / 2; ++i) {
-        const qf2_t v = *reinterpret_cast<const qf2_t*>(w + 2 * i);
-        dw[2 * i] = v.x;
-        dw[2 * i + 1] = v.y;
-      }
+      // two chains side by side, each in the oracle's order (oldest d first); the 38-word window is read eight words at a time so
+      // that it never occupies more than a dozen registers (the tap tables leave few)
       float a0 = 0.0f, a1 = 0.0f;
+      float dw[QTA + QDA + 3];
 #pragma unroll
-      for (int k = 0; k < QTA; ++k) {                          // the oracle's chain order: oldest d first
-        a0 = __builtin_fmaf(gr[k], dw[k], a0);
-        a1 = __builtin_fmaf(gr[k], dw[QDA + k], a1);
+      for (int blk = 0; blk < (QTA + QDA + 3) / 8; ++blk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const qf2_t v = *reinterpret_cast<const qf2_t*>(w + 8 * blk + 2 * i);
+          dw[8 * blk + 2 * i] = v.x;
+          dw[8 * blk + 2 * i + 1] = v.y;
+        }
+#pragma unroll
+        for (int e = 8 * blk; e < 8 * blk + 8; ++e) {            // window word e: tap e of output 0, tap e - 5 of output 1
+          if (e < QTA) a0 = __builtin_fmaf(gr[e], dw[e], a0);
+          if (e >= QDA && e - QDA < QTA) a1 = __builtin_fmaf(gr[e - QDA], dw[e], a1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
       float* out = p.audio + (size_t)stream * p.audio_stride;
       const int j = jst + 2 * lane;
@@ -255,6 +331,7 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
         jst += 128;
         mbase += 640;
       }
+      Q_PHASE(6);                                               // audio stage
     }
   }
 #ifdef SDRFM_Q_STAMPS
@@ -275,7 +352,10 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
 #ifdef SDRFM_Q_STAMPS
   if (tsp && lane == 0) {
     tsp[0] = t_entry; tsp[1] = t_first; tsp[2] = t_loop; tsp[3] = __builtin_amdgcn_s_memrealtime(); tsp[4] = t_wait;
-    tsp[5] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7; tsp[6] = (unsigned long long)nsteps;
+#ifdef SDRFM_Q_PHASES
+    for (int i = 0; i < 8; ++i) tsp[8 + i] = t_ph[i];
+#endif
+    tsp[5] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7; tsp[6] = (unsigned long long)nsteps; tsp[7] = __builtin_readcyclecounter() - c_entry;
   }
 #endif
 }
@@ -283,10 +363,10 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
 typedef void (*QKernel)(SdrfmQParams);
 struct QVariant { uint32_t c0, nslot; QKernel k; const char* name; };
 #define QV(C0_, NS_) { C0_, NS_, k_mfir<C0_, NS_>, "k_mfir<" #C0_ "," #NS_ ">" }
-const QVariant kQVariants[] = {QV(0, 5), QV(0, 10), QV(0, 15), QV(1, 5), QV(1, 10), QV(1, 15), QV(2, 5), QV(2, 10), QV(2, 15)};
+const QVariant kQVariants[] = {QV(0, 5), QV(0, 10), QV(0, 15), QV(1, 5), QV(1, 10), QV(1, 15)};
 
 const QVariant* q_find(uint32_t c0, uint32_t nslot) {
-  if (c0 > 2) c0 = 2;
+  if (c0 > 1) c0 = 1;
   for (const QVariant& v : kQVariants)
     if (v.c0 == c0 && v.nslot == nslot) return &v;
   return nullptr;
@@ -299,6 +379,13 @@ uint32_t sdrfm_q_lds_bytes(uint32_t nslot) { return (uint32_t)(PRE + 1024 * (int
 const char* sdrfm_q_kernel_symbol(uint32_t first_chunk, uint32_t nslot) {
   const QVariant* v = q_find(first_chunk, nslot);
   return v ? v->name : "";
+}
+
+int sdrfm_q_blocks_per_cu(uint32_t first_chunk, uint32_t nslot) {
+  const QVariant* v = q_find(first_chunk, nslot);
+  int nb = 0;
+  if (!v || hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(v->k), 64, sdrfm_q_lds_bytes(nslot)) != hipSuccess) return 0;
+  return nb;
 }
 
 hipError_t sdrfm_q_launch(const SdrfmQParams& p, uint32_t first_chunk, uint32_t nslot, hipStream_t stream) {

@@ -16,7 +16,9 @@ extern "C" {
 #define SDRFM_Q_HMAX (127 * 65793)          /* largest |H| three digits in [-128, 127] can hold: 127 (65536 + 256 + 1) */
 #define SDRFM_Q_MAX_D 16                    /* FIR decimation: even, <= 16 (D / 2 K-chunks of 64 bytes per window) */
 
-/* h[0..T) -> A[D/2][3][64][16] (chunk, digit, lane, byte), the fp32 scale q (y = q * (S0 + 256 S1 + 65536 S2) + cst),
+#define SDRFM_Q_SPARSE_CHUNKS(D) (((D) + 3u) / 4u)   /* K-chunks of 128 window bytes (v_smfmac_i32_16x16x128_i8) per digit */
+
+/* h[0..T) -> A[ceil(D/4)][3][64][16] (sparse chunk, digit, lane, kept slot), the fp32 scale q (y = q * (S0 + 256 S1 + 65536 S2) + cst),
  * cst = 0.5 * sum(h), and the first chunk that holds a non-zero tap (chunks before it need no MFMA).
  * Returns 0, or -1 when the geometry / taps cannot be served (T > 9 D, D odd, non-finite or all-zero taps). */
 int sdrfm_q_build(const float* h, uint32_t T, uint32_t D, int8_t* A, float* q, float* cst, uint32_t* first_chunk);

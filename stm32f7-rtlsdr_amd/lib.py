@@ -15,7 +15,6 @@ F_DEVICE_PTRS = 1
 ABI_SYMBOLS = [
     "sdrfm_create", "sdrfm_destroy", "sdrfm_reset", "sdrfm_audio_count", "sdrfm_process", "sdrfm_process_batch",
     "sdrfm_set_stream", "sdrfm_synchronize", "sdrfm_kernel_name", "sdrfm_abi_version", "sdrfm_strerror",
-    "sdrfm_host_atan2f", "sdrfm_host_discriminate", "sdrfm_debug_phase_cycles", "sdrfm_debug_discriminate", "sdrfm_debug_raw",
     "sdrfm_wbfm_create", "sdrfm_wbfm_destroy", "sdrfm_wbfm_reset", "sdrfm_wbfm_audio_count", "sdrfm_wbfm_process_batch",
     "sdrfm_wbfm_set_stream", "sdrfm_wbfm_synchronize", "sdrfm_wbfm_kernel_name", "sdrfm_rtl_pack_fir", "sdrfm_rtl_resampler", "sdrfm_e4k_pll_params",
     "sdrfm_spectrum_create", "sdrfm_spectrum_destroy", "sdrfm_spectrum_process_batch", "sdrfm_spectrum_set_stream",
@@ -25,6 +24,11 @@ ABI_SYMBOLS = [
     "sdrfm_pcm_sink_set_stream", "sdrfm_pcm_sink_synchronize", "sdrfm_pcm_sink_get_state",
     "sdrfm_ring_create", "sdrfm_ring_destroy", "sdrfm_ring_submit", "sdrfm_ring_collect",
 ]
+
+
+# include/sdrfm_dev.h: test hooks the product library also exports / development-library-only aids (not the drop-in boundary)
+TEST_HOOK_SYMBOLS = ["sdrfm_host_atan2f", "sdrfm_host_discriminate", "sdrfm_debug_discriminate", "sdrfm_q_build"]
+DEV_ONLY_SYMBOLS = ["sdrfm_debug_phase_cycles", "sdrfm_debug_raw", "sdrfm_dev_read_debug"]
 
 
 class SdrfmError(RuntimeError):
@@ -110,10 +114,13 @@ def load_library(dev=False):
     lib.sdrfm_host_atan2f.restype = C.c_float
     lib.sdrfm_host_discriminate.argtypes = [C.c_float] * 4
     lib.sdrfm_host_discriminate.restype = C.c_float
-    lib.sdrfm_debug_phase_cycles.argtypes = [vp, C.POINTER(C.c_uint64)]
-    lib.sdrfm_debug_phase_cycles.restype = C.c_int
-    lib.sdrfm_debug_raw.argtypes = [vp, C.POINTER(C.c_uint64)]
-    lib.sdrfm_debug_raw.restype = C.c_int
+    if dev:
+        lib.sdrfm_debug_phase_cycles.argtypes = [vp, C.POINTER(C.c_uint64)]
+        lib.sdrfm_debug_phase_cycles.restype = C.c_int
+        lib.sdrfm_debug_raw.argtypes = [vp, C.POINTER(C.c_uint64)]
+        lib.sdrfm_debug_raw.restype = C.c_int
+    lib.sdrfm_q_build.argtypes = [vp, u32, u32, vp, C.POINTER(C.c_float), C.POINTER(C.c_float), u32p]
+    lib.sdrfm_q_build.restype = C.c_int
     lib.sdrfm_debug_discriminate.argtypes = [C.c_int] + [vp] * 6 + [u32]
     lib.sdrfm_debug_discriminate.restype = C.c_int
     lib.sdrfm_wbfm_create.argtypes = [C.POINTER(WbfmConfig), C.POINTER(vp)]

@@ -26,6 +26,29 @@ def test_library_exports_every_declared_symbol(pkg):
     assert lib.sdrfm_abi_version() == 1
 
 
+def test_test_hooks_live_in_their_own_header(pkg):
+    """include/sdrfm.h is the drop-in boundary and nothing else; the hooks tests use are declared in include/sdrfm_dev.h.  The
+    product library exports the arithmetic hooks (they compute nothing for a caller) but no instrumented-kernel accessor."""
+    import subprocess
+    boundary = _declared_symbols()
+    src = open(os.path.join(ROOT, "include", "sdrfm_dev.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    hooks = sorted(set(re.findall(r"\b(sdrfm_[a-z0-9_]+)\s*\(", src)))
+    assert sorted(hooks) == sorted(pkg.lib.TEST_HOOK_SYMBOLS + pkg.lib.DEV_ONLY_SYMBOLS)
+    assert not set(hooks) & set(boundary)
+    assert not [s for s in boundary if "debug" in s or "_host_" in s or "_dev_" in s]
+    dyn = subprocess.run(["nm", "-D", pkg.library_path()], capture_output=True, text=True, check=True).stdout
+    for sym in pkg.lib.TEST_HOOK_SYMBOLS:
+        assert (" T " + sym) in dyn, sym
+    for sym in pkg.lib.DEV_ONLY_SYMBOLS:
+        assert sym not in dyn, sym
+    dev = pkg.library_path(dev=True)
+    if os.path.exists(dev):
+        ddyn = subprocess.run(["nm", "-D", dev], capture_output=True, text=True, check=True).stdout
+        for sym in pkg.lib.TEST_HOOK_SYMBOLS + pkg.lib.DEV_ONLY_SYMBOLS:
+            assert (" T " + sym) in ddyn, sym
+
+
 def test_status_codes_match_usbh_status_enum(pkg):
     # USBH_OK=0, USBH_BUSY, USBH_FAIL, USBH_NOT_SUPPORTED, USBH_UNRECOVERED_ERROR
     # (Middlewares/ST/STM32_USB_Host_Library/Core/Inc/usbh_def.h:303-311)

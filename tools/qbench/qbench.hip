@@ -52,7 +52,7 @@ int main(int argc, char** argv) {
   const int M = nsamp / D, A = M / Da;
   std::vector<float> h, g;
   lowpass(h, T, 100e3 / 2.4e6); lowpass(g, Ta, 15e3 / 240e3);
-  std::vector<int8_t> At(5 * 3 * 64 * 16);
+  std::vector<int8_t> At(3 * 3 * 64 * 16);
   float q, cst; uint32_t c0;
   if (sdrfm_q_build(h.data(), T, D, At.data(), &q, &cst, &c0)) { fprintf(stderr, "sdrfm_q_build failed\n"); return 2; }
 
@@ -145,29 +145,39 @@ int main(int argc, char** argv) {
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   if (getenv("QBENCH_STAMPS")) {   // one more launch with per-wave stamps (kernel built with -DSDRFM_Q_STAMPS), summarised per XCC 0
     const size_t nw = (size_t)ns * runs;
-    unsigned long long* d_dbg; CK(hipMalloc(&d_dbg, nw * 64)); CK(hipMemset(d_dbg, 0, nw * 64));
+    unsigned long long* d_dbg; CK(hipMalloc(&d_dbg, nw * 128)); CK(hipMemset(d_dbg, 0, nw * 128));
     p.dbg = d_dbg; p.iq = d_iq + (size_t)(iters % NB) * batch;
     CK(sdrfm_q_launch(p, c0, nslot, st)); CK(hipStreamSynchronize(st));
-    std::vector<unsigned long long> hd(nw * 8);
-    CK(hipMemcpy(hd.data(), d_dbg, nw * 64, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> hd16(nw * 16), hd(nw * 8);
+    CK(hipMemcpy(hd16.data(), d_dbg, nw * 128, hipMemcpyDeviceToHost));
+    for (size_t w = 0; w < nw; ++w) for (int i = 0; i < 8; ++i) hd[8 * w + i] = hd16[16 * w + i];
     unsigned long long t0 = ~0ull;
     for (size_t w = 0; w < nw; ++w) if (hd[8 * w + 6] && hd[8 * w + 5] == 0 && hd[8 * w] < t0) t0 = hd[8 * w];
-    double sum[4] = {0, 0, 0, 0}, mx[4] = {0, 0, 0, 0}, mn[4] = {1e30, 1e30, 1e30, 1e30}, waitc = 0, steps = 0; size_t cnt = 0;
+    double sum[4] = {0, 0, 0, 0}, mx[4] = {0, 0, 0, 0}, mn[4] = {1e30, 1e30, 1e30, 1e30}, waitc = 0, steps = 0, clk_cyc = 0, clk_us = 0; size_t cnt = 0;
     for (size_t w = 0; w < nw; ++w) {
       if (!hd[8 * w + 6] || hd[8 * w + 5] != 0) continue;
       for (int i = 0; i < 4; ++i) { const double v = (double)(hd[8 * w + i] - t0) * 0.01; sum[i] += v; if (v > mx[i]) mx[i] = v; if (v < mn[i]) mn[i] = v; }
       waitc += (double)hd[8 * w + 4]; steps += (double)hd[8 * w + 6]; ++cnt;
+      clk_cyc += (double)hd[8 * w + 7]; clk_us += (double)(hd[8 * w + 3] - hd[8 * w]) * 0.01;
     }
     if (getenv("QBENCH_DUMP")) {   // raw per-wave stamps (all XCCs) for offline analysis: block, xcc, entry, first, loop_end, exit (ticks), wait, steps
       FILE* f = fopen(getenv("QBENCH_DUMP"), "w");
       for (size_t w = 0; w < nw; ++w) if (hd[8 * w + 6]) fprintf(f, "%zu %llu %llu %llu %llu %llu %llu %llu\n", w, hd[8 * w + 5], hd[8 * w], hd[8 * w + 1], hd[8 * w + 2], hd[8 * w + 3], hd[8 * w + 4], hd[8 * w + 6]);
       fclose(f);
     }
+    {
+      double ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st = 0;
+      for (size_t w = 0; w < nw; ++w) { if (!hd[8 * w + 6]) continue; st += (double)hd[8 * w + 6]; for (int i = 0; i < 8; ++i) ph[i] += (double)hd16[16 * w + 8 + i]; }
+      if (ph[0] + ph[1] + ph[3] > 0)
+        printf("{\"phase_cycles_per_step\":{\"data_wait\":%.0f,\"b_reads\":%.0f,\"refill_issue\":%.0f,\"xor_mfma_combine\":%.0f,\"neighbour\":%.0f,\"disc_dwrite\":%.0f,\"audio\":%.0f}}\n",
+               ph[0] / st, ph[1] / st, ph[2] / st, ph[3] / st, ph[4] / st, ph[5] / st, ph[6] / st);
+    }
     printf("{\"stamps_us_xcc0\":{\"waves\":%zu,\"entry\":[%.2f,%.2f,%.2f],\"first_data\":[%.2f,%.2f,%.2f],\"loop_end\":[%.2f,%.2f,%.2f],\"exit\":[%.2f,%.2f,%.2f],"
-           "\"wait_cycles_per_step\":%.0f,\"steps_per_wave\":%.2f}}\n", cnt, mn[0], sum[0] / cnt, mx[0], mn[1], sum[1] / cnt, mx[1], mn[2], sum[2] / cnt, mx[2],
-           mn[3], sum[3] / cnt, mx[3], waitc / steps, steps / cnt);
+           "\"wait_cycles_per_step\":%.0f,\"steps_per_wave\":%.2f,\"shader_GHz\":%.3f}}\n", cnt, mn[0], sum[0] / cnt, mx[0], mn[1], sum[1] / cnt, mx[1], mn[2], sum[2] / cnt, mx[2],
+           mn[3], sum[3] / cnt, mx[3], waitc / steps, steps / cnt, clk_cyc / clk_us * 1e-3);
   }
   const double us = ms * 1e3 / iters, bytes = (double)ns * nsamp * 2.08;
+  printf("{\"blocks_per_cu_api\":%d}\n", sdrfm_q_blocks_per_cu(c0, nslot));
   printf("{\"kernel\":\"%s\",\"ns\":%d,\"nsamp\":%d,\"T\":%d,\"nslot\":%d,\"runs\":%d,\"mode\":\"%s\",\"first_chunk\":%u,\"checked_streams\":%zu,"
          "\"max_scaled_err\":%.3g,\"worst_at\":[%d,%d],\"n_over_tol\":%ld,\"nonfinite\":%ld,\"state_err\":%.3g,\"us_per_launch\":%.2f,\"frac_of_8TBs\":%.4f,\"batches\":%d}\n",
          sdrfm_q_kernel_symbol(c0, nslot), ns, nsamp, T, nslot, runs, mode ? "random" : "fm", c0, chk.size(), worst, worst_s, worst_j, bad, nonfinite,

@@ -46,7 +46,7 @@ template <int NSLOT, int AUX>
 static void run(const uint8_t* d, size_t buf_kib, unsigned waves, unsigned kib_per_wave, int pattern, unsigned G, unsigned item, unsigned* sink) {
   const unsigned total = waves * kib_per_wave;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  const int iters = 20;
+  const int iters = getenv("UB_ITERS") ? atoi(getenv("UB_ITERS")) : 20;
   size_t off = 0;
   auto launch = [&] {
     if (off + total > buf_kib) off = 0;
