@@ -122,16 +122,18 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
   const int phi = QDA * j0 + QDA - 1 - 128 * s0;                // its newest d, relative to the first owned output (0..4)
   const int sigma = (phi + 1) & 1;                              // shifts the d buffer so that every lane's window starts on an even word
 
-  // ---- carried state (the stream's first run) -----------------------------------------------------------------------------
+  // ---- carried state (the stream's first run): the loads are issued here and land in LDS after the ring's prologue has left ------
   float cr = 0.0f, ci = 0.0f;                                   // y[m-1] of the step's first output (lane 0)
+  const int HT = (int)p.T - 1;
+  unsigned short hb0 = 0, hb1 = 0;
+  float hd0 = 0.0f;
   if (!warm) {
     const float2 yp = p.yprev_in[stream];
     cr = yp.x; ci = yp.y;
-    const int HT = (int)p.T - 1;
-    for (int k = lane; k < HT; k += 64)                         // the last T-1 samples before the call -> end of the pre-halo
-      *reinterpret_cast<unsigned short*>(smem + PRE - 2 * HT + 2 * k) =
-          reinterpret_cast<const unsigned short*>(p.hist_b_in)[(size_t)stream * HT + k];
-    if (lane < QTA - 1) db[DB0 + sigma - (QTA - 1) + lane] = p.hist_d_in[(size_t)stream * (QTA - 1) + lane];
+    const unsigned short* hbp = reinterpret_cast<const unsigned short*>(p.hist_b_in) + (size_t)stream * HT;
+    if (lane < HT) hb0 = hbp[lane];                             // the last T-1 <= 89 samples before the call
+    if (lane + 64 < HT) hb1 = hbp[lane + 64];
+    if (lane < QTA - 1) hd0 = p.hist_d_in[(size_t)stream * (QTA - 1) + lane];
   }
 
   // ---- the ring --------------------------------------------------------------------------------------------------------------
@@ -141,23 +143,23 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
   const qi4_t rsrc = {(int)(unsigned)gaddr, (int)(unsigned)(gaddr >> 32), (int)hi, 0x00020000};
   int vpos = STEPB * ks + 16 * lane;                            // this lane's byte offset in the row for the next chunk
   auto slot_ptr = [&](int slot) { return (__attribute__((address_space(3))) void*)(smem + PRE + 1024 * slot); };
+  // prologue: NSLOT chunks.  A warm-up step needs only its last four blocks and the block before them (bytes >= 1664 of the step,
+  // rounded to a line): the pieces before that are switched off by an out-of-range offset (the instruction still counts).  The
+  // first three chunks (what the first step waits for) go out first, then the requests for the L2-resident tables, then the rest of
+  // the ring: the opening burst of all waves' first steps is what every wave's start waits behind.
   {
-    // prologue: NSLOT chunks.  A warm-up step needs only its last four blocks and the block before them (bytes >= 1664 of the
-    // step, rounded to a line): the pieces before that are switched off by an out-of-range offset (the instruction still counts).
     const int v0 = warm ? OOBV : vpos;
     const int v1 = (warm && lane < 40) ? OOBV : vpos + 1024;
     q_raw_buffer_load_lds(rsrc, slot_ptr(0), 16, v0, 0, 0, SDRFM_Q_AUX);
     q_raw_buffer_load_lds(rsrc, slot_ptr(1), 16, v1, 0, 0, SDRFM_Q_AUX);
-#pragma unroll
     // (the instruction's immediate offset moves BOTH the memory address and the LDS address: a group of up to four chunks shares
     // one voffset register and one LDS base)
-    for (int q = 2; q < NSLOT; ++q) q_raw_buffer_load_lds(rsrc, slot_ptr(q & ~3), 16, vpos + 1024 * (q & ~3), 0, 1024 * (q & 3), SDRFM_Q_AUX);
-    vpos += 1024 * NSLOT;
+    q_raw_buffer_load_lds(rsrc, slot_ptr(0), 16, vpos, 0, 2048, SDRFM_Q_AUX);
   }
   __builtin_amdgcn_sched_barrier(0);
-  asm volatile("" ::: "memory");   // the ring's first requests leave the CU before the (L2-resident) tables are fetched
-  // ---- wave constants: tap tables (A operands), audio taps.  15 KiB per wave out of L2: issued AFTER the ring's prologue so that
-  // the HBM requests are not queued behind them in the CU's texture path (they come back in order, right after the first bytes)
+  asm volatile("" ::: "memory");
+  // ---- wave constants: tap tables (A operands), audio taps: 9 KiB per wave out of L2 / L1, behind the first step's HBM requests in
+  // the CU's texture path (they come back in order, right after those bytes)
   qi4_t At[NSC - C0][SDRFM_Q_DIGITS];
 #pragma unroll
   for (int c = C0; c < NSC; ++c)
@@ -174,6 +176,16 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
   for (int k = 0; k < QTA; ++k)                                 // wave-uniform: kept in SGPRs (the tap tables take 60 VGPRs; four waves per SIMD need the rest)
     gr[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.g[QTA - 1 - k])));
 
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int q = 3; q < NSLOT; ++q) q_raw_buffer_load_lds(rsrc, slot_ptr(q & ~3), 16, vpos + 1024 * (q & ~3), 0, 1024 * (q & 3), SDRFM_Q_AUX);
+  vpos += 1024 * NSLOT;
+  if (!warm) {
+    if (lane < HT) *reinterpret_cast<unsigned short*>(smem + PRE - 2 * HT + 2 * lane) = hb0;           // -> end of the pre-halo
+    if (lane + 64 < HT) *reinterpret_cast<unsigned short*>(smem + PRE - 2 * HT + 2 * (lane + 64)) = hb1;
+    if (lane < QTA - 1) db[DB0 + sigma - (QTA - 1) + lane] = hd0;
+  }
   int slot = 0;                                                 // ring slot of the next chunk
   int ringoff = 0;                                              // ring byte offset of the current step
   int osm = warm ? -1 : 0;                                      // owned steps in the d buffer since the last audio stage
@@ -341,7 +353,6 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
 
   // ---- state hand-over by the wave that holds the end of the stream's chunk --------------------------------------------------
   if (last_run) {
-    const int HT = (int)p.T - 1;
     const unsigned char* row = p.iq + (size_t)stream * p.iq_stride;
     for (int k = lane; k < HT; k += 64) {
       const unsigned raw = *reinterpret_cast<const unsigned short*>(row + 2 * ((size_t)p.N - HT + k));

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Summarise one workload of tools/profile_round3.sh: per-dispatch means of every counter for the dominant kernel, the exact fabric
+traffic (TCC_EA0_RDREQ by request size; WRREQ 64 B / 32 B), the guide's FETCH_SIZE figure beside it (x2 on gfx950 for 16-B-per-lane
+streams, /opt/skills/guides/MI355X_MICROARCH.md "HBM"), and the derived VALU-busy / clock figures."""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+work, out, tag, wl, kfilter, commit = sys.argv[1:7]
+acc, cnt, kname = defaultdict(float), defaultdict(int), None
+dur_in_pass = {}      # counter name -> mean dispatch duration (ns) IN THE PASS that collected it (clock / busy figures never mix passes)
+dsum, dcnt = defaultdict(float), defaultdict(int)
+for fn in glob.glob(os.path.join(work, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    for row in csv.DictReader(open(fn)):
+        if kfilter in row["Kernel_Name"]:
+            acc[row["Counter_Name"]] += float(row["Counter_Value"]); cnt[row["Counter_Name"]] += 1; kname = row["Kernel_Name"]
+            try:
+                dsum[row["Counter_Name"]] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"]); dcnt[row["Counter_Name"]] += 1
+            except Exception:
+                pass
+m = {k: acc[k] / cnt[k] for k in sorted(acc)}
+dur_in_pass = {k: dsum[k] / dcnt[k] for k in dsum if dcnt[k]}
+bench = {}
+try:
+    bench = json.loads(open(os.path.join(out, "%s_%s_bench_under_rocprof.json" % (tag, wl))).read())
+except Exception:
+    pass
+stats = {}
+try:
+    for row in csv.DictReader(open(os.path.join(out, "%s_%s_kernel_stats.csv" % (tag, wl)))):
+        if kfilter in row["Name"]:
+            stats = {"calls": int(row["Calls"]), "avg_ns": float(row["AverageNs"]), "min_ns": float(row["MinNs"]), "max_ns": float(row["MaxNs"])}
+except Exception:
+    pass
+rd = 32 * m.get("TCC_EA0_RDREQ_32B_sum", 0) + 64 * m.get("TCC_EA0_RDREQ_64B_sum", 0) + 128 * m.get("TCC_EA0_RDREQ_128B_sum", 0)
+wr64 = m.get("TCC_EA0_WRREQ_64B_sum", 0)
+wr = 64 * wr64 + 32 * (m.get("TCC_EA0_WRREQ_sum", 0) - wr64)
+alg = bench.get("roofline", {}).get("algorithmic_bytes_per_launch")
+res = {
+    "round": tag, "workload": wl, "commit": commit, "rocprof_kernel": kname, "kernel_name": bench.get("config", {}).get("kernel"),
+    "kernel_trace": stats,
+    "bench_kernel_ms_avg_under_tracer": bench.get("roofline", {}).get("kernel_ms_avg"),
+    "fabric_read_bytes_per_launch": rd, "fabric_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
+    "method": "reads: TCC_EA0_RDREQ_{32B,64B,128B}_sum x request size; writes: TCC_EA0_WRREQ_64B x 64 + (WRREQ - WRREQ_64B) x 32; separate --pmc passes, "
+              "per-dispatch means.  Infinity-Cache hits are included (the counters sit on the L2's fabric side).",
+    "guide_method": {"FETCH_SIZE_KiB_raw": m.get("FETCH_SIZE"), "WRITE_SIZE_KiB_raw": m.get("WRITE_SIZE"),
+                     "read_bytes_2x_FETCH_SIZE": 2048.0 * m["FETCH_SIZE"] if "FETCH_SIZE" in m else None,
+                     "note": "gfx950: FETCH_SIZE tallies 128-B requests at 64 B, so it is doubled for 16-B-per-lane streams (guide); agrees with the request-size count when every request is 128 B"},
+    "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": (rd + wr) / alg if alg else None,
+    "derived": {},
+    "counters_per_dispatch_mean": m,
+}
+if "GRBM_GUI_ACTIVE" in m and dur_in_pass.get("GRBM_GUI_ACTIVE"):
+    # GRBM_GUI_ACTIVE is summed over the 8 XCDs; the duration is the dispatch's own in the SAME counter pass
+    res["derived"]["kernel_us_in_the_counter_pass"] = dur_in_pass["GRBM_GUI_ACTIVE"] / 1e3
+    res["derived"]["effective_clock_GHz"] = m["GRBM_GUI_ACTIVE"] / 8.0 / dur_in_pass["GRBM_GUI_ACTIVE"]
+if "SQ_ACTIVE_INST_VALU" in m and "GRBM_GUI_ACTIVE" in m:
+    # SQ_ACTIVE_INST_VALU counts quad-cycles over all waves; 1024 SIMDs; kernel cycles = GRBM_GUI_ACTIVE / 8 (same pass: the SQ group
+    # of tools/profile_round3.sh carries GRBM_GUI_ACTIVE)
+    res["derived"]["valu_issue_busy_fraction"] = 4.0 * m["SQ_ACTIVE_INST_VALU"] / 1024.0 / (m["GRBM_GUI_ACTIVE"] / 8.0)
+    res["derived"]["valu_insts_per_iq_sample_per_lane"] = None
+if "SQ_VALU_MFMA_BUSY_CYCLES" in m and "GRBM_GUI_ACTIVE" in m:
+    res["derived"]["matrix_pipe_busy_fraction"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (m["GRBM_GUI_ACTIVE"] / 8.0)
+if "SQ_INSTS_VALU" in m and bench:
+    spl = bench["config"].get("streams_per_gpu", 0) * bench["config"].get("bytes_per_stream", 0) / 2.0
+    if spl:
+        res["derived"]["valu_insts_per_iq_sample_per_lane"] = m["SQ_INSTS_VALU"] * 64.0 / spl
+with open(os.path.join(out, "%s_%s_pmc.json" % (tag, wl)), "w") as f:
+    json.dump(res, f, indent=1)
+if wl == "fm256":
+    t = {k: res[k] for k in ("round", "commit", "rocprof_kernel", "kernel_name", "fabric_read_bytes_per_launch", "fabric_write_bytes_per_launch",
+                              "hbm_bytes_per_launch", "method", "guide_method", "algorithmic_bytes_per_launch", "traffic_over_algorithmic")}
+    t["workload"] = bench.get("config", {}).get("workload")
+    with open(os.path.join(out, "traffic_%s.json" % tag), "w") as f:
+        json.dump(t, f, indent=1)
+print(json.dumps({k: res[k] for k in ("workload", "kernel_name", "kernel_trace", "hbm_bytes_per_launch", "traffic_over_algorithmic", "derived")}))
