@@ -1,0 +1,185 @@
+/*
+ * multi_gpu_main.c — the multi-GPU host in plain C (north-star: "host code stays in C", "RCCL over xGMI only for the fan-out /
+ * fan-in of stream batches").  ONE process, N devices: one sdrfm_t per device (sdrfm_config.device), streams sharded
+ * in contiguous blocks (sdrfm_shard_range), no collective on the data path.  The reference's host is a single C superloop too
+ * (src/main.c:40-81); its hand-off point is RTLSDR_XFER_COMPLETE (Class/RTLSDR/Src/usbh_rtlsdr.c:1094-1097).
+ *
+ *   C1 fan-out : the root device holds the whole batch [n_streams][nbytes]; every other device receives its block with grouped
+ *                ncclSend (root) / ncclRecv (peer) — or hipMemcpyPeerAsync with --peer-copy;
+ *   hot path   : sdrfm_process_batch(SDRFM_F_DEVICE_PTRS) on every device's own stream, all devices concurrently;
+ *   C2 fan-in  : the audio blocks come back to the root the same way.
+ *
+ *   multi_gpu_main <iq.u8> <h.f32> <g.f32> <n_streams> <nbytes_per_stream> <n_gpus (0 = all)> <audio_out.f32> [--peer-copy] [--reps K]
+ *
+ * iq.u8 holds n_streams rows of nbytes_per_stream bytes.  audio_out: n_streams rows of n_audio floats.  Prints one JSON line.
+ * With --reps K the timed loop repeats fan-out -> hot path -> fan-in K times on the same batch (end-to-end rate, SURVEY 7-5 b).
+ */
+#define _POSIX_C_SOURCE 199309L   /* clock_gettime */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include "sdrfm.h"
+
+#define HIPC(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #call, hipGetErrorString(e_)); return 1; } } while (0)
+#define NCCLC(call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { fprintf(stderr, "%s: %s\n", #call, ncclGetErrorString(r_)); return 1; } } while (0)
+#define SDRC(call) do { int st_ = (call); if (st_ != SDRFM_OK) { fprintf(stderr, "%s: %s\n", #call, sdrfm_strerror(st_)); return 1; } } while (0)
+#define MAX_GPUS 16
+
+static void* slurp(const char* path, size_t* n) {
+  FILE* f = fopen(path, "rb");
+  if (!f) { perror(path); exit(2); }
+  fseek(f, 0, SEEK_END);
+  long sz = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  void* p = malloc(sz > 0 ? (size_t)sz : 1);
+  if (fread(p, 1, (size_t)sz, f) != (size_t)sz) { perror("fread"); exit(2); }
+  fclose(f);
+  *n = (size_t)sz;
+  return p;
+}
+
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 8) { fprintf(stderr, "usage: %s iq.u8 h.f32 g.f32 n_streams nbytes_per_stream n_gpus audio_out.f32 [--peer-copy] [--reps K]\n", argv[0]); return 2; }
+  size_t niq, nh, ng;
+  unsigned char* iq = (unsigned char*)slurp(argv[1], &niq);
+  float* h = (float*)slurp(argv[2], &nh);
+  float* g = (float*)slurp(argv[3], &ng);
+  const uint32_t n_streams = (uint32_t)atoi(argv[4]), nbytes = (uint32_t)atoi(argv[5]);
+  int world = atoi(argv[6]), peer_copy = 0, reps = 1;
+  for (int i = 8; i < argc; ++i) {
+    if (!strcmp(argv[i], "--peer-copy")) peer_copy = 1;
+    else if (!strcmp(argv[i], "--reps") && i + 1 < argc) reps = atoi(argv[++i]);
+  }
+  if ((size_t)n_streams * nbytes != niq || (nbytes & 1u) || !n_streams) { fprintf(stderr, "iq.u8 must hold n_streams x nbytes_per_stream bytes (even)\n"); return 2; }
+  int ndev = 0;
+  HIPC(hipGetDeviceCount(&ndev));
+  if (world <= 0 || world > ndev) world = ndev;
+  if (world > MAX_GPUS) world = MAX_GPUS;
+  if (world < 1) { fprintf(stderr, "no HIP device\n"); return 1; }
+
+  /* ---- one handle, one stream, one shard per device ----------------------------------------------------------------------- */
+  sdrfm_t* dm[MAX_GPUS];
+  hipStream_t st[MAX_GPUS];
+  unsigned char* d_iq[MAX_GPUS];
+  float* d_audio[MAX_GPUS];
+  uint32_t first[MAX_GPUS], count[MAX_GPUS], n_audio = 0;
+  ncclComm_t comm[MAX_GPUS];
+  int devs[MAX_GPUS];
+  for (int d = 0; d < world; ++d) devs[d] = d;
+  if (!peer_copy) NCCLC(ncclCommInitAll(comm, world, devs));
+  sdrfm_config cfg;
+  memset(&cfg, 0, sizeof cfg);
+  cfg.struct_size = sizeof cfg;
+  cfg.fir_taps = (uint32_t)(nh / sizeof(float)); cfg.fir_decim = 10; cfg.fir_coeffs = h;
+  cfg.audio_taps = (uint32_t)(ng / sizeof(float)); cfg.audio_decim = 5; cfg.audio_coeffs = g;
+  cfg.max_bytes_per_call = nbytes;
+  unsigned char* d_iq_root = NULL;       /* the whole batch on the root device */
+  float* d_audio_root = NULL;
+  size_t audio_stride = 0;
+  for (int d = 0; d < world; ++d) {
+    SDRC(sdrfm_shard_range(n_streams, (uint32_t)world, (uint32_t)d, &first[d], &count[d]));
+    HIPC(hipSetDevice(d));
+    HIPC(hipStreamCreateWithFlags(&st[d], hipStreamNonBlocking));
+    dm[d] = NULL; d_iq[d] = NULL; d_audio[d] = NULL;
+    if (!count[d]) continue;
+    cfg.n_streams = count[d]; cfg.device = d;
+    SDRC(sdrfm_create(&cfg, &dm[d]));
+    SDRC(sdrfm_set_stream(dm[d], (void*)st[d]));
+    SDRC(sdrfm_audio_count(dm[d], nbytes, &n_audio));
+    audio_stride = ((size_t)n_audio + 63) & ~(size_t)63;
+    if (d == 0) {
+      HIPC(hipMalloc((void**)&d_iq_root, (size_t)n_streams * nbytes));
+      HIPC(hipMalloc((void**)&d_audio_root, (size_t)n_streams * audio_stride * sizeof(float)));
+      HIPC(hipMemcpy(d_iq_root, iq, (size_t)n_streams * nbytes, hipMemcpyHostToDevice));
+      d_iq[0] = d_iq_root + (size_t)first[0] * nbytes;           /* the root's own block is used in place */
+      d_audio[0] = d_audio_root + (size_t)first[0] * audio_stride;
+    } else {
+      HIPC(hipMalloc((void**)&d_iq[d], (size_t)count[d] * nbytes));
+      HIPC(hipMalloc((void**)&d_audio[d], (size_t)count[d] * audio_stride * sizeof(float)));
+    }
+  }
+  for (int d = 0; d < world; ++d) { HIPC(hipSetDevice(d)); HIPC(hipDeviceSynchronize()); }
+
+  const double t0 = now_s();
+  for (int rep = 0; rep < reps; ++rep) {
+    /* C1: fan-out of the IQ blocks from the root */
+    if (world > 1) {
+      if (peer_copy) {
+        for (int d = 1; d < world; ++d)
+          if (count[d]) HIPC(hipMemcpyPeerAsync(d_iq[d], d, d_iq_root + (size_t)first[d] * nbytes, 0, (size_t)count[d] * nbytes, st[d]));
+      } else {
+        /* the root's sends run on its stream after whatever produced the batch; a peer's receive on the peer's stream */
+        NCCLC(ncclGroupStart());
+        for (int d = 1; d < world; ++d) {
+          if (!count[d]) continue;
+          NCCLC(ncclSend(d_iq_root + (size_t)first[d] * nbytes, (size_t)count[d] * nbytes, ncclUint8, d, comm[0], st[0]));
+          NCCLC(ncclRecv(d_iq[d], (size_t)count[d] * nbytes, ncclUint8, 0, comm[d], st[d]));
+        }
+        NCCLC(ncclGroupEnd());
+      }
+    }
+    /* the hot path on every device, enqueued without waiting: the devices run concurrently */
+    for (int d = 0; d < world; ++d) {
+      if (!count[d]) continue;
+      uint32_t na = 0;
+      SDRC(sdrfm_process_batch(dm[d], d_iq[d], nbytes, nbytes, d_audio[d], audio_stride, &na, SDRFM_F_DEVICE_PTRS));
+      if (na != n_audio) { fprintf(stderr, "device %d: %u audio samples, expected %u\n", d, na, n_audio); return 1; }
+    }
+    /* C2: fan-in of the audio blocks */
+    if (world > 1) {
+      if (peer_copy) {
+        for (int d = 1; d < world; ++d)
+          if (count[d]) HIPC(hipMemcpyPeerAsync(d_audio_root + (size_t)first[d] * audio_stride, 0, d_audio[d], d, (size_t)count[d] * audio_stride * sizeof(float), st[d]));
+      } else {
+        NCCLC(ncclGroupStart());
+        for (int d = 1; d < world; ++d) {
+          if (!count[d]) continue;
+          NCCLC(ncclSend(d_audio[d], (size_t)count[d] * audio_stride, ncclFloat32, 0, comm[d], st[d]));
+          NCCLC(ncclRecv(d_audio_root + (size_t)first[d] * audio_stride, (size_t)count[d] * audio_stride, ncclFloat32, d, comm[0], st[0]));
+        }
+        NCCLC(ncclGroupEnd());
+      }
+    }
+    for (int d = 0; d < world; ++d) { HIPC(hipSetDevice(d)); HIPC(hipStreamSynchronize(st[d])); }
+  }
+  const double dt = now_s() - t0;
+
+  /* ---- results --------------------------------------------------------------------------------------------------------------- */
+  float* audio = (float*)malloc((size_t)n_streams * n_audio * sizeof(float) + 4);
+  HIPC(hipSetDevice(0));
+  HIPC(hipMemcpy2D(audio, (size_t)n_audio * sizeof(float), d_audio_root, audio_stride * sizeof(float), (size_t)n_audio * sizeof(float), n_streams, hipMemcpyDeviceToHost));
+  FILE* fo = fopen(argv[7], "wb");
+  if (!fo) { perror(argv[7]); return 2; }
+  fwrite(audio, sizeof(float), (size_t)n_streams * n_audio, fo);
+  fclose(fo);
+  printf("{\"n_gpus\":%d,\"n_streams\":%u,\"bytes_per_stream\":%u,\"n_audio\":%u,\"transport\":\"%s\",\"reps\":%d,\"seconds\":%.6f,"
+         "\"end_to_end_MSamples_per_s\":%.1f,\"kernel\":\"%s\",\"shards\":[", world, n_streams, nbytes, n_audio,
+         peer_copy ? "hipMemcpyPeerAsync" : "RCCL ncclSend/ncclRecv", reps, dt, (double)reps * n_streams * (nbytes / 2) / dt / 1e6,
+         dm[0] ? sdrfm_kernel_name(dm[0]) : "");
+  for (int d = 0; d < world; ++d) printf("%s[%u,%u]", d ? "," : "", first[d], count[d]);
+  printf("]}\n");
+  for (int d = 0; d < world; ++d) {
+    HIPC(hipSetDevice(d));
+    if (dm[d]) sdrfm_destroy(dm[d]);
+    if (d > 0 && d_iq[d]) HIPC(hipFree(d_iq[d]));
+    if (d > 0 && d_audio[d]) HIPC(hipFree(d_audio[d]));
+    if (!peer_copy) ncclCommDestroy(comm[d]);
+    HIPC(hipStreamDestroy(st[d]));
+  }
+  HIPC(hipSetDevice(0));
+  HIPC(hipFree(d_iq_root)); HIPC(hipFree(d_audio_root));
+  free(audio); free(iq); free(h); free(g);
+  return 0;
+}

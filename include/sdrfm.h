@@ -151,7 +151,7 @@ int  sdrfm_ring_collect(sdrfm_ring_t* r, float* audio, uint32_t audio_cap, uint3
 /* flags for sdrfm_wbfm_config.flags (all are test hooks; results do not depend on them) */
 #define SDRFM_WBFM_CFG_FORCE_GENERIC 1u        /* never run a fused kernel */
 #define SDRFM_WBFM_CFG_BRANCH_LANES 2u         /* fused kernel with one lane per polyphase branch instead of one lane per step */
-#define SDRFM_WBFM_CFG_RUN_STEPS_SHIFT 8       /* flags >> 8 = fixed run length (steps) of the fused kernel, 0 = chosen per call */
+#define SDRFM_WBFM_CFG_RUN_STEPS_SHIFT 8       /* flags >> 8 = fixed run length (steps, 64..8192) of the fused kernel, 0 = chosen per call */
 
 typedef struct sdrfm_wbfm_config {
   uint32_t struct_size;           /* = sizeof(sdrfm_wbfm_config) */
@@ -177,8 +177,9 @@ int  sdrfm_wbfm_process_batch(sdrfm_wbfm_t* h, const uint8_t* iq, size_t iq_stri
                               float* audio, size_t band_stride, uint32_t* n_audio_per_band, uint32_t flags);
 int  sdrfm_wbfm_set_stream(sdrfm_wbfm_t* h, void* hip_stream);
 int  sdrfm_wbfm_synchronize(sdrfm_wbfm_t* h);
-/* starts with "wbfm-fused" (128-tap prototype, <= 10 resampler taps per phase; the kernel in use follows in brackets) or
-   "wbfm-generic" (any shape, two kernels) */
+/* the kernel that served the LAST call (before any call: the one the configuration selects): starts with "wbfm-fused" (128-tap
+   prototype, <= 10 resampler taps per phase; the kernel follows in brackets) or "wbfm-generic" (any shape, two kernels; also
+   serves calls too short for a fused kernel) */
 const char* sdrfm_wbfm_kernel_name(const sdrfm_wbfm_t* h);
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -222,6 +223,11 @@ int  sdrfm_spectrum_synchronize(sdrfm_spectrum_t* h);
 int sdrfm_rtl_pack_fir(const int* fir16, uint8_t* out20);
 int sdrfm_rtl_resampler(uint32_t samp_rate, uint32_t xtal_hz, uint32_t* rsamp_ratio, uint32_t* real_rsamp_ratio,
                         double* real_rate);
+/* Multi-GPU fan-out / fan-in of stream batches (streams are independent: one handle per GPU, no data-path collective): the contiguous
+ * block [*first, *first + *count) of the n_streams streams that rank `rank` of `world` owns; the first n_streams % world ranks own one
+ * stream more.  examples/multi_gpu_main.c (one C process, N devices, RCCL send/recv) and the Python fan-out use this one definition. */
+int sdrfm_shard_range(uint32_t n_streams, uint32_t world, uint32_t rank, uint32_t* first, uint32_t* count);
+
 typedef struct sdrfm_e4k_pll {   /* mirrors struct e4k_pll_params (Class/RTLSDR/Inc/tuner_e4k.h:227-236) */
   uint32_t fosc, intended_flo, flo;
   uint16_t x;

@@ -73,3 +73,14 @@ int sdrfm_e4k_pll_params(uint32_t fosc_hz, uint32_t intended_flo_hz, sdrfm_e4k_p
   out->threephase = (code & 0x08) ? 1 : 0;
   return SDRFM_OK;
 }
+
+/* Multi-GPU fan-out: the contiguous block of streams rank `rank` of `world` owns — the first n_streams % world
+ * ranks get one stream more.  The one definition both hosts use: examples/multi_gpu_main.c directly, the Python fan-out
+ * (stm32f7-rtlsdr_amd/fanout.py: shard_range) through ctypes. */
+int sdrfm_shard_range(uint32_t n_streams, uint32_t world, uint32_t rank, uint32_t* first, uint32_t* count) {
+  if (!first || !count || world == 0 || rank >= world) return SDRFM_EINVAL;
+  const uint32_t q = n_streams / world, r = n_streams % world;
+  *first = rank * q + (rank < r ? rank : r);
+  *count = q + (rank < r ? 1u : 0u);
+  return SDRFM_OK;
+}

@@ -1093,6 +1093,7 @@ int sdrfm_wbfm_create(const sdrfm_wbfm_config* cfg, sdrfm_wbfm_t** out) {
   h->steps_ok = h->fused_ok && cfg->resamp_up >= 2 && !(cfg->flags & SDRFM_WBFM_CFG_BRANCH_LANES);
   h->n_cu = (uint32_t)prop.multiProcessorCount;
   h->force_nt = (cfg->flags >> SDRFM_WBFM_CFG_RUN_STEPS_SHIFT) & ~1u;   // test hook: fixed run length of the fused kernel (0 = chosen per call)
+  if (h->force_nt && (h->force_nt < 64u || h->force_nt > 8192u)) { wfree(h); return SDRFM_EINVAL; }   // the range the kernels' own choice stays in
   snprintf(h->kernel_name, sizeof(h->kernel_name), "%s", h->steps_ok ? "wbfm-fused (k_wbfm_steps<8,10>)" : h->fused_ok ? "wbfm-fused (k_wbfm_fused<8,10>)" : "wbfm-generic (k_wbfm_chan + k_wbfm_res)");
   const int rc = sdrfm_wbfm_reset(h);
   if (rc != SDRFM_OK) { wfree(h); return rc; }
@@ -1205,6 +1206,7 @@ static int wenqueue(sdrfm_wbfm* h, const uint8_t* d_iq, size_t iq_stride, uint32
 #endif
     hipLaunchKernelGGL((k_wbfm_steps<8, 10>), dim3(c.n_streams * w.tiles_per_stream), dim3(64), lds, h->stream, w);
     WTRY(hipGetLastError(), SDRFM_FAIL);
+    snprintf(h->kernel_name, sizeof(h->kernel_name), "wbfm-fused (k_wbfm_steps<8,10>)");   // the kernel that served THIS call
     h->cur ^= 1;
     h->phase_x = (uint32_t)((h->phase_x + (uint64_t)N) % NB);
     h->n_d += Tn; h->n_a += A;
@@ -1239,6 +1241,7 @@ static int wenqueue(sdrfm_wbfm* h, const uint8_t* d_iq, size_t iq_stride, uint32
     const uint32_t waves = (uint32_t)quads * w.tiles_per_stream;
     hipLaunchKernelGGL((k_wbfm_fused<8, 10>), dim3((waves + 3) / 4), dim3(256), 0, h->stream, w);
     WTRY(hipGetLastError(), SDRFM_FAIL);
+    snprintf(h->kernel_name, sizeof(h->kernel_name), "wbfm-fused (k_wbfm_fused<8,10>)");
     h->cur ^= 1;
     h->phase_x = (uint32_t)((h->phase_x + (uint64_t)N) % NB);
     h->n_d += Tn; h->n_a += A;
@@ -1250,6 +1253,7 @@ static int wenqueue(sdrfm_wbfm* h, const uint8_t* d_iq, size_t iq_stride, uint32
   const uint32_t per_stream = (A * NB + 255) / 256;
   hipLaunchKernelGGL(k_wbfm_res, dim3(c.n_streams * per_stream + c.n_streams), dim3(256), 0, h->stream, w);
   WTRY(hipGetLastError(), SDRFM_FAIL);
+  snprintf(h->kernel_name, sizeof(h->kernel_name), "wbfm-generic (k_wbfm_chan + k_wbfm_res)");
   h->cur ^= 1;
   h->phase_x = (uint32_t)((h->phase_x + (uint64_t)N) % NB);
   h->n_d += Tn; h->n_a += A;

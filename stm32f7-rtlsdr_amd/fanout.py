@@ -9,10 +9,15 @@ import torch.distributed as dist
 
 
 def shard_range(n_streams, rank, world):
-    """Contiguous block of streams owned by `rank` (first n_streams % world ranks get one extra)."""
-    q, r = divmod(n_streams, world)
-    lo = rank * q + min(rank, r)
-    return lo, lo + q + (1 if rank < r else 0)
+    """Contiguous block [lo, hi) of streams owned by `rank` (first n_streams % world ranks get one extra): sdrfm_shard_range of the
+    C-ABI, the definition the plain-C multi-GPU host (examples/multi_gpu_main.c) uses too."""
+    import ctypes as C
+    from .lib import load_library
+    first, count = C.c_uint32(), C.c_uint32()
+    st = load_library().sdrfm_shard_range(int(n_streams), int(world), int(rank), C.byref(first), C.byref(count))
+    if st != 0:
+        raise ValueError("sdrfm_shard_range(%r, %r, %r): status %d" % (n_streams, world, rank, st))
+    return first.value, first.value + count.value
 
 
 def scatter_streams(iq_root, n_streams, nbytes, device, src=0, group=None):

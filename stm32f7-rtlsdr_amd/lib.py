@@ -17,6 +17,7 @@ ABI_SYMBOLS = [
     "sdrfm_set_stream", "sdrfm_synchronize", "sdrfm_kernel_name", "sdrfm_abi_version", "sdrfm_strerror",
     "sdrfm_wbfm_create", "sdrfm_wbfm_destroy", "sdrfm_wbfm_reset", "sdrfm_wbfm_audio_count", "sdrfm_wbfm_process_batch",
     "sdrfm_wbfm_set_stream", "sdrfm_wbfm_synchronize", "sdrfm_wbfm_kernel_name", "sdrfm_rtl_pack_fir", "sdrfm_rtl_resampler", "sdrfm_e4k_pll_params",
+    "sdrfm_shard_range",
     "sdrfm_spectrum_create", "sdrfm_spectrum_destroy", "sdrfm_spectrum_process_batch", "sdrfm_spectrum_set_stream",
     "sdrfm_spectrum_synchronize",
     "sdrfm_pcm_deemph_s16", "sdrfm_pcm_alpha",
@@ -155,6 +156,8 @@ def load_library(dev=False):
     lib.sdrfm_rtl_resampler.restype = C.c_int
     lib.sdrfm_e4k_pll_params.argtypes = [u32, u32, vp]
     lib.sdrfm_e4k_pll_params.restype = C.c_int
+    lib.sdrfm_shard_range.argtypes = [u32, u32, u32, u32p, u32p]
+    lib.sdrfm_shard_range.restype = C.c_int
     lib.sdrfm_pcm_deemph_s16.argtypes = [vp, u32, C.c_float, C.c_float, C.POINTER(C.c_float), vp]
     lib.sdrfm_pcm_deemph_s16.restype = C.c_int
     lib.sdrfm_pcm_alpha.argtypes = [C.c_float, C.c_float]

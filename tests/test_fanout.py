@@ -69,3 +69,26 @@ def test_shard_range_partitions(pkg):
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_shard_range_is_one_definition_in_c(pkg):
+    """sdrfm_shard_range (C, csrc/rtlctl.c) is what both hosts use: examples/multi_gpu_main.c directly, fanout.shard_range through
+    ctypes.  Contiguous, exhaustive, the first n % world ranks own one stream more; bad arguments are refused."""
+    import ctypes as C
+    lib = pkg.load_library()
+    for n in (0, 1, 7, 256, 512, 1000, 4096, 4099):
+        for world in (1, 2, 3, 4, 8):
+            pos = 0
+            for rank in range(world):
+                first, count = C.c_uint32(), C.c_uint32()
+                assert lib.sdrfm_shard_range(n, world, rank, C.byref(first), C.byref(count)) == 0
+                q, r = divmod(n, world)
+                assert (first.value, count.value) == (rank * q + min(rank, r), q + (1 if rank < r else 0))
+                assert first.value == pos
+                pos += count.value
+                assert pkg.fanout.shard_range(n, rank, world) == (first.value, first.value + count.value)
+            assert pos == n
+    first, count = C.c_uint32(), C.c_uint32()
+    assert lib.sdrfm_shard_range(8, 0, 0, C.byref(first), C.byref(count)) == 16      # SDRFM_EINVAL
+    assert lib.sdrfm_shard_range(8, 2, 2, C.byref(first), C.byref(count)) == 16
+    assert lib.sdrfm_shard_range(8, 2, 1, None, C.byref(count)) == 16

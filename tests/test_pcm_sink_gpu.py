@@ -63,3 +63,62 @@ def test_sink_argument_errors(pkg):
     assert e.value.status == 16
     with pkg.PcmSink(2, alpha, gain) as sink:
         assert sink.process_batch(np.zeros((2, 0), np.float32)).shape == (2, 0)
+
+
+def test_device_sink_against_the_exact_rational_definition(pkg):
+    """The device kernel against an INDEPENDENT restatement (exact rationals, correctly rounded to fp32 at every operation:
+    tests/test_pcm_sink.py), not against the product's own host routine: 96 samples per stream, saturation, ties and tiny values
+    included, state carried across two calls."""
+    from test_pcm_sink import pcm_reference
+    alpha, gain = _params(pkg)
+    rng = np.random.default_rng(7)
+    ns, n = 3, 48
+    x = (rng.standard_normal((ns, 2 * n)) * 1.5).astype(np.float32)
+    x[0, :8] = [10.0, 10.0, -10.0, -10.0, 0.0, 1e-30, -1e-30, 0.5 / 3.0]
+    x[1, :4] = [np.float32(0.5) / gain, np.float32(1.5) / gain, np.float32(-2.5) / gain, 0.0]
+    with pkg.PcmSink(ns, alpha, gain) as sink:
+        got = np.concatenate([sink.process_batch(x[:, :n]), sink.process_batch(x[:, n:])], axis=1)
+        st_dev = sink.state()
+    for s in range(ns):
+        want, y_end = pcm_reference(x[s], alpha, gain, 0.0)
+        assert np.array_equal(got[s], want), (s, int(np.argmax(got[s] != want)))
+        assert np.float32(y_end).view(np.uint32) == st_dev[s].view(np.uint32)
+
+
+def test_device_sink_on_its_own_stream_behind_an_event(pkg):
+    """The arrangement DESIGN.md 4.7 describes: the sink runs on ITS OWN stream, ordered behind the demodulator's launch by an
+    event, while the demodulator's stream goes on with the next batch (double-buffered audio).  PCM equal to sinking the same
+    audio on the host, for every batch."""
+    import torch
+    alpha, gain = _params(pkg)
+    ns, nsamp, nbatch = 256, 24000, 4
+    h, g = pkg.default_config(64)
+    iqs = [torch.from_numpy(pkg.make_iq(ns, nsamp, mode="fm", first_id=800 + 7 * b)).cuda() for b in range(nbatch)]
+    audio = [torch.zeros((ns, 480), dtype=torch.float32, device="cuda") for _ in range(2)]
+    pcm = [torch.zeros((ns, 960), dtype=torch.int16, device="cuda") for _ in range(nbatch)]
+    torch.cuda.synchronize()
+    s_dm, s_sink = torch.cuda.Stream(), torch.cuda.Stream()
+    done_sink = [None, None]
+    with pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=ns)) as dm, pkg.PcmSink(ns, alpha, gain) as sink:
+        dm.set_stream(s_dm.cuda_stream)
+        sink.set_stream(s_sink.cuda_stream)
+        for b in range(nbatch):
+            buf = b & 1
+            if done_sink[buf] is not None:
+                s_dm.wait_event(done_sink[buf])                  # the audio buffer is free again once its previous sink pass ended
+            n = dm.process_batch_device(iqs[b], audio[buf])
+            ev = torch.cuda.Event()
+            ev.record(s_dm)
+            s_sink.wait_event(ev)                                # the sink starts when this batch's audio exists ...
+            sink.process_batch_device(audio[buf], pcm[b], n)
+            done_sink[buf] = torch.cuda.Event()
+            done_sink[buf].record(s_sink)                        # ... and the demodulator does not wait for it
+        s_dm.synchronize(); s_sink.synchronize()
+        got = [p.cpu().numpy() for p in pcm]
+    with pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=ns)) as dm2:
+        ref_audio = [dm2.process_batch(iq.cpu().numpy()) for iq in iqs]
+    for s in (0, 1, 77, 255):
+        st = 0.0
+        for b in range(nbatch):
+            want, st = pkg.pcm_deemph_s16_host(ref_audio[b][s], alpha, gain, st)
+            assert np.array_equal(got[b][s], want), (s, b)

@@ -214,3 +214,21 @@ def test_device_path_with_unaligned_rows_matches_generic_bitwise(pkg, byte_off, 
         dm.close()
     assert outs["steps"].shape == outs["generic"].shape == (ns, 16, 780)
     assert np.array_equal(outs["steps"].view(np.uint32), outs["generic"].view(np.uint32))
+
+
+def test_kernel_name_follows_the_call_and_run_steps_is_bounded(pkg):
+    """sdrfm_wbfm_kernel_name tells which kernel served the LAST call: a call too short for the fused kernels (< 64 channelizer steps)
+    runs on the generic pair and says so; the run-length test hook is range-checked at create."""
+    p, g = _taps(pkg)
+    dm = pkg.WbfmDemod(pkg.WbfmConfig(proto_coeffs=p, resamp_coeffs=g, n_streams=2))
+    assert "k_wbfm_steps" in dm.kernel_name                         # what the configuration selects
+    iq = pkg.make_iq(2, 64000, mode="fm", fs=3.2e6, first_id=7)
+    dm.process_batch(iq[:, :2 * 40 * 16])                           # 40 steps
+    assert dm.kernel_name.startswith("wbfm-generic"), dm.kernel_name
+    dm.process_batch(iq[:, 2 * 40 * 16:])
+    assert "k_wbfm_steps" in dm.kernel_name, dm.kernel_name
+    dm.close()
+    for bad in (2, 32, 8194, 60000):
+        with pytest.raises(pkg.SdrfmError) as e:
+            pkg.WbfmDemod(pkg.WbfmConfig(proto_coeffs=p, resamp_coeffs=g, n_streams=2, run_steps=bad))
+        assert e.value.status == 16
