@@ -1847,13 +1847,14 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
                          // which cuts its segments as short as the call needs
                          (uint64_t)c.n_streams * ((N / h->fast_s->seg + 62) / 63) >= 4ull * h->n_cu;
   // Design Q serves whole numbers of audio periods at decimator phase 0 on 16-byte aligned rows, when the call holds enough steps
-  // (128 outputs each) to give every resident wave a run of at least four; the first call after a reset must be long enough
-  // that the state it hands over holds no output computed from the (inexpressible in bytes) zero history.
+  // (128 outputs each) to put at least two waves on every CU; the first call after a reset must be long enough that the state it
+  // hands over holds no output computed from the (inexpressible in bytes) zero history.  It also serves one dongle's second of IQ
+  // (BASELINE configs[1]: 1875 steps cut into two-step runs, 5.7 us against 9.6 - 13 us for design B).
   const uint32_t q_steps = (M + SDRFM_Q_STEP_OUT - 1) / SDRFM_Q_STEP_OUT;
   const bool q_ok = h->d_qA && A > 0 && h->phase_x == 0 && h->phase_d == 0 && (N % (SDRFM_Q_D * SDRFM_Q_DA * 8u)) == 0 &&
                     ((uintptr_t)d_iq % 16 == 0) && (iq_stride % 16 == 0) && N < (1u << 30) && M >= c.audio_taps &&
                     (h->n_seen + 1 >= c.fir_taps || M >= y_aff + c.audio_taps) &&
-                    (uint64_t)c.n_streams * q_steps >= 8ull * h->n_cu;
+                    (uint64_t)c.n_streams * q_steps >= 2ull * h->n_cu;
   if (q_ok) {
     SdrfmQParams q;
     q.iq = d_iq; q.iq_stride = iq_stride; q.audio = d_audio; q.audio_stride = audio_stride;
@@ -1861,9 +1862,11 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
     q.hist_b_in = p.hist_b_in; q.hist_b_out = p.hist_b_out; q.hist_x_out = p.hist_x_out;
     q.A = h->d_qA; q.g = h->d_g; q.q0 = h->q_scale; q.q2 = 65536.0f * h->q_scale; q.cst = h->q_cst;
     q.T = c.fir_taps; q.N = N; q.M = M; q.A_out = A; q.steps_total = q_steps; q.n_streams = c.n_streams; q.dbg = nullptr;
-    // runs (waves) per stream: fill the machine once, every run at least four owned steps
+    // runs (waves) per stream: fill the machine once; every run at least four owned steps (a run that does not start its stream
+    // recomputes one step), two when the call is too small to fill the machine otherwise
     uint32_t runs = (h->q_waves_per_cu * h->n_cu) / c.n_streams;
-    if (runs > q_steps / 4) runs = q_steps / 4;
+    const uint32_t min_steps = ((uint64_t)c.n_streams * (q_steps / 4) >= (uint64_t)h->q_waves_per_cu * h->n_cu / 2) ? 4u : 2u;
+    if (runs > q_steps / min_steps) runs = q_steps / min_steps;
     if (runs < 1) runs = 1;
     q.runs = runs;
     HIP_TRY(sdrfm_q_launch(q, h->q_c0, h->q_nslot, h->stream), SDRFM_FAIL);

@@ -38,10 +38,16 @@ def test_config2_single_stream_one_second(pkg, oracle_mod, T):
     dm, h, g = _demod(pkg, T, max_bytes_per_call=4800000)
     iq = pkg.make_iq(1, 2400000, mode="fm")[0]
     got = dm.process(iq)
+    assert dm.kernel_name.startswith("fast-q"), dm.kernel_name    # one dongle's second is 1875 steps: two-step runs of design Q
     want = oracle_mod.Oracle(h, g).process(iq)
     assert got.size == want.size == 48000
     assert scaled_err(got, want) <= TOL
     dm.close()
+    ex, _, _ = _demod(pkg, T, max_bytes_per_call=4800000, bit_exact=True)
+    got_exact = ex.process(iq)
+    assert ex.kernel_name.startswith("fast-b"), ex.kernel_name
+    assert scaled_err(got_exact, want) <= TOL and scaled_err(got, got_exact) <= 2e-6
+    ex.close()
 
 
 @pytest.mark.parametrize("mode", ["fm", "random", "const", "counter"])
@@ -270,7 +276,7 @@ def test_specialised_kernels_equal_generic_kernel_bitwise(pkg, oracle_mod, monke
     h, g = pkg.default_config(T)
     iq = pkg.make_iq(1, 180000, mode="fm", first_id=77)[0]
     cuts = [2 * 5000, 2 * 5000 + 2 * 61000, 2 * 140008]          # all even sample counts -> specialised path stays eligible
-    fast = pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, max_bytes_per_call=400000, dev_library=dev))
+    fast = pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, max_bytes_per_call=400000, dev_library=dev, bit_exact=True))
     gen = pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, max_bytes_per_call=400000, force_generic=True))
     a_fast = _run_chunks(fast, iq, cuts)
     assert fast.kernel_name.startswith("fast-" + kind), fast.kernel_name
