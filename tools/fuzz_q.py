@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Randomised soak of design Q (the matrix-pipe kernel, csrc/sdrfm_q.hip): batches of every size class (machine-filling, one dongle,
+more streams than waves), tap counts 16 / 32 / 64 and random taps, call sizes that are / are not whole audio periods, resets in
+mid-stream, device-resident buffers with odd row strides.  Every call is compared with the bit-exact kernels on a twin handle
+and, for the distinct rows, with the oracle (both 1e-5 scaled; on the BASELINE taps the worst is 7e-7, a random narrow filter that attenuates the test signal by 40 dB makes every fp32 implementation noisier: worst seen 6.8e-6).  usage: fuzz_q.py [seconds] [seed]"""
+import importlib, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+pkg = importlib.import_module("stm32f7-rtlsdr_amd")
+from oracle.oracle import Oracle
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+t_end, cases, calls_q, fails, worst_exact, worst_oracle = time.time() + budget, 0, 0, 0, 0.0, 0.0
+while time.time() < t_end:
+    T = int(rng.choice([16, 32, 64, 64, 48, 90, 33]))
+    g = pkg.default_config(64)[1]
+    lowpass = True
+    if T in (16, 32, 64):
+        h, g = pkg.default_config(T)
+    elif rng.random() < 0.7:
+        h = pkg.lowpass_taps(T, float(rng.uniform(0.02, 0.06)))            # other lengths / cut-offs: still low-pass, still design Q
+    else:
+        h = (rng.standard_normal(T) * np.hamming(T)).astype(np.float32); h /= np.abs(h).sum(); lowpass = False   # no pass band: never design Q
+    ns = int(rng.choice([1, 2, 7, 64, 256, 300, 1024, 3100]))
+    unit = 400
+    sizes = []
+    for _ in range(int(rng.integers(2, 5))):
+        if ns <= 7:
+            k = int(rng.integers(300, 3000))
+        elif ns <= 300:
+            k = int(rng.integers(8, 120))
+        else:
+            k = int(rng.integers(1, 12))
+        sizes.append(unit * k if rng.random() < 0.8 else int(rng.integers(1, unit * k)))
+    total = sum(sizes)
+    nd = min(ns, 6)
+    rows = np.concatenate([pkg.make_iq(max(nd - 2, 1), total, mode="fm", first_id=int(rng.integers(1 << 20))),
+                           pkg.make_iq(2, total, mode=str(rng.choice(["random", "const", "counter"])), first_id=int(rng.integers(1 << 20)))])[:nd]
+    stride = 2 * total + int(rng.choice([0, 16, 48, 2, 6]))
+    dev = torch.zeros((ns, stride), dtype=torch.uint8, device="cuda")
+    dev[:, :2 * total] = torch.from_numpy(np.tile(rows, ((ns + nd - 1) // nd, 1))[:ns]).cuda()
+    torch.cuda.synchronize()
+    kw = dict(fir_coeffs=h, audio_coeffs=g, n_streams=ns, max_bytes_per_call=2 * max(sizes) + 64)
+    fast = pkg.FmDemod(pkg.FmConfig(**kw)); exact = pkg.FmDemod(pkg.FmConfig(bit_exact=True, **kw))
+    orcs = [Oracle(h, g) for _ in range(nd)]
+    pos, log, bad = 0, [], False
+    for n in sizes:
+        if rng.random() < 0.15:
+            fast.reset(); exact.reset(); [o.reset() for o in orcs]; log.append("reset")
+        cap = fast.audio_count(2 * n) + 1
+        a1 = torch.full((ns, cap), 3.0, dtype=torch.float32, device="cuda"); a2 = torch.full((ns, cap), 5.0, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        n1 = fast.process_batch_device(dev[:, 2 * pos:], a1, nbytes=2 * n); name = fast.kernel_name.split()[0]
+        n2 = exact.process_batch_device(dev[:, 2 * pos:], a2, nbytes=2 * n)
+        fast.synchronize(); exact.synchronize()
+        log.append((n, name)); calls_q += name == "fast-q"
+        if name == "fast-q" and not lowpass:
+            bad = True                                                      # heavy-cancellation taps must stay on the bit-exact kernels
+        g1, g2 = a1[:, :n1].cpu().numpy().astype(np.float64), a2[:, :n2].cpu().numpy().astype(np.float64)
+        if n1 != n2 or not np.isfinite(g1).all():
+            bad = True
+        elif n1:
+            e = float((np.abs(g1 - g2) / np.maximum(np.abs(g2), 1.0)).max()); worst_exact = max(worst_exact, e); bad |= e > 1e-5
+            if nd < ns and not np.array_equal(g1[:nd], g1[nd:2 * nd][:nd] if ns >= 2 * nd else g1[:nd]):
+                bad = True
+        for s in range(nd):
+            w = orcs[s].process(rows[s, 2 * pos:2 * (pos + n)]).astype(np.float64)
+            if w.size:
+                e = float((np.abs(g1[s] - w) / np.maximum(np.abs(w), 1.0)).max()); worst_oracle = max(worst_oracle, e); bad |= e > 1e-5
+        pos += n
+    fast.close(); exact.close()
+    cases += 1
+    if bad:
+        fails += 1; print("FAIL", dict(T=T, ns=ns, stride=stride, log=log), flush=True)
+print("design-Q soak: cases %d  calls served by fast-q %d  failures %d  worst vs bit-exact kernels %.3g  worst vs oracle %.3g  (seed %d, %.0f s)"
+      % (cases, calls_q, fails, worst_exact, worst_oracle, seed, budget))
+sys.exit(1 if fails else 0)
