@@ -62,7 +62,7 @@ enum {
 #define SDRFM_CFG_BIT_EXACT     4u  /* only kernels whose audio is bit-identical to the fp32 fmaf-chain definition above (the generic kernel's):
                                        never the matrix-pipe kernel ("fast-q"), which evaluates the channel FIR exactly in integers from
                                        taps rounded to 24-bit fixed point and lands within 1e-6 of that definition (tolerance: 1e-5).
-                                       Without the flag "fast-q" serves low-pass channel filters (sum|h| <= 4 |sum h|) at D = 10,
+                                       Without the flag "fast-q" serves low-pass channel filters (sum|h| <= 2 |sum h|) at D = 10,
                                        32 audio taps / 5; every other configuration runs the bit-identical kernels anyway */
 #define SDRFM_CFG_NO_ZEROCOPY   2u  /* URB-sized host calls use the staged H2D/D2H path instead of mapped host memory (tests) */
 
