@@ -14,7 +14,8 @@ typedef int i4 __attribute__((ext_vector_type(4)));
 __device__ void dma(i4 rsrc, __attribute__((address_space(3))) void* lds, int size, int voffset, int soffset, int offset, int aux) __asm("llvm.amdgcn.raw.buffer.load.lds");
 
 template <int NSLOT, int AUX>
-__global__ void __launch_bounds__(64) k_stream(const uint8_t* base, unsigned total_kib, unsigned kib_per_wave, int pattern, unsigned G, unsigned item, unsigned* sink) {
+__global__ void __launch_bounds__(64) k_stream(const uint8_t* base, unsigned total_kib, unsigned kib_per_wave, int pattern, unsigned G, unsigned item, unsigned* sink, unsigned long long* stamps) {
+  const unsigned long long t_in = __builtin_amdgcn_s_memrealtime();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const unsigned w = blockIdx.x, W = gridDim.x, lane = threadIdx.x;
   const unsigned long long ga = (unsigned long long)base;
@@ -39,6 +40,7 @@ __global__ void __launch_bounds__(64) k_stream(const uint8_t* base, unsigned tot
     slot = (slot + 1 == NSLOT) ? 0 : slot + 1;
   }
   __builtin_amdgcn_s_waitcnt(0x0f70);
+  if (stamps && threadIdx.x == 0) { stamps[3 * blockIdx.x] = t_in; stamps[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(); stamps[3 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7; }
   if (acc == 0x12345678u) sink[0] = acc;
 }
 
@@ -50,7 +52,7 @@ static void run(const uint8_t* d, size_t buf_kib, unsigned waves, unsigned kib_p
   size_t off = 0;
   auto launch = [&] {
     if (off + total > buf_kib) off = 0;
-    hipLaunchKernelGGL((k_stream<NSLOT, AUX>), dim3(waves), dim3(64), NSLOT * 1024, 0, d + (off << 10), total, kib_per_wave, pattern, G, item, sink);
+    hipLaunchKernelGGL((k_stream<NSLOT, AUX>), dim3(waves), dim3(64), NSLOT * 1024, 0, d + (off << 10), total, kib_per_wave, pattern, G, item, sink, (unsigned long long*)nullptr);
     off += total;
   };
   for (int i = 0; i < 3; ++i) launch();
@@ -60,6 +62,18 @@ static void run(const uint8_t* d, size_t buf_kib, unsigned waves, unsigned kib_p
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   const double us = ms * 1e3 / iters;
+  if (getenv("UB_STAMPS")) {   // one more launch with per-wave entry / exit times (100 MHz), summarised for XCC 0
+    unsigned long long* ds; CK(hipMalloc(&ds, (size_t)waves * 24)); CK(hipMemset(ds, 0, (size_t)waves * 24));
+    if (off + total > buf_kib) off = 0;
+    hipLaunchKernelGGL((k_stream<NSLOT, AUX>), dim3(waves), dim3(64), NSLOT * 1024, 0, d + (off << 10), total, kib_per_wave, pattern, G, item, sink, ds);
+    CK(hipDeviceSynchronize());
+    unsigned long long* hs = (unsigned long long*)malloc((size_t)waves * 24);
+    CK(hipMemcpy(hs, ds, (size_t)waves * 24, hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull, t1 = 0, tin_max = 0, tout_min = ~0ull;
+    for (unsigned w = 0; w < waves; ++w) if (hs[3 * w + 2] == 0) { if (hs[3 * w] < t0) t0 = hs[3 * w]; if (hs[3 * w] > tin_max) tin_max = hs[3 * w]; if (hs[3 * w + 1] > t1) t1 = hs[3 * w + 1]; if (hs[3 * w + 1] < tout_min) tout_min = hs[3 * w + 1]; }
+    printf("{\"stamps_xcc0_us\":{\"last_entry\":%.2f,\"first_exit\":%.2f,\"last_exit\":%.2f}}\n", (tin_max - t0) * 0.01, (tout_min - t0) * 0.01, (t1 - t0) * 0.01);
+    free(hs); CK(hipFree(ds));
+  }
   printf("{\"nslot\":%d,\"aux\":%d,\"waves\":%u,\"kib_per_wave\":%u,\"pattern\":%d,\"G\":%u,\"item_kib\":%u,\"MB\":%.1f,\"us_per_launch\":%.2f,\"TBps\":%.3f}\n",
          NSLOT, AUX, waves, kib_per_wave, pattern, G, item, total / 1024.0 * 1.048576, us, (double)total * 1024 / (us * 1e-6) * 1e-12);
   fflush(stdout);
