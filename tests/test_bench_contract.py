@@ -19,7 +19,8 @@ def test_traffic_lookup_matches_kernel_and_workload_size():
     b = _bench()
     head = json.load(open(os.path.join(ROOT, "profiles", "traffic_r02.json")))
     t = b.latest_traffic(head["kernel_name"], head["algorithmic_bytes_per_launch"])
-    assert t is not None and t["file"].startswith(("traffic_r02", "r02_")) and t["hbm_bytes_per_launch"] == head["hbm_bytes_per_launch"]
+    # (the newest committed pass of this kernel and size wins: round 3 re-profiled design S as the bit-exact handle's kernel)
+    assert t is not None and t["file"].startswith(("traffic_r0", "r0")) and abs(t["hbm_bytes_per_launch"] / head["hbm_bytes_per_launch"] - 1.0) < 0.01
     # same kernel, twice the streams: the 512-stream profile, not the 256-stream one
     t512 = b.latest_traffic(head["kernel_name"], 2 * head["algorithmic_bytes_per_launch"])
     assert t512 is not None and abs(t512["hbm_bytes_per_launch"] / t["hbm_bytes_per_launch"] - 2.0) < 0.02
@@ -28,10 +29,20 @@ def test_traffic_lookup_matches_kernel_and_workload_size():
     assert b.latest_traffic("no such kernel", head["algorithmic_bytes_per_launch"]) is None
 
 
+def test_round3_traffic_feeds_the_headline_kernel():
+    """The default bench line (design Q, configs[2]) takes `roofline.traffic` from the round-3 counter passes of the same kernel and size."""
+    b = _bench()
+    head = json.load(open(os.path.join(ROOT, "profiles", "traffic_r03.json")))
+    assert head["kernel_name"].startswith("fast-q") and "k_mfir" in head["rocprof_kernel"]
+    t = b.latest_traffic(head["kernel_name"], head["algorithmic_bytes_per_launch"])
+    assert t is not None and t["file"].startswith(("traffic_r03", "r03_")) and t["hbm_bytes_per_launch"] == head["hbm_bytes_per_launch"]
+    assert 1.0 <= t["hbm_bytes_per_launch"] / head["algorithmic_bytes_per_launch"] < 1.06       # warm-up re-reads: ~4 %
+
+
 def test_traffic_never_below_algorithmic_bytes():
     """A committed summary whose traffic is below the algorithmic bytes would mean a broken counter pass."""
     import glob
-    for fn in glob.glob(os.path.join(ROOT, "profiles", "r02_*_pmc.json")):
+    for fn in glob.glob(os.path.join(ROOT, "profiles", "r0[23]_*_pmc.json")):
         d = json.load(open(fn))
         assert d["hbm_bytes_per_launch"] >= 0.999 * d["algorithmic_bytes_per_launch"], fn
         assert d.get("commit") and d["commit"] != "wip", fn

@@ -49,17 +49,21 @@ res = {
     "derived": {},
     "counters_per_dispatch_mean": m,
 }
-if "GRBM_GUI_ACTIVE" in m and dur_in_pass.get("GRBM_GUI_ACTIVE"):
-    # GRBM_GUI_ACTIVE is summed over the 8 XCDs; the duration is the dispatch's own in the SAME counter pass
-    res["derived"]["kernel_us_in_the_counter_pass"] = dur_in_pass["GRBM_GUI_ACTIVE"] / 1e3
-    res["derived"]["effective_clock_GHz"] = m["GRBM_GUI_ACTIVE"] / 8.0 / dur_in_pass["GRBM_GUI_ACTIVE"]
-if "SQ_ACTIVE_INST_VALU" in m and "GRBM_GUI_ACTIVE" in m:
-    # SQ_ACTIVE_INST_VALU counts quad-cycles over all waves; 1024 SIMDs; kernel cycles = GRBM_GUI_ACTIVE / 8 (same pass: the SQ group
-    # of tools/profile_round3.sh carries GRBM_GUI_ACTIVE)
-    res["derived"]["valu_issue_busy_fraction"] = 4.0 * m["SQ_ACTIVE_INST_VALU"] / 1024.0 / (m["GRBM_GUI_ACTIVE"] / 8.0)
+# Kernel cycles: SQ_BUSY_CYCLES summed over the 32 shader engines, divided by 32 — from the SAME pass as SQ_ACTIVE_INST_VALU (VERDICT r02
+# weak item 8).  GRBM_GUI_ACTIVE / 8 is NOT used: it runs 35-40 % above the product of the dispatch's duration and the 2.4 GHz clock limit
+# (it also counts the command processor's work around the dispatch); it is kept in the raw counters only.
+if "SQ_BUSY_CYCLES" in m and dur_in_pass.get("SQ_BUSY_CYCLES"):
+    kcyc = m["SQ_BUSY_CYCLES"] / 32.0
+    res["derived"]["kernel_us_in_the_counter_pass"] = dur_in_pass["SQ_BUSY_CYCLES"] / 1e3
+    res["derived"]["kernel_cycles_SQ_BUSY_per_shader_engine"] = kcyc
+    res["derived"]["effective_clock_GHz"] = kcyc / dur_in_pass["SQ_BUSY_CYCLES"]
+    if "SQ_ACTIVE_INST_VALU" in m:
+        res["derived"]["valu_issue_busy_fraction"] = 4.0 * m["SQ_ACTIVE_INST_VALU"] / 1024.0 / kcyc   # quad-cycles over all waves; 1024 SIMDs
+    if "SQ_WAIT_ANY" in m and "SQ_WAVE_CYCLES" in m:
+        res["derived"]["wave_cycles_parked_in_waitcnt_fraction"] = m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"]
     res["derived"]["valu_insts_per_iq_sample_per_lane"] = None
-if "SQ_VALU_MFMA_BUSY_CYCLES" in m and "GRBM_GUI_ACTIVE" in m:
-    res["derived"]["matrix_pipe_busy_fraction"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (m["GRBM_GUI_ACTIVE"] / 8.0)
+if "SQ_VALU_MFMA_BUSY_CYCLES" in m and "SQ_BUSY_CYCLES" in m:
+    res["derived"]["matrix_pipe_busy_fraction"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (m["SQ_BUSY_CYCLES"] / 32.0)   # two passes: indicative
 if "SQ_INSTS_VALU" in m and bench:
     spl = bench["config"].get("streams_per_gpu", 0) * bench["config"].get("bytes_per_stream", 0) / 2.0
     if spl:
