@@ -57,6 +57,9 @@ def parse():
                     "knobs, e.g. SDRFM_NO_STREAM=1 for design B); the reported line then says so and is not a product figure")
     ap.add_argument("--bit-exact", action="store_true", help="fm workload: SDRFM_CFG_BIT_EXACT handle — the fmaf-chain kernels only (design S "
                     "instead of the matrix-pipe design Q); a comparison figure, labelled as such")
+    ap.add_argument("--no-overlap", action="store_true", help="fm workload: make the timed calls one after the other (without SDRFM_F_OVERLAP); "
+                    "by default consecutive calls may overlap on the device (two audio buffers in turn) and `value` is that throughput, "
+                    "while `roofline` is always taken from calls made one after the other — the duration rocprofv3 reports per kernel")
     ap.add_argument("--end-to-end", action="store_true",
                     help="fm workload: every step also scatters the IQ batch from rank 0 to all ranks and gathers the audio back "
                          "over RCCL (SURVEY 8e C1/C2); reported separately from the compute-only default")
@@ -182,9 +185,10 @@ def pick_batches(args, bytes_per_batch):
     return max(3, -(-int(1.5 * L3_BYTES) // int(bytes_per_batch)) + 1)   # (nb - 1) batches between two uses of one > 1.5 x L3
 
 
-def timed(torch, dist, use_dist, stream, step, steps):
+def timed(torch, dist, use_dist, stream, step, steps, finish=None):
     """K back-to-back steps between ONE pair of HIP events on the launch stream, bracketed by barrier + synchronize on both
-    sides; returns (max-over-ranks wall seconds, event span / K in ms)."""
+    sides; returns (max-over-ranks wall seconds, event span / K in ms).  `finish` (overlapped calls: sdrfm_flush) is called after the
+    last step, before the closing event: it puts the launch stream behind every call."""
     def fence():
         torch.cuda.synchronize()
         if use_dist:
@@ -196,6 +200,8 @@ def timed(torch, dist, use_dist, stream, step, steps):
     ev0.record(stream)
     for i in range(steps):
         step(i)
+    if finish is not None:
+        finish()
     ev1.record(stream)
     fence()
     elapsed = time.perf_counter() - t0
@@ -287,12 +293,35 @@ def main():
     def step_res(i):
         last["n"] = dm.process_batch_device(batches[0], audio)
 
+    # SDRFM_F_OVERLAP (include/sdrfm.h): consecutive calls may run concurrently on the device — a call's start-up under the previous
+    # call's tail.  What the flag asks of the caller holds here by construction: the previous call's input batch stays intact (the loop
+    # rotates over nb >= 3 resident batches) and the audio goes to two buffers in turn.
+    overlap = e2e is None and not args.no_overlap and nb >= 3
+    if overlap:
+        with torch.cuda.stream(stream):
+            audio_pair = [audio, torch.zeros_like(audio)]
+        stream.synchronize()
+
+    def step_ovl(i):
+        last["n"] = dm.process_batch_device(batches[i % nb], audio_pair[i & 1], overlap=True)
+
     for i in range(args.warmup):
-        step_rot(i)
+        (step_ovl if overlap else step_rot)(i)
+    dm.flush()
     # Timed region: K back-to-back launches between ONE pair of HIP events on the launch stream (an event pair around every
     # launch costs ~6 us of idle GPU per step).  kernel_ms_avg = event span / K is therefore the average launch duration
     # INCLUDING any inter-launch gap; per-launch event timings come from a short untimed pass afterwards.
-    elapsed, kernel_ms_avg = timed(torch, dist, use_dist, stream, step_rot, args.steps)
+    kernel_ms_ovl = kernel_ms_ovl_sus = None
+    served_by = None
+    if overlap:
+        elapsed, kernel_ms_ovl = timed(torch, dist, use_dist, stream, step_ovl, args.steps, finish=dm.flush)
+        served_by = dm.kernel_name
+        for i in range(min(args.warmup, 5)):
+            step_rot(i)
+        # the roofline figure: the same K calls made one after the other (what rocprofv3 --kernel-trace reports as the kernel's duration)
+        _, kernel_ms_avg = timed(torch, dist, use_dist, stream, step_rot, args.steps)
+    else:
+        elapsed, kernel_ms_avg = timed(torch, dist, use_dist, stream, step_rot, args.steps)
     n_audio = last["n"]
     kernel_ms = per_launch_events(torch, stream, step_rot, min(args.steps, 20))
     # sustained figure: at least 300 back-to-back steps (a short timed region runs at the boost clock)
@@ -301,6 +330,8 @@ def main():
     else:
         sus_steps = 300
         _, kernel_ms_sus = timed(torch, dist, use_dist, stream, step_rot, sus_steps)
+    if overlap:
+        _, kernel_ms_ovl_sus = (None, kernel_ms_ovl) if args.steps >= 300 else timed(torch, dist, use_dist, stream, step_ovl, 300, finish=dm.flush)
     # second, labelled figure: ONE resident input batch (fits the 256 MiB Infinity Cache) — what round 1 reported as `value`
     res_steps = min(args.steps, 100)
     for i in range(min(args.warmup, 10)):
@@ -334,7 +365,9 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "mode": "end-to-end (RCCL scatter of IQ from rank 0 + gather of audio every step)" if args.end_to_end else "compute-only (IQ resident per GPU)",
+            "mode": "end-to-end (RCCL scatter of IQ from rank 0 + gather of audio every step)" if args.end_to_end else
+                    ("compute-only (IQ resident per GPU); timed calls made with SDRFM_F_OVERLAP: consecutive calls may run concurrently on the device"
+                     if overlap else "compute-only (IQ resident per GPU); calls one after the other"),
             "config": {"workload": "BASELINE %s: %d concurrent 2.4 MS/s uint8 IQ streams per GPU x %.1f s (%d B each), "
                                    "%d-tap FIR /%d + FM discriminator + %d-tap /%d -> 48 kHz; device-resident, streams sharded "
                                    "across GPUs with no collective; timed loop rotates over %d input batches = %.0f MB per GPU (> 256 MiB "
@@ -355,6 +388,14 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes},
             "gen_seconds": round(t_gen, 2),
         }
+        if overlap:
+            # `roofline` above: calls one after the other = the kernel's own duration.  This: the timed region itself (overlapped calls);
+            # event span / K is then shorter than a kernel's duration, because consecutive kernels run side by side.
+            res["roofline"]["overlapped_calls"] = {
+                "kernel": served_by, "ms_per_call": round(kernel_ms_ovl, 4),
+                "frac": round(alg_bytes / (kernel_ms_ovl * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                "frac_sustained": round(alg_bytes / (kernel_ms_ovl_sus * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                "note": "bytes per call / (event span of the timed region / K); `value` is measured on these calls"}
         if args.bit_exact:
             res["handle"] = "SDRFM_CFG_BIT_EXACT (fmaf-chain kernels only: NOT the default path)"
         if args.dev_library:

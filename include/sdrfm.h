@@ -73,6 +73,18 @@ enum {
                                      other stream, so work that produces iq or touches audio elsewhere must be
                                      synchronised by the caller, or the caller's stream given via sdrfm_set_stream */
 
+#define SDRFM_F_OVERLAP 2u        /* (with SDRFM_F_DEVICE_PTRS) the call may run on the device CONCURRENTLY with the previous
+                                     call made with this flag: a call's start-up then hides under the previous call's tail (12 % more
+                                     calls per second on BASELINE configs[2]).  The call is ordered behind what the handle's stream
+                                     holds when it is made (so iq may be produced there), but the handle's stream does not wait for
+                                     it: sdrfm_flush / sdrfm_synchronize / any call without the flag order the stream behind all
+                                     overlapped calls.  The caller promises, until the call has completed: (a) the PREVIOUS call's
+                                     iq buffer stays intact — the call warms its streams up from that buffer's last bytes instead of
+                                     waiting for the previous call's state —, and (b) audio is not a buffer the previous overlapped
+                                     call writes (two audio buffers taken in turn).  Same audio, bit for bit, as without the flag.
+                                     Calls that the matrix-pipe kernel does not serve (see SDRFM_CFG_BIT_EXACT), and the first call
+                                     after create / reset / a host-pointer call, run as if the flag were absent */
+
 typedef struct sdrfm_config {
   uint32_t struct_size;           /* = sizeof(sdrfm_config) */
   uint32_t n_streams;             /* independent IQ streams processed per call (>= 1) */
@@ -120,6 +132,8 @@ int  sdrfm_process_batch(sdrfm_t* h, const uint8_t* iq, size_t iq_stride, uint32
 /* Run on a caller-owned HIP stream (hipStream_t passed as void*; NULL = the handle's own stream). */
 int  sdrfm_set_stream(sdrfm_t* h, void* hip_stream);
 int  sdrfm_synchronize(sdrfm_t* h);
+/* Order the handle's stream behind every call made with SDRFM_F_OVERLAP so far (enqueues two event waits; does not block the host). */
+int  sdrfm_flush(sdrfm_t* h);
 
 /* Introspection used by bench/tests: the kernel variant that served the LAST call (before any call: the one the
  * configuration selects), e.g. "fast T64 D10 R4 Ta32 Da5" or "generic T7 D3 Ta5 Da4 NA64". */

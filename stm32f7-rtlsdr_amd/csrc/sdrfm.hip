@@ -1485,10 +1485,20 @@ struct sdrfm {
   float q_scale, q_cst;
   uint32_t q_c0, q_nslot, q_waves_per_cu;
   char fast_q_name[64];
+  // SDRFM_F_OVERLAP: two internal streams taken in turn, so that consecutive calls run concurrently on the device (a call's ramp-up
+  // under the previous call's tail).  ovl_in orders a call behind what the handle's stream holds when it is made; join_overlap()
+  // records ovl_done[k] behind the calls put on internal stream k and makes the handle's stream wait for it.
+  hipStream_t ovl_stream[2];
+  hipEvent_t ovl_in, ovl_done[2];
+  bool ovl_pending[2];
+  uint32_t ovl_next;
+  // the previous call's device buffer (valid after a SDRFM_F_DEVICE_PTRS call): what an overlapped call warms its streams up from
+  const uint8_t* prev_iq; size_t prev_stride; uint32_t prev_nbytes;
 };
 
 static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nbytes, float* d_audio, size_t audio_stride,
-                   uint32_t* n_audio);
+                   uint32_t* n_audio, uint32_t call_flags = 0);
+static int join_overlap(sdrfm* h);
 
 #define HIP_TRY(expr, code)                                                                          \
   do {                                                                                               \
@@ -1508,6 +1518,8 @@ static uint32_t max_audio_for(const sdrfm_config& c, uint32_t nbytes) {
 static void free_handle(sdrfm* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
+  for (int k = 0; k < 2; ++k)
+    if (h->ovl_stream[k]) (void)hipStreamSynchronize(h->ovl_stream[k]);     // overlapped calls still use the buffers freed below
   if (h->d_h) (void)hipFree(h->d_h);
   if (h->d_g) (void)hipFree(h->d_g);
   for (int i = 0; i < 2; ++i) {
@@ -1522,6 +1534,11 @@ static void free_handle(sdrfm* h) {
   if (h->d_audio) (void)hipFree(h->d_audio);
   if (h->d_dbg) (void)hipFree(h->d_dbg);
   if (h->d_qA) (void)hipFree(h->d_qA);
+  for (int k = 0; k < 2; ++k) {
+    if (h->ovl_stream[k]) (void)hipStreamDestroy(h->ovl_stream[k]);
+    if (h->ovl_done[k]) (void)hipEventDestroy(h->ovl_done[k]);
+  }
+  if (h->ovl_in) (void)hipEventDestroy(h->ovl_in);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   free(const_cast<float*>(h->cfg.fir_coeffs));
   free(const_cast<float*>(h->cfg.audio_coeffs));
@@ -1768,6 +1785,8 @@ int sdrfm_reset(sdrfm_t* h) {
   HIP_TRY(hipSetDevice(h->device), SDRFM_FAIL);
   const size_t ns = h->cfg.n_streams, T = h->cfg.fir_taps, Ta = h->cfg.audio_taps;
   const size_t hx = (T > 1 ? T - 1 : 1), hd = (Ta > 1 ? Ta - 1 : 1);
+  { const int jrc = join_overlap(h); if (jrc != SDRFM_OK) return jrc; }
+  h->prev_iq = nullptr;
   for (int i = 0; i < 2; ++i) {
     HIP_TRY(hipMemsetAsync(h->d_hist_x[i], 0, sizeof(float2) * ns * hx, h->stream), SDRFM_FAIL);
     HIP_TRY(hipMemsetAsync(h->d_yprev[i], 0, sizeof(float2) * ns, h->stream), SDRFM_FAIL);
@@ -1790,9 +1809,27 @@ int sdrfm_audio_count(const sdrfm_t* h, uint32_t nbytes, uint32_t* n_audio) {
   return SDRFM_OK;
 }
 
+// Everything issued with SDRFM_F_OVERLAP so far is ordered before whatever the handle's stream is given next.
+static int join_overlap(sdrfm* h) {
+  for (int k = 0; k < 2; ++k)
+    if (h->ovl_pending[k]) {
+      HIP_TRY(hipEventRecord(h->ovl_done[k], h->ovl_stream[k]), SDRFM_FAIL);
+      HIP_TRY(hipStreamWaitEvent(h->stream, h->ovl_done[k], 0), SDRFM_FAIL);
+      h->ovl_pending[k] = false;
+    }
+  return SDRFM_OK;
+}
+
+int sdrfm_flush(sdrfm_t* h) {
+  if (!h) return SDRFM_EINVAL;
+  HIP_TRY(hipSetDevice(h->device), SDRFM_FAIL);
+  return join_overlap(h);
+}
+
 int sdrfm_set_stream(sdrfm_t* h, void* hip_stream) {
   if (!h) return SDRFM_EINVAL;
   HIP_TRY(hipSetDevice(h->device), SDRFM_FAIL);
+  { const int jrc = join_overlap(h); if (jrc != SDRFM_OK) return jrc; }
   HIP_TRY(hipStreamSynchronize(h->stream), SDRFM_FAIL);
   h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
   return SDRFM_OK;
@@ -1801,6 +1838,7 @@ int sdrfm_set_stream(sdrfm_t* h, void* hip_stream) {
 int sdrfm_synchronize(sdrfm_t* h) {
   if (!h) return SDRFM_EINVAL;
   HIP_TRY(hipSetDevice(h->device), SDRFM_FAIL);
+  { const int jrc = join_overlap(h); if (jrc != SDRFM_OK) return jrc; }
   HIP_TRY(hipStreamSynchronize(h->stream), SDRFM_FAIL);
   return SDRFM_OK;
 }
@@ -1809,7 +1847,7 @@ const char* sdrfm_kernel_name(const sdrfm_t* h) { return h ? h->kernel_name : ""
 
 // Enqueue one call on device-resident buffers and advance the host-side phases / state set.
 static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nbytes, float* d_audio, size_t audio_stride,
-                   uint32_t* n_audio) {
+                   uint32_t* n_audio, uint32_t call_flags) {
   const sdrfm_config& c = h->cfg;
   const uint32_t N = nbytes / 2;
   const uint32_t M = (uint32_t)(((uint64_t)h->phase_x + N) / c.fir_decim);
@@ -1861,8 +1899,42 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
                     ((uintptr_t)d_iq % 16 == 0) && (iq_stride % 16 == 0) && N < (1u << 30) && M >= c.audio_taps &&
                     (h->n_seen + 1 >= c.fir_taps || M >= y_aff + c.audio_taps) &&
                     (uint64_t)c.n_streams * q_steps >= 2ull * h->n_cu;
+  // SDRFM_F_OVERLAP: the call goes to one of two internal streams and warms every stream up from the previous call's buffer instead
+  // of reading the carried state, so that it depends on nothing the previous call computes (the state sets are still written, for
+  // whatever call comes next without the flag).  Any other call first orders the handle's stream behind the overlapped ones.
+  const bool ovl = q_ok && (call_flags & SDRFM_F_OVERLAP) && h->prev_iq && h->n_seen + 1 >= c.fir_taps &&
+                   h->prev_nbytes >= 2u * 10u * SDRFM_Q_STEP_OUT && (h->prev_nbytes % 16 == 0) && ((uintptr_t)h->prev_iq % 16 == 0) &&
+                   (h->prev_stride % 16 == 0);
+  if (!ovl) { const int jrc = join_overlap(h); if (jrc != SDRFM_OK) return jrc; }
   if (q_ok) {
     SdrfmQParams q;
+    hipStream_t qs = h->stream;
+    uint32_t k = 0;
+    q.iq_prev = nullptr; q.iq_prev_stride = 0; q.N_prev = 0;
+    if (ovl) {
+      if (!h->ovl_in) {
+        HIP_TRY(hipEventCreateWithFlags(&h->ovl_in, hipEventDisableTiming), SDRFM_ENOMEM);
+        // Two streams only overlap when they sit on different hardware queues, and the runtime hands streams of one priority a small
+        // shared pool of queues (two streams created back to back were seen on the same one: the calls then ran one after the other).
+        // Queues are pooled per priority, so the two internal streams take the two priorities ordinary streams do not use.
+        int pr_least = 0, pr_greatest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest), SDRFM_FAIL);
+        for (int i = 0; i < 2; ++i) {
+          HIP_TRY(hipStreamCreateWithPriority(&h->ovl_stream[i], hipStreamNonBlocking, i == 0 ? pr_greatest : pr_least), SDRFM_ENOMEM);
+          HIP_TRY(hipEventCreateWithFlags(&h->ovl_done[i], hipEventDisableTiming), SDRFM_ENOMEM);
+        }
+      }
+      k = h->ovl_next; h->ovl_next ^= 1u;
+      qs = h->ovl_stream[k];
+      // behind whatever the handle's stream still holds (it may produce iq); an idle stream — the steady state of a caller whose
+      // buffers are filled elsewhere — costs one query instead of two packets
+      if (hipStreamQuery(h->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        HIP_TRY(hipEventRecord(h->ovl_in, h->stream), SDRFM_FAIL);
+        HIP_TRY(hipStreamWaitEvent(qs, h->ovl_in, 0), SDRFM_FAIL);
+      }
+      q.iq_prev = h->prev_iq; q.iq_prev_stride = h->prev_stride; q.N_prev = h->prev_nbytes / 2;
+    }
     q.iq = d_iq; q.iq_stride = iq_stride; q.audio = d_audio; q.audio_stride = audio_stride;
     q.yprev_in = p.yprev_in; q.yprev_out = p.yprev_out; q.hist_d_in = p.hist_d_in; q.hist_d_out = p.hist_d_out;
     q.hist_b_in = p.hist_b_in; q.hist_b_out = p.hist_b_out; q.hist_x_out = p.hist_x_out;
@@ -1875,8 +1947,9 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
     if (runs > q_steps / min_steps) runs = q_steps / min_steps;
     if (runs < 1) runs = 1;
     q.runs = runs;
-    HIP_TRY(sdrfm_q_launch(q, h->q_c0, h->q_nslot, h->stream), SDRFM_FAIL);
-    snprintf(h->kernel_name, sizeof(h->kernel_name), "%s", h->fast_q_name);
+    HIP_TRY(sdrfm_q_launch(q, h->q_c0, h->q_nslot, qs), SDRFM_FAIL);
+    if (ovl) h->ovl_pending[k] = true;
+    snprintf(h->kernel_name, sizeof(h->kernel_name), "%s%s", h->fast_q_name, ovl ? " overlapped" : "");
   } else if (stream_ok) {
     const uint32_t segs = N / h->fast_s->seg;
     p.tiles_per_stream = (segs + 62) / 63;                      // waves per stream: 63 useful lane segments each
@@ -1927,6 +2000,8 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
 
   h->cur ^= 1;
   h->n_seen += N;
+  if (call_flags & SDRFM_F_DEVICE_PTRS) { h->prev_iq = d_iq; h->prev_stride = iq_stride; h->prev_nbytes = nbytes; }
+  else h->prev_iq = nullptr;
   h->phase_x = (uint32_t)(((uint64_t)h->phase_x + N) % c.fir_decim);
   h->phase_d = (uint32_t)(((uint64_t)h->phase_d + M) % c.audio_decim);
   return SDRFM_OK;
@@ -1935,7 +2010,8 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
 int sdrfm_process_batch(sdrfm_t* h, const uint8_t* iq, size_t iq_stride, uint32_t nbytes, float* audio,
                         size_t audio_stride, uint32_t* n_audio, uint32_t flags) {
   if (!h || !n_audio) return SDRFM_EINVAL;
-  if (flags & ~SDRFM_F_DEVICE_PTRS) return SDRFM_EINVAL;
+  if (flags & ~(SDRFM_F_DEVICE_PTRS | SDRFM_F_OVERLAP)) return SDRFM_EINVAL;
+  if ((flags & SDRFM_F_OVERLAP) && !(flags & SDRFM_F_DEVICE_PTRS)) return SDRFM_EINVAL;
   if (nbytes & 1u) return SDRFM_EODD;
   if (nbytes == 0) { *n_audio = 0; return SDRFM_OK; }
   if (!iq) return SDRFM_EINVAL;
@@ -1947,7 +2023,7 @@ int sdrfm_process_batch(sdrfm_t* h, const uint8_t* iq, size_t iq_stride, uint32_
   if (ns > 1 && audio_stride < A) return SDRFM_ECAPACITY;
   HIP_TRY(hipSetDevice(h->device), SDRFM_FAIL);
 
-  if (flags & SDRFM_F_DEVICE_PTRS) return enqueue(h, iq, iq_stride, nbytes, audio, audio_stride, n_audio);
+  if (flags & SDRFM_F_DEVICE_PTRS) return enqueue(h, iq, iq_stride, nbytes, audio, audio_stride, n_audio, flags);
 
   // host buffers: stage -> kernels -> copy back, synchronous (the caller may re-arm `iq` as soon as we return,
   // like the reference FSM does with CommItf.buff)

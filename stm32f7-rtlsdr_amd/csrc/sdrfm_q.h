@@ -13,6 +13,9 @@
 struct SdrfmQParams {
   const uint8_t* iq;            // [n_streams][iq_stride] interleaved u8 I/Q (device), rows 16-byte aligned
   size_t iq_stride;             // bytes
+  const uint8_t* iq_prev;       // the previous call's buffer (rows of N_prev samples, iq_prev_stride bytes apart, 16-byte aligned, N_prev >= 1280
+  size_t iq_prev_stride;        //   and 2 N_prev % 16 == 0) or nullptr: with it the stream's first run needs no carried state
+  uint32_t N_prev;
   float* audio;                 // [n_streams][audio_stride]
   size_t audio_stride;          // floats
   const float2* yprev_in;       // streaming state, as the other kernels keep it (sdrfm.hip: CallParams)

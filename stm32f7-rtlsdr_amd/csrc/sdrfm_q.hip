@@ -114,7 +114,11 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
 #ifdef SDRFM_Q_PHASES
   unsigned long long t_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = 0;
 #endif
-  const bool warm = s0 > 0, last_run = (uint32_t)s1 == p.steps_total;
+  // A run recomputes the step before it unless it starts the stream's chunk AND takes the carried state; with iq_prev (the previous
+  // call's buffer: SDRFM_F_OVERLAP) the stream's first run warms up too, from that buffer's last bytes, and the call depends on
+  // nothing the previous call computes.
+  const bool from_prev = s0 == 0 && p.iq_prev != nullptr;
+  const bool warm = s0 > 0 || from_prev, last_run = (uint32_t)s1 == p.steps_total;
   const int ks = warm ? s0 - 1 : s0, nsteps = s1 - ks;
   const int j0 = (128 * s0) / QDA;                              // first audio output whose newest d lies in an owned step
   int j1 = (128 * s1) / QDA;
@@ -147,7 +151,17 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
   // rounded to a line): the pieces before that are switched off by an out-of-range offset (the instruction still counts).  The
   // first three chunks (what the first step waits for) go out first, then the requests for the L2-resident tables, then the rest of
   // the ring: the opening burst of all waves' first steps is what every wave's start waits behind.
-  {
+  if (from_prev) {
+    // step -1 = the last STEPB bytes of the previous call's row: its bytes >= 1664 come from there (lanes 40.. of chunk 1, lanes ..31
+    // of chunk 2), the rest of chunk 2 is the head of this call's row.  Lanes are switched off by EXEC here, not by an out-of-range
+    // offset, so that no lane's piece is written twice.
+    const unsigned long long pa = (unsigned long long)(p.iq_prev + (size_t)stream * p.iq_prev_stride) + 2ull * p.N_prev - STEPB;
+    const qi4_t rprev = {(int)(unsigned)pa, (int)(unsigned)(pa >> 32), STEPB, 0x00020000};
+    q_raw_buffer_load_lds(rsrc, slot_ptr(0), 16, OOBV, 0, 0, SDRFM_Q_AUX);
+    if (lane >= 40) q_raw_buffer_load_lds(rprev, slot_ptr(1), 16, 1024 + 16 * lane, 0, 0, SDRFM_Q_AUX);
+    if (lane < 32) q_raw_buffer_load_lds(rprev, slot_ptr(0), 16, 16 * lane, 0, 2048, SDRFM_Q_AUX);
+    else q_raw_buffer_load_lds(rsrc, slot_ptr(0), 16, vpos, 0, 2048, SDRFM_Q_AUX);
+  } else {
     const int v0 = warm ? OOBV : vpos;
     const int v1 = (warm && lane < 40) ? OOBV : vpos + 1024;
     q_raw_buffer_load_lds(rsrc, slot_ptr(0), 16, v0, 0, 0, SDRFM_Q_AUX);
@@ -288,8 +302,8 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
 #if defined(SDRFM_Q_ABLATE) && (SDRFM_Q_ABLATE & 1)   // timing experiments of the development harness only (wrong results)
     const float d0 = y[0] + pr + y[1] * pi, d1 = y[2] + y[3] * y[1] + y[0];
 #else
+    const float d1 = q_discriminate(y[2], y[3], y[0], y[1]);   // (the pair that needs no neighbour first: its chain runs while the exchange is in flight)
     const float d0 = q_discriminate(y[0], y[1], pr, pi);
-    const float d1 = q_discriminate(y[2], y[3], y[0], y[1]);
 #endif
     {
       float* dst = db + DB0 + sigma + 128 * osm + dlane;
@@ -311,25 +325,26 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
       int jend = jst + 128;
       if (jend > j1) jend = j1;
       const float* w = db + DB0 + sigma + phi + 10 * lane - (QTA - 1);   // oldest d of output jst + 2 lane: an even word
-      // two chains side by side, each in the oracle's order (oldest d first); the 38-word window is read eight words at a time so
-      // that it never occupies more than a dozen registers (the tap tables leave few)
-      float a0 = 0.0f, a1 = 0.0f;
+      // The whole 40-word window is read up front (one LDS round trip), then four independent chains: each output's 32 taps as two
+      // halves of 16, oldest d first within a half, summed at the end.  (Reading the window eight words at a time in two chains took 340
+      // - 470 cycles per step of the wave's time against 280 for this; the kernel's time did not move: the steps wait for their bytes.)
       float dw[QTA + QDA + 3];
 #pragma unroll
-      for (int blk = 0; blk < (QTA + QDA + 3) / 8; ++blk) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const qf2_t v = *reinterpret_cast<const qf2_t*>(w + 8 * blk + 2 * i);
-          dw[8 * blk + 2 * i] = v.x;
-          dw[8 * blk + 2 * i + 1] = v.y;
-        }
-#pragma unroll
-        for (int e = 8 * blk; e < 8 * blk + 8; ++e) {            // window word e: tap e of output 0, tap e - 5 of output 1
-          if (e < QTA) a0 = __builtin_fmaf(gr[e], dw[e], a0);
-          if (e >= QDA && e - QDA < QTA) a1 = __builtin_fmaf(gr[e - QDA], dw[e], a1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < (QTA + QDA + 3) / 2; ++i) {
+        const qf2_t v = *reinterpret_cast<const qf2_t*>(w + 2 * i);
+        dw[2 * i] = v.x;
+        dw[2 * i + 1] = v.y;
       }
+      float a0 = 0.0f, a0b = 0.0f, a1 = 0.0f, a1b = 0.0f;
+#pragma unroll
+      for (int k = 0; k < QTA / 2; ++k) {
+        a0 = __builtin_fmaf(gr[k], dw[k], a0);
+        a0b = __builtin_fmaf(gr[QTA / 2 + k], dw[QTA / 2 + k], a0b);
+        a1 = __builtin_fmaf(gr[k], dw[QDA + k], a1);
+        a1b = __builtin_fmaf(gr[QTA / 2 + k], dw[QDA + QTA / 2 + k], a1b);
+      }
+      a0 += a0b;
+      a1 += a1b;
       float* out = p.audio + (size_t)stream * p.audio_stride;
       const int j = jst + 2 * lane;
       if (j < jend) __builtin_nontemporal_store(a0, out + j);
@@ -366,7 +381,8 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
 #ifdef SDRFM_Q_PHASES
     for (int i = 0; i < 8; ++i) tsp[8 + i] = t_ph[i];
 #endif
-    tsp[5] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7; tsp[6] = (unsigned long long)nsteps; tsp[7] = __builtin_readcyclecounter() - c_entry;
+    tsp[5] = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 8);
+    tsp[6] = (unsigned long long)nsteps; tsp[7] = __builtin_readcyclecounter() - c_entry;   // word 5: XCC_ID | HW_ID << 8
   }
 #endif
 }

@@ -123,11 +123,13 @@ class FmDemod:
         return out[:, : n.value]
 
     # -- device buffers (torch tensors on cfg.device) -----------------------------------------------------------
-    def process_batch_device(self, iq, audio, nbytes=None):
+    def process_batch_device(self, iq, audio, nbytes=None, overlap=False):
         """Enqueue one batch on device-resident buffers (SDRFM_F_DEVICE_PTRS); returns n_audio per stream.
 
         iq: torch.uint8 [n_streams, >=nbytes] (row stride = iq.stride(0)); audio: torch.float32 [n_streams, cap].
         Nothing is synchronised; the work runs on the stream given to set_stream() (or the handle's own).
+        overlap=True adds SDRFM_F_OVERLAP (include/sdrfm.h): consecutive calls may run concurrently; the previous call's `iq` must stay
+        intact and `audio` must alternate between two buffers; flush() / synchronize() order the stream behind them.
         """
         assert iq.is_cuda and audio.is_cuda and iq.dim() == 2 and audio.dim() == 2
         assert iq.stride(1) == 1 and audio.stride(1) == 1
@@ -135,5 +137,9 @@ class FmDemod:
         n = C.c_uint32()
         self._ck(self._lib.sdrfm_process_batch(self._h, C.c_void_p(iq.data_ptr()), iq.stride(0), nbytes,
                                                C.c_void_p(audio.data_ptr()), audio.stride(0), C.byref(n),
-                                               _l.F_DEVICE_PTRS), "sdrfm_process_batch(device)")
+                                               _l.F_DEVICE_PTRS | (_l.F_OVERLAP if overlap else 0)), "sdrfm_process_batch(device)")
         return n.value
+
+    def flush(self):
+        """Order the handle's stream behind every overlapped call made so far (sdrfm_flush); does not block the host."""
+        self._ck(self._lib.sdrfm_flush(self._h), "sdrfm_flush")

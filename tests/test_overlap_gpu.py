@@ -1,0 +1,119 @@
+"""SDRFM_F_OVERLAP (include/sdrfm.h): consecutive device-pointer calls that may run concurrently on the device.  An overlapped call warms
+its streams up from the previous call's buffer instead of reading the carried state, so the audio must be the same, bit for bit, as
+that of the same calls made one after the other; the state the overlapped calls leave must serve whatever call comes next."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _handles(pkg, ns, T=64, **kw):
+    h, g = pkg.default_config(T)
+    return pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=ns, **kw))
+
+
+@pytest.mark.parametrize("ns,nsamp,T", [(256, 24000, 64), (64, 240000, 64), (256, 24000, 16), (3, 1200000, 64)])
+def test_overlapped_calls_equal_serial_calls_bitwise(pkg, ns, nsamp, T):
+    import torch
+    nb = 6
+    iqs = [torch.from_numpy(pkg.make_iq(ns, nsamp, mode=("fm", "random")[b & 1], first_id=40 * b + 1)).cuda() for b in range(nb)]
+    A = nsamp // 50
+    got = [torch.full((ns, A), float("nan"), dtype=torch.float32, device="cuda") for _ in range(nb)]
+    want = [torch.full((ns, A), float("nan"), dtype=torch.float32, device="cuda") for _ in range(nb)]
+    tail_iq = torch.from_numpy(pkg.make_iq(ns, 777, mode="fm", first_id=999)).cuda()      # an odd-sized call: generic kernel, carried state
+    tail_got = torch.zeros((ns, 64), dtype=torch.float32, device="cuda")
+    tail_want = torch.zeros((ns, 64), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    with _handles(pkg, ns, T) as dm, _handles(pkg, ns, T) as ref:
+        names = []
+        for b in range(nb):
+            assert dm.process_batch_device(iqs[b], got[b], overlap=True) == A
+            names.append(dm.kernel_name)
+        n_tail = dm.process_batch_device(tail_iq, tail_got)            # no flag: ordered behind the overlapped calls by the library
+        dm.synchronize()
+        for b in range(nb):
+            assert ref.process_batch_device(iqs[b], want[b]) == A
+        assert ref.process_batch_device(tail_iq, tail_want) == n_tail
+        ref.synchronize()
+        assert "fast-q" in ref.kernel_name or "generic" in ref.kernel_name
+    assert "overlapped" not in names[0], names                        # nothing to warm up from: served as an ordinary call
+    assert all("fast-q" in n and "overlapped" in n for n in names[1:]), names
+    for b in range(nb):
+        a, w = got[b].cpu().numpy(), want[b].cpu().numpy()
+        assert np.isfinite(w).all()
+        assert np.array_equal(a.view(np.uint32), w.view(np.uint32)), (b, int(np.argmax((a != w).any(axis=0))))
+    assert n_tail > 0
+    assert np.array_equal(tail_got.cpu().numpy()[:, :n_tail].view(np.uint32), tail_want.cpu().numpy()[:, :n_tail].view(np.uint32))
+
+
+def test_overlapped_calls_against_the_oracle(pkg, oracle_mod, tol):
+    """Not only equal to the serial calls: right.  Three overlapped calls on 16 streams against the oracle's one-shot run."""
+    import torch
+    from conftest import scaled_err
+    ns, nsamp = 16, 240000
+    h, g = pkg.default_config(64)
+    host = [pkg.make_iq(ns, nsamp, mode="fm", first_id=70 + 16 * b) for b in range(3)]
+    iqs = [torch.from_numpy(x).cuda() for x in host]
+    out = [torch.zeros((ns, 4800), dtype=torch.float32, device="cuda") for _ in range(3)]
+    torch.cuda.synchronize()
+    with pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=ns)) as dm:
+        for b in range(3):
+            dm.process_batch_device(iqs[b], out[b], overlap=True)
+        assert "overlapped" in dm.kernel_name
+        dm.flush()
+        dm.synchronize()
+    got = np.concatenate([o.cpu().numpy() for o in out], axis=1)
+    for s in (0, 7, 15):
+        want = oracle_mod.Oracle(h, g).process(np.concatenate([x[s] for x in host]))
+        assert scaled_err(got[s], want) <= tol
+
+
+def test_overlapped_call_waits_for_input_produced_on_the_handles_stream(pkg):
+    """iq filled on the caller's stream right before the call (an H2D copy): the overlapped call runs on an internal stream but behind
+    that copy; the caller's stream sees the audio after flush()."""
+    import torch
+    ns, nsamp, nb = 256, 24000, 8
+    host = [torch.from_numpy(pkg.make_iq(ns, nsamp, mode="fm", first_id=300 + b)).pin_memory() for b in range(nb)]
+    ring = [torch.zeros((ns, 2 * nsamp), dtype=torch.uint8, device="cuda") for _ in range(3)]     # the previous buffer stays intact
+    audio = [torch.zeros((ns, 480), dtype=torch.float32, device="cuda") for _ in range(2)]
+    res = [torch.zeros((ns, 480), dtype=torch.float32, device="cuda") for _ in range(nb)]
+    torch.cuda.synchronize()
+    st = torch.cuda.Stream()
+    with _handles(pkg, ns) as dm, _handles(pkg, ns) as ref:
+        dm.set_stream(st.cuda_stream)
+        with torch.cuda.stream(st):
+            for b in range(nb):
+                ring[b % 3].copy_(host[b], non_blocking=True)
+                dm.process_batch_device(ring[b % 3], audio[b & 1], overlap=True)
+                dm.flush()                                                # the copy below runs on `st`: behind the call
+                res[b].copy_(audio[b & 1], non_blocking=True)
+        st.synchronize()
+        want = [ref.process_batch(h.numpy()) for h in host]
+    for b in range(nb):
+        assert np.array_equal(res[b].cpu().numpy().view(np.uint32), want[b].view(np.uint32)), b
+
+
+def test_overlap_flag_on_a_bit_exact_handle_and_flag_errors(pkg):
+    import torch
+    ns, nsamp = 256, 24000
+    iqs = [torch.from_numpy(pkg.make_iq(ns, nsamp, mode="fm", first_id=5 + b)).cuda() for b in range(3)]
+    a = [torch.zeros((ns, 480), dtype=torch.float32, device="cuda") for _ in range(3)]
+    w = [torch.zeros((ns, 480), dtype=torch.float32, device="cuda") for _ in range(3)]
+    torch.cuda.synchronize()
+    with _handles(pkg, ns, bit_exact=True) as dm, _handles(pkg, ns, bit_exact=True) as ref:
+        for b in range(3):
+            dm.process_batch_device(iqs[b], a[b], overlap=True)      # not served by the matrix-pipe kernel: as if the flag were absent
+            assert "overlapped" not in dm.kernel_name and "fast-q" not in dm.kernel_name
+            ref.process_batch_device(iqs[b], w[b])
+        dm.synchronize(); ref.synchronize()
+        for b in range(3):
+            assert np.array_equal(a[b].cpu().numpy().view(np.uint32), w[b].cpu().numpy().view(np.uint32))
+        lib = pkg.load_library()
+        n = C.c_uint32()
+        host = np.zeros((ns, 2 * nsamp), np.uint8)
+        out = np.zeros((ns, 480), np.float32)
+        rc = lib.sdrfm_process_batch(dm._h, host.ctypes.data_as(C.c_void_p), host.strides[0], 2 * nsamp, out.ctypes.data_as(C.c_void_p), 480,
+                                     C.byref(n), 2)                   # SDRFM_F_OVERLAP without SDRFM_F_DEVICE_PTRS
+        assert rc == 16                                                # SDRFM_EINVAL

@@ -135,6 +135,25 @@ int main(int argc, char** argv) {
       if (ohb[((size_t)s * HT + k) * 2] != row[2 * (nsamp - HT + k)] || ohb[((size_t)s * HT + k) * 2 + 1] != row[2 * (nsamp - HT + k) + 1]) worst_state = 1e9;
   }
 
+  if (getenv("QBENCH_PREV") && NB >= 2) {   // the call after this one, twice: state carried from this call's hand-over vs. warmed up from this call's buffer
+    float *d_a1, *d_a2, *d_hd1, *d_hd2; float2 *d_yp1, *d_yp2; uint8_t* d_hb2;
+    CK(hipMalloc(&d_a1, astride * ns * 4)); CK(hipMalloc(&d_a2, astride * ns * 4)); CK(hipMalloc(&d_hd1, ns * 31 * 4)); CK(hipMalloc(&d_hd2, ns * 31 * 4));
+    CK(hipMalloc(&d_yp1, ns * 8)); CK(hipMalloc(&d_yp2, ns * 8)); CK(hipMalloc(&d_hb2, (size_t)ns * HT * 2));
+    CK(hipMemset(d_a1, 0xff, astride * ns * 4)); CK(hipMemset(d_a2, 0xee, astride * ns * 4));
+    SdrfmQParams b1 = p, b2 = p;
+    b1.iq = d_iq + batch; b1.audio = d_a1; b1.yprev_in = d_ypo; b1.hist_d_in = d_hdo; b1.hist_b_in = d_hbo; b1.yprev_out = d_yp1; b1.hist_d_out = d_hd1; b1.hist_b_out = d_hb2;
+    b2.iq = d_iq + batch; b2.audio = d_a2; b2.iq_prev = d_iq; b2.iq_prev_stride = stride; b2.N_prev = nsamp; b2.yprev_in = nullptr; b2.hist_d_in = nullptr; b2.hist_b_in = nullptr;
+    b2.yprev_out = d_yp2; b2.hist_d_out = d_hd2; b2.hist_b_out = d_hb2;
+    CK(sdrfm_q_launch(b1, c0, nslot, st)); CK(sdrfm_q_launch(b2, c0, nslot, st)); CK(hipStreamSynchronize(st));
+    std::vector<uint32_t> a1(astride * ns), a2(astride * ns), s1(ns * 33), s2(ns * 33);
+    CK(hipMemcpy(a1.data(), d_a1, a1.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(a2.data(), d_a2, a2.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(s1.data(), d_hd1, ns * 31 * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(s2.data(), d_hd2, ns * 31 * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(s1.data() + ns * 31, d_yp1, ns * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(s2.data() + ns * 31, d_yp2, ns * 8, hipMemcpyDeviceToHost));
+    size_t diff = 0, first = 0, sdiff = 0;
+    for (int s = 0; s < ns; ++s) for (int j = 0; j < A; ++j) if (a1[s * astride + j] != a2[s * astride + j]) { if (!diff) first = s * (size_t)A + j; ++diff; }
+    for (size_t i = 0; i < s1.size(); ++i) sdiff += s1[i] != s2[i];
+    printf("{\"from_prev_vs_carried_state\":{\"audio_words_differing\":%zu,\"first\":[%zu,%zu],\"state_words_differing\":%zu,\"a1\":\"%08x\",\"a2\":\"%08x\"}}\n", diff, first / A, first % A, sdiff, a1[0], a2[0]);
+  }
   // ---- timing: back-to-back launches over rotating batches, one pair of events ---------------------------------------------------
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int i = 0; i < 5; ++i) { p.iq = d_iq + (size_t)(i % NB) * batch; CK(sdrfm_q_launch(p, c0, nslot, st)); }
@@ -143,6 +162,17 @@ int main(int argc, char** argv) {
   for (int i = 0; i < iters; ++i) { p.iq = d_iq + (size_t)(i % NB) * batch; CK(sdrfm_q_launch(p, c0, nslot, st)); }
   CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  if (getenv("QBENCH_TWO")) {   // the same launches alternating between TWO streams (no dependency between consecutive launches): what would overlapping calls give?
+    hipStream_t s2[2]; CK(hipStreamCreateWithFlags(&s2[0], hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2[1], hipStreamNonBlocking));
+    hipEvent_t f0, f1, j1; CK(hipEventCreate(&f0)); CK(hipEventCreate(&f1)); CK(hipEventCreate(&j1));
+    for (int i = 0; i < 6; ++i) { p.iq = d_iq + (size_t)(i % NB) * batch; CK(sdrfm_q_launch(p, c0, nslot, s2[i & 1])); }
+    CK(hipStreamSynchronize(s2[0])); CK(hipStreamSynchronize(s2[1]));
+    CK(hipEventRecord(f0, s2[0])); CK(hipStreamWaitEvent(s2[1], f0, 0));
+    for (int i = 0; i < iters; ++i) { p.iq = d_iq + (size_t)(i % NB) * batch; CK(sdrfm_q_launch(p, c0, nslot, s2[i & 1])); }
+    CK(hipEventRecord(j1, s2[1])); CK(hipStreamWaitEvent(s2[0], j1, 0)); CK(hipEventRecord(f1, s2[0])); CK(hipEventSynchronize(f1));
+    float ms2; CK(hipEventElapsedTime(&ms2, f0, f1));
+    printf("{\"two_streams_us_per_launch\":%.2f,\"one_stream_us_per_launch\":%.2f}\n", ms2 * 1e3 / iters, ms * 1e3 / iters);
+  }
   if (getenv("QBENCH_STAMPS")) {   // one more launch with per-wave stamps (kernel built with -DSDRFM_Q_STAMPS), summarised per XCC 0
     const size_t nw = (size_t)ns * runs;
     unsigned long long* d_dbg; CK(hipMalloc(&d_dbg, nw * 128)); CK(hipMemset(d_dbg, 0, nw * 128));
@@ -152,10 +182,10 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(hd16.data(), d_dbg, nw * 128, hipMemcpyDeviceToHost));
     for (size_t w = 0; w < nw; ++w) for (int i = 0; i < 8; ++i) hd[8 * w + i] = hd16[16 * w + i];
     unsigned long long t0 = ~0ull;
-    for (size_t w = 0; w < nw; ++w) if (hd[8 * w + 6] && hd[8 * w + 5] == 0 && hd[8 * w] < t0) t0 = hd[8 * w];
+    for (size_t w = 0; w < nw; ++w) if (hd[8 * w + 6] && (hd[8 * w + 5] & 0xff) == 0 && hd[8 * w] < t0) t0 = hd[8 * w];
     double sum[4] = {0, 0, 0, 0}, mx[4] = {0, 0, 0, 0}, mn[4] = {1e30, 1e30, 1e30, 1e30}, waitc = 0, steps = 0, clk_cyc = 0, clk_us = 0; size_t cnt = 0;
     for (size_t w = 0; w < nw; ++w) {
-      if (!hd[8 * w + 6] || hd[8 * w + 5] != 0) continue;
+      if (!hd[8 * w + 6] || (hd[8 * w + 5] & 0xff) != 0) continue;
       for (int i = 0; i < 4; ++i) { const double v = (double)(hd[8 * w + i] - t0) * 0.01; sum[i] += v; if (v > mx[i]) mx[i] = v; if (v < mn[i]) mn[i] = v; }
       waitc += (double)hd[8 * w + 4]; steps += (double)hd[8 * w + 6]; ++cnt;
       clk_cyc += (double)hd[8 * w + 7]; clk_us += (double)(hd[8 * w + 3] - hd[8 * w]) * 0.01;
