@@ -54,6 +54,8 @@ constexpr int STEPB = 16 * BLKB;                // bytes per step
 constexpr int PRE = BLKB;                       // pre-halo: the block before the ring's first byte
 constexpr int DB0 = 128;                        // d buffer: word DB0 + sigma = first d of the current audio stage
 constexpr int DBW = DB0 + 656;                  // words
+constexpr int ABS = 4;                          // audio stages (128 outputs each) parked in LDS before they are stored
+constexpr int ABW = 128 * ABS;                  // words, after the d buffer
 #ifndef SDRFM_Q_AUX
 #define SDRFM_Q_AUX 2   // cache policy of the ring's fetches: 2 = nt (streamed once; measured 0.4-1 us per launch better than the default policy)
 #endif
@@ -101,6 +103,7 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
   static_assert(RINGB % (2 * STEPB) == 0 && NSLOT >= 5 && NSLOT - 4 < 16, "ring: whole pairs of steps");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* const db = reinterpret_cast<float*>(smem + PRE + RINGB);
+  float* const ab = db + DBW;                                   // parked audio outputs
   const int lane = (int)threadIdx.x, n = lane & 15, g = lane >> 4;
   const uint32_t stream = blockIdx.x / p.runs, run = blockIdx.x - stream * p.runs;
   const int s0 = (int)(((uint64_t)run * p.steps_total) / p.runs), s1 = (int)(((uint64_t)(run + 1) * p.steps_total) / p.runs);
@@ -203,7 +206,6 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
   int slot = 0;                                                 // ring slot of the next chunk
   int ringoff = 0;                                              // ring byte offset of the current step
   int osm = warm ? -1 : 0;                                      // owned steps in the d buffer since the last audio stage
-  int jst = j0;                                                 // first audio output of the current stage
   int mbase = 128 * s0;                                         // output index of d-buffer word DB0 + sigma
   const int baddr = BLKB * n + 16 * g;                          // window of block n starts at PRE + ringoff - BLKB + BLKB n
   const int srcaddr = 4 * (g > 0 ? lane - 16 : ((lane + 47) & 63));   // lane holding y[m-1] of this lane's first output
@@ -248,6 +250,30 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
     q_raw_buffer_load_lds(rsrc, slot_ptr(slot), 16, vpos, 0, 1024, SDRFM_Q_AUX);   // chunk numbers = 0 or 2 mod 5); offset:1024 moves both addresses
     slot = (slot + 2 >= NSLOT) ? slot + 2 - NSLOT : slot + 2;
     vpos += 2048;
+  };
+  // The audio is not stored stage by stage: a store counts in vmcnt like the ring's fetches, and the next step's wait for "all but the
+  // youngest fetches" then also waits for the stores' acknowledgement AND for the fetches issued before them — a full round trip through
+  // the memory system every five steps (measured: 4.5 of 27.5 us per call on configs[2]).  The outputs are parked in LDS and stored
+  // after the run's last step (every ABS stages in a long run), whole 8-byte pairs when the row allows.
+  int npend = 0, jfl = j0;                                      // parked stages; first parked output
+  auto flush_audio = [&]() {
+    float* out = p.audio + (size_t)stream * p.audio_stride + jfl;
+#if defined(SDRFM_Q_ABLATE) && (SDRFM_Q_ABLATE & 128)
+    const int cnt = (ab[lane] == 1234.5f) ? 2 : 0;
+#else
+    const int cnt = (j1 - jfl < 128 * npend) ? j1 - jfl : 128 * npend;
+#endif
+    if ((reinterpret_cast<uintptr_t>(out) & 7) == 0) {
+      for (int i = 2 * lane; i < cnt; i += 128) {
+        const qf2_t v = *reinterpret_cast<const qf2_t*>(ab + i);
+        if (i + 1 < cnt) *reinterpret_cast<qf2_t*>(out + i) = v;
+        else out[i] = v.x;
+      }
+    } else {
+      for (int i = lane; i < cnt; i += 64) out[i] = ab[i];
+    }
+    jfl += 128 * npend;
+    npend = 0;
   };
   for (int kk = 0; kk < nsteps; ++kk) {
 #ifdef SDRFM_Q_PHASES
@@ -322,9 +348,7 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
 
     // ---- K4: 128 audio outputs per five owned steps, two consecutive outputs per lane -------------------------------------------
     if (osm == 5 || (kk == nsteps - 1 && osm > 0)) {
-      int jend = jst + 128;
-      if (jend > j1) jend = j1;
-      const float* w = db + DB0 + sigma + phi + 10 * lane - (QTA - 1);   // oldest d of output jst + 2 lane: an even word
+      const float* w = db + DB0 + sigma + phi + 10 * lane - (QTA - 1);   // oldest d of the stage's output 2 lane: an even word
       // The whole 40-word window is read up front (one LDS round trip), then four independent chains: each output's 32 taps as two
       // halves of 16, oldest d first within a half, summed at the end.  (Reading the window eight words at a time in two chains took 340
       // - 470 cycles per step of the wave's time against 280 for this; the kernel's time did not move: the steps wait for their bytes.)
@@ -345,19 +369,17 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
       }
       a0 += a0b;
       a1 += a1b;
-      float* out = p.audio + (size_t)stream * p.audio_stride;
-      const int j = jst + 2 * lane;
-      if (j < jend) __builtin_nontemporal_store(a0, out + j);
-      if (j + 1 < jend) __builtin_nontemporal_store(a1, out + j + 1);
+      *reinterpret_cast<qf2_t*>(ab + 128 * npend + 2 * lane) = qf2_t{a0, a1};
+      ++npend;
       if (osm == 5) {                                           // the stage's last 32 d's become the next stage's history
         if (lane < QTA) {
           const float hv = db[DB0 + sigma + 640 - QTA + lane];
           db[DB0 + sigma - QTA + lane] = hv;
         }
         osm = 0;
-        jst += 128;
         mbase += 640;
       }
+      if (npend == ABS) flush_audio();                          // (long runs only: configs[2]'s runs hold 3.4 stages)
       Q_PHASE(6);                                               // audio stage
     }
   }
@@ -365,6 +387,7 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
   const unsigned long long t_loop = __builtin_amdgcn_s_memrealtime();
 #endif
   wait_vmcnt<0>();                                              // nothing may still be in flight towards this wave's LDS when it ends
+  flush_audio();
 
   // ---- state hand-over by the wave that holds the end of the stream's chunk --------------------------------------------------
   if (last_run) {
@@ -401,7 +424,7 @@ const QVariant* q_find(uint32_t c0, uint32_t nslot) {
 
 }  // namespace
 
-uint32_t sdrfm_q_lds_bytes(uint32_t nslot) { return (uint32_t)(PRE + 1024 * (int)nslot + 4 * DBW); }
+uint32_t sdrfm_q_lds_bytes(uint32_t nslot) { return (uint32_t)(PRE + 1024 * (int)nslot + 4 * (DBW + ABW)); }
 
 const char* sdrfm_q_kernel_symbol(uint32_t first_chunk, uint32_t nslot) {
   const QVariant* v = q_find(first_chunk, nslot);
