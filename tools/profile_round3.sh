@@ -26,12 +26,20 @@ run_wl() {   # name, kernel filter, bench args...
   done
   python3 tools/profile_round3_summarize.py "$W" "$OUT" "$TAG" "$WL" "$KF" "$COMMIT"
 }
-WLS=${WLS:-"fm256 fm512 fm256_T16 fm256_bitexact wbfm spectrum"}      # WLS="wbfm" re-takes one workload only
+WLS=${WLS:-"fm256 fm512 fm256_T16 fm256_bitexact fm256_overlap fm512_overlap wbfm spectrum"}      # WLS="wbfm" re-takes one workload only
 for wl in $WLS; do case $wl in
-  fm256)     run_wl fm256 k_mfir ;;
-  fm512)     run_wl fm512 k_mfir --streams-per-gpu 512 ;;
-  fm256_T16) run_wl fm256_T16 k_mfir --fir-taps 16 ;;
-  fm256_bitexact) run_wl fm256_bitexact k_stream --bit-exact ;;
+  # (--no-overlap: every call after the previous one, so that the tracer's per-kernel duration is the launch's duration; the overlapped
+  #  calls the bench line's `value` is measured on are traced separately below)
+  fm256)     run_wl fm256 k_mfir --no-overlap ;;
+  fm512)     run_wl fm512 k_mfir --streams-per-gpu 512 --no-overlap ;;
+  fm256_T16) run_wl fm256_T16 k_mfir --fir-taps 16 --no-overlap ;;
+  fm256_bitexact) run_wl fm256_bitexact k_stream --bit-exact --no-overlap ;;
+  fm256_overlap|fm512_overlap)   # SDRFM_F_OVERLAP calls: the kernel trace itself (start / end of every dispatch, queue ids) and what it says
+    W=$OUT/work_$wl; mkdir -p "$W"
+    EXTRA=""; [ $wl = fm512_overlap ] && EXTRA="--streams-per-gpu 512"
+    rocprofv3 --output-format csv --kernel-trace -d "$W/trace" -o trace -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline $EXTRA > "$W/bench_trace.log" 2>&1
+    grep "^{\"metric\"" "$W/bench_trace.log" | tail -1 > "$OUT/${TAG}_${wl}_bench_under_rocprof.json"
+    python3 tools/overlap_trace_summarize.py "$(find "$W/trace" -name "*kernel_trace.csv" | head -1)" "$OUT/${TAG}_${wl}_trace.json" "$COMMIT" ;;
   wbfm)      run_wl wbfm k_wbfm_ --workload wbfm ;;
   spectrum)  run_wl spectrum k_spectrum --workload spectrum ;;
 esac; done
