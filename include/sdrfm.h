@@ -134,6 +134,9 @@ int  sdrfm_set_stream(sdrfm_t* h, void* hip_stream);
 int  sdrfm_synchronize(sdrfm_t* h);
 /* Order the handle's stream behind every call made with SDRFM_F_OVERLAP so far (enqueues two event waits; does not block the host). */
 int  sdrfm_flush(sdrfm_t* h);
+/* The same for every overlapped call but the most recent one: a consumer of call k-1's audio that runs on the handle's stream is put behind
+ * call k-1 only, so call k keeps running beside it (and call k+1, ordered behind the consumer, may reuse call k-1's audio buffer). */
+int  sdrfm_flush_previous(sdrfm_t* h);
 
 /* Introspection used by bench/tests: the kernel variant that served the LAST call (before any call: the one the
  * configuration selects), e.g. "fast T64 D10 R4 Ta32 Da5" or "generic T7 D3 Ta5 Da4 NA64". */

@@ -1826,6 +1826,19 @@ int sdrfm_flush(sdrfm_t* h) {
   return join_overlap(h);
 }
 
+// All overlapped calls but the most recent one: what a consumer of call k - 1's audio on the handle's stream needs while call k runs.
+int sdrfm_flush_previous(sdrfm_t* h) {
+  if (!h) return SDRFM_EINVAL;
+  HIP_TRY(hipSetDevice(h->device), SDRFM_FAIL);
+  const uint32_t k = h->ovl_next;                                // the stream the NEXT call takes = the one the call before the last took
+  if (h->ovl_pending[k]) {
+    HIP_TRY(hipEventRecord(h->ovl_done[k], h->ovl_stream[k]), SDRFM_FAIL);
+    HIP_TRY(hipStreamWaitEvent(h->stream, h->ovl_done[k], 0), SDRFM_FAIL);
+    h->ovl_pending[k] = false;
+  }
+  return SDRFM_OK;
+}
+
 int sdrfm_set_stream(sdrfm_t* h, void* hip_stream) {
   if (!h) return SDRFM_EINVAL;
   HIP_TRY(hipSetDevice(h->device), SDRFM_FAIL);

@@ -140,6 +140,10 @@ class FmDemod:
                                                _l.F_DEVICE_PTRS | (_l.F_OVERLAP if overlap else 0)), "sdrfm_process_batch(device)")
         return n.value
 
-    def flush(self):
-        """Order the handle's stream behind every overlapped call made so far (sdrfm_flush); does not block the host."""
-        self._ck(self._lib.sdrfm_flush(self._h), "sdrfm_flush")
+    def flush(self, keep_last=False):
+        """Order the handle's stream behind every overlapped call made so far (sdrfm_flush) — or, with keep_last, behind all but the most
+        recent one (sdrfm_flush_previous); does not block the host."""
+        if keep_last:
+            self._ck(self._lib.sdrfm_flush_previous(self._h), "sdrfm_flush_previous")
+        else:
+            self._ck(self._lib.sdrfm_flush(self._h), "sdrfm_flush")

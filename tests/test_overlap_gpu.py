@@ -117,3 +117,33 @@ def test_overlap_flag_on_a_bit_exact_handle_and_flag_errors(pkg):
         rc = lib.sdrfm_process_batch(dm._h, host.ctypes.data_as(C.c_void_p), host.strides[0], 2 * nsamp, out.ctypes.data_as(C.c_void_p), 480,
                                      C.byref(n), 2)                   # SDRFM_F_OVERLAP without SDRFM_F_DEVICE_PTRS
         assert rc == 16                                                # SDRFM_EINVAL
+
+
+def test_pipeline_with_the_pcm_sink_on_the_handles_stream(pkg):
+    """The loop INTEGRATION.md shows: call k overlapped, then the consumer of call k-1 (the device PCM sink, on the handle's stream) behind
+    sdrfm_flush_previous; two audio buffers in turn.  PCM equal to the host sink over the serial calls' audio."""
+    import torch
+    lib = pkg.load_library()
+    alpha, gain = lib.sdrfm_pcm_alpha(48000.0, 75e-6), np.float32(32767.0 / (2 * np.pi * 75e3 / 240e3))
+    ns, nsamp, nb = 256, 24000, 7
+    iqs = [torch.from_numpy(pkg.make_iq(ns, nsamp, mode="fm", first_id=900 + 3 * b)).cuda() for b in range(nb)]
+    audio = [torch.zeros((ns, 480), dtype=torch.float32, device="cuda") for _ in range(2)]
+    pcm = [torch.zeros((ns, 960), dtype=torch.int16, device="cuda") for _ in range(nb)]
+    torch.cuda.synchronize()
+    st = torch.cuda.Stream()
+    with _handles(pkg, ns) as dm, pkg.PcmSink(ns, alpha, gain) as sink, _handles(pkg, ns) as ref:
+        dm.set_stream(st.cuda_stream); sink.set_stream(st.cuda_stream)
+        for k in range(nb):
+            n = dm.process_batch_device(iqs[k], audio[k & 1], overlap=True)
+            if k:
+                dm.flush(keep_last=True)
+                sink.process_batch_device(audio[(k - 1) & 1], pcm[k - 1], n)
+        dm.flush()
+        sink.process_batch_device(audio[(nb - 1) & 1], pcm[nb - 1], n)
+        st.synchronize()
+        want_audio = [ref.process_batch(x.cpu().numpy()) for x in iqs]
+    for s in (0, 100, 255):
+        state = 0.0
+        for k in range(nb):
+            want, state = pkg.pcm_deemph_s16_host(want_audio[k][s], alpha, gain, state)
+            assert np.array_equal(pcm[k].cpu().numpy()[s], want), (s, k)
