@@ -23,6 +23,7 @@ import glob
 import importlib
 import json
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -94,7 +95,7 @@ def latest_traffic(kernel_name, alg_bytes=None):
     kernel AND this workload size (same algorithmic bytes per launch); None when no committed profile matches."""
     best = None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_pmc.json")) + glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")),
-                   key=lambda fn: (os.path.basename(fn).replace("traffic_", "")[:3], os.path.basename(fn).startswith("traffic_")))
+                   key=lambda fn: (re.match(r"(?:traffic_)?(r\d+[a-z]?)", os.path.basename(fn)).group(1), os.path.basename(fn).startswith("traffic_")))
     for fn in files:
         try:
             with open(fn) as f:
@@ -321,6 +322,9 @@ def main():
     if overlap:
         elapsed, kernel_ms_ovl = timed(torch, dist, use_dist, stream, step_ovl, args.steps, finish=dm.flush)
         served_by = dm.kernel_name
+        if "overlapped" not in served_by:                        # a handle the matrix-pipe kernel does not serve (--bit-exact, other taps): the
+            overlap = False                                      # library makes the calls one after the other; time them as such (below)
+    if overlap:
         # the roofline figure: the same K calls made one after the other (what rocprofv3 --kernel-trace reports as the kernel's duration),
         # from a rested GPU and behind the same warm-up as the timed region
         time.sleep(0.05)

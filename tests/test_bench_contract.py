@@ -32,17 +32,17 @@ def test_traffic_lookup_matches_kernel_and_workload_size():
 def test_round3_traffic_feeds_the_headline_kernel():
     """The default bench line (design Q, configs[2]) takes `roofline.traffic` from the round-3 counter passes of the same kernel and size."""
     b = _bench()
-    head = json.load(open(os.path.join(ROOT, "profiles", "traffic_r03.json")))
+    head = json.load(open(os.path.join(ROOT, "profiles", "traffic_r03b.json")))      # the round's second pass (after the audio stores moved out of the loop)
     assert head["kernel_name"].startswith("fast-q") and "k_mfir" in head["rocprof_kernel"]
     t = b.latest_traffic(head["kernel_name"], head["algorithmic_bytes_per_launch"])
-    assert t is not None and t["file"].startswith(("traffic_r03", "r03_")) and t["hbm_bytes_per_launch"] == head["hbm_bytes_per_launch"]
-    assert 1.0 <= t["hbm_bytes_per_launch"] / head["algorithmic_bytes_per_launch"] < 1.06       # warm-up re-reads: ~4 %
+    assert t is not None and t["file"].startswith(("traffic_r03b", "r03b_")) and t["hbm_bytes_per_launch"] == head["hbm_bytes_per_launch"]
+    assert 1.0 <= t["hbm_bytes_per_launch"] / head["algorithmic_bytes_per_launch"] < 1.06       # warm-up re-reads: ~2 % of the bytes
 
 
 def test_traffic_never_below_algorithmic_bytes():
     """A committed summary whose traffic is below the algorithmic bytes would mean a broken counter pass."""
     import glob
-    for fn in glob.glob(os.path.join(ROOT, "profiles", "r0[23]_*_pmc.json")):
+    for fn in glob.glob(os.path.join(ROOT, "profiles", "r0[23]*_pmc.json")):
         d = json.load(open(fn))
         assert d["hbm_bytes_per_launch"] >= 0.999 * d["algorithmic_bytes_per_launch"], fn
         assert d.get("commit") and d["commit"] != "wip", fn
