@@ -23,6 +23,9 @@
  *   a[j]  = sum_{k} g[k] * d[(j+1)*Da - 1 - k]       d[m<0] = 0, fp32 FMA chain, oldest sample first
  * All state (FIR history, y[m-1], d history, decimator phases) persists across calls; chunk lengths need
  * not be multiples of D.
+ * Which kernel evaluates this is chosen per call: the matrix-pipe kernel ("fast-q": y evaluated exactly in integers from taps rounded
+ * to 24-bit fixed point, within 1e-6 of the definition; tolerance 1e-5) where it applies, kernels that are bit-identical to the
+ * definition everywhere else and on SDRFM_CFG_BIT_EXACT handles — see the flag below and sdrfm_kernel_name().
  *
  * There is NO CPU fallback in this library: every entry point that computes runs hand-written HIP kernels
  * on a gfx950 device and fails with SDRFM_NO_DEVICE when none is usable.
