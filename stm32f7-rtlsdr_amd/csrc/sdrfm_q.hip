@@ -257,7 +257,11 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
   // after the run's last step (every ABS stages in a long run), whole 8-byte pairs when the row allows.
   int npend = 0, jfl = j0;                                      // parked stages; first parked output
   auto flush_audio = [&]() {
+#if defined(SDRFM_Q_ABLATE) && (SDRFM_Q_ABLATE & 256)   // every wave stores to the same 2 KiB (same instructions, no write traffic to speak of)
+    float* out = p.audio;
+#else
     float* out = p.audio + (size_t)stream * p.audio_stride + jfl;
+#endif
 #if defined(SDRFM_Q_ABLATE) && (SDRFM_Q_ABLATE & 128)
     const int cnt = (ab[lane] == 1234.5f) ? 2 : 0;
 #else

@@ -103,3 +103,42 @@ def test_c_multi_gpu_host_on_the_devices_present(pkg, oracle_mod, tmp_path, tran
         assert scaled_err(got[s_], o.process(iq[s_])) <= TOL, s_
     for rep in range(1, ns // 8):
         assert np.array_equal(got[8 * rep:8 * rep + 8].view(np.uint32), got[:8].view(np.uint32)), rep
+
+
+def test_c_pipeline_host_overlapped_equals_serial_and_the_host_sink(pkg, tmp_path):
+    """examples/pipeline_main.c: a capture ring of three device buffers filled on the stream, SDRFM_F_OVERLAP calls, the device PCM sink
+    as the consumer of call k-1 behind sdrfm_flush_previous while call k runs.  The PCM must equal the same program's --serial output
+    bit for bit, and the host sink run over the Python wrapper's serial audio."""
+    import json
+    exe = os.path.join(ROOT, "examples", "pipeline_main")
+    if not os.path.exists(exe):
+        import __graft_entry__ as g
+        g.build()
+    h, g_ = pkg.default_config(64)
+    ns, nsamp, n_calls = 256, 24000, 9
+    batches = [pkg.make_iq(ns, nsamp, mode="fm", first_id=1000 + 5 * k) for k in range(n_calls)]
+    (tmp_path / "iq.u8").write_bytes(b"".join(b.tobytes() for b in batches))
+    (tmp_path / "h.f32").write_bytes(h.tobytes())
+    (tmp_path / "g.f32").write_bytes(g_.tobytes())
+    outs = {}
+    for mode in ("overlapped", "serial"):
+        out = tmp_path / ("pcm_%s.s16" % mode)
+        cmd = [exe, str(tmp_path / "iq.u8"), str(tmp_path / "h.f32"), str(tmp_path / "g.f32"), str(ns), str(2 * nsamp), str(n_calls), str(out)]
+        if mode == "serial":
+            cmd.append("--serial")
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        info = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert info["mode"] == mode and info["n_audio"] == 480 and info["kernel"].startswith("fast-q")
+        assert ("overlapped" in info["kernel"]) == (mode == "overlapped")
+        outs[mode] = np.fromfile(out, dtype=np.int16).reshape(n_calls, ns, 960)
+    assert np.array_equal(outs["overlapped"], outs["serial"])
+    lib = pkg.load_library()
+    alpha, gain = lib.sdrfm_pcm_alpha(48000.0, 75e-6), np.float32(16688.0)                   # the program's constants
+    with pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g_, n_streams=ns)) as dm:
+        audio = [dm.process_batch(b) for b in batches]
+    for s_ in (0, 131, 255):
+        st = 0.0
+        for k in range(n_calls):
+            want, st = pkg.pcm_deemph_s16_host(audio[k][s_], alpha, gain, st)
+            assert np.array_equal(outs["overlapped"][k, s_], want), (s_, k)
