@@ -14,7 +14,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 t_end, cases, calls_q, fails, worst_exact, worst_oracle = time.time() + budget, 0, 0, 0, 0.0, 0.0
-n_scaled = n_cut = 0
+n_scaled = n_cut = calls_ovl = 0
 while time.time() < t_end:
     T = int(rng.choice([16, 32, 64, 64, 48, 90, 33]))
     g = pkg.default_config(64)[1]
@@ -56,7 +56,9 @@ while time.time() < t_end:
         cap = fast.audio_count(2 * n) + 1
         a1 = torch.full((ns, cap), 3.0, dtype=torch.float32, device="cuda"); a2 = torch.full((ns, cap), 5.0, dtype=torch.float32, device="cuda")
         torch.cuda.synchronize()
-        n1 = fast.process_batch_device(dev[:, 2 * pos:], a1, nbytes=2 * n); name = fast.kernel_name.split()[0]
+        ovl = bool(rng.random() < 0.5)                                                                # SDRFM_F_OVERLAP on half of the calls: the previous call's bytes
+        n1 = fast.process_batch_device(dev[:, 2 * pos:], a1, nbytes=2 * n, overlap=ovl)                # lie right before this call's in `dev` and stay intact
+        name = fast.kernel_name.split()[0]; calls_ovl += "overlapped" in fast.kernel_name
         n2 = exact.process_batch_device(dev[:, 2 * pos:], a2, nbytes=2 * n)
         fast.synchronize(); exact.synchronize()
         log.append((n, name)); calls_q += name == "fast-q"
@@ -113,7 +115,7 @@ while time.time() < t_end:
             os.makedirs(os.environ["FUZZ_DUMP"], exist_ok=True)
             np.savez_compressed(os.path.join(os.environ["FUZZ_DUMP"], "case_%d_%d.npz" % (seed, cases)), h=h, g=g, ns=ns, stride=stride, rows=rows,
                                 sizes=np.array(sizes), resets=np.array([i for i, x in enumerate([e for e in log if e == "reset" or (isinstance(e, tuple) and isinstance(e[0], int))]) if x == "reset"]))
-print("design-Q soak: cases %d  calls served by fast-q %d  failures %d  worst vs bit-exact kernels %.3g  worst vs oracle %.3g  (seed %d, %.0f s); "
+print("design-Q soak: cases %d  calls served by fast-q %d (%d of them overlapped)  failures %d  worst vs bit-exact kernels %.3g  worst vs oracle %.3g  (seed %d, %.0f s); "
       "ill-conditioned outputs of the distinct rows: %d judged with a tolerance scaled by 2e-2 / |y| (deep fades), %d left out (branch cut)"
-      % (cases, calls_q, fails, worst_exact, worst_oracle, seed, budget, n_scaled, n_cut))
+      % (cases, calls_q, calls_ovl, fails, worst_exact, worst_oracle, seed, budget, n_scaled, n_cut))
 sys.exit(1 if fails else 0)
