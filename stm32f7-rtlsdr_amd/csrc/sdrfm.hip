@@ -1952,7 +1952,7 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
     q.yprev_in = p.yprev_in; q.yprev_out = p.yprev_out; q.hist_d_in = p.hist_d_in; q.hist_d_out = p.hist_d_out;
     q.hist_b_in = p.hist_b_in; q.hist_b_out = p.hist_b_out; q.hist_x_out = p.hist_x_out;
     q.A = h->d_qA; q.g = h->d_g; q.q0 = h->q_scale; q.q2 = 65536.0f * h->q_scale; q.cst = h->q_cst;
-    q.T = c.fir_taps; q.N = N; q.M = M; q.A_out = A; q.steps_total = q_steps; q.n_streams = c.n_streams; q.dbg = nullptr;
+    q.T = c.fir_taps; q.N = N; q.M = M; q.A_out = A; q.steps_total = q_steps; q.n_streams = c.n_streams; q.dbg = nullptr; q.prio_by_age = ovl ? 0u : 1u;
     // runs (waves) per stream: fill the machine once; every run at least four owned steps (a run that does not start its stream
     // recomputes one step), two when the call is too small to fill the machine otherwise
     uint32_t runs = (h->q_waves_per_cu * h->n_cu) / c.n_streams;

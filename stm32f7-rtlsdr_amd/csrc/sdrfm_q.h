@@ -33,6 +33,7 @@ struct SdrfmQParams {
   uint32_t steps_total;         // ceil(M / 128)
   uint32_t runs;                // runs (waves) per stream
   uint32_t n_streams;
+  uint32_t prio_by_age;         // 1: from the middle of its run a wave's issue priority is its age rank in the SIMD (calls one after the other)
   unsigned long long* dbg;      // development build: per-wave time stamps (else nullptr)
 };
 

@@ -91,7 +91,7 @@ int main(int argc, char** argv) {
   p.iq = d_iq; p.iq_stride = stride; p.audio = d_audio; p.audio_stride = astride;
   p.yprev_in = d_ypi; p.yprev_out = d_ypo; p.hist_d_in = d_hdi; p.hist_d_out = d_hdo; p.hist_b_in = d_hbi; p.hist_b_out = d_hbo; p.hist_x_out = d_hxo;
   p.A = d_A; p.g = d_g; p.q0 = q; p.q2 = 65536.0f * q; p.cst = cst;
-  p.T = T; p.N = nsamp; p.M = M; p.A_out = A; p.steps_total = (M + 127) / 128; p.runs = runs; p.n_streams = ns; p.dbg = nullptr;
+  p.T = T; p.N = nsamp; p.M = M; p.A_out = A; p.steps_total = (M + 127) / 128; p.runs = runs; p.n_streams = ns; p.dbg = nullptr; p.prio_by_age = getenv("QBENCH_NOPRIO") ? 0u : 1u;
   hipStream_t st; CK(hipStreamCreate(&st));
   CK(sdrfm_q_launch(p, c0, nslot, st));
   CK(hipStreamSynchronize(st));
@@ -165,6 +165,7 @@ int main(int argc, char** argv) {
   if (getenv("QBENCH_TWO")) {   // the same launches alternating between TWO streams (no dependency between consecutive launches): what would overlapping calls give?
     hipStream_t s2[2]; CK(hipStreamCreateWithFlags(&s2[0], hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2[1], hipStreamNonBlocking));
     hipEvent_t f0, f1, j1; CK(hipEventCreate(&f0)); CK(hipEventCreate(&f1)); CK(hipEventCreate(&j1));
+    p.prio_by_age = 0;                                             // (as the library does for overlapped calls)
     for (int i = 0; i < 6; ++i) { p.iq = d_iq + (size_t)(i % NB) * batch; CK(sdrfm_q_launch(p, c0, nslot, s2[i & 1])); }
     CK(hipStreamSynchronize(s2[0])); CK(hipStreamSynchronize(s2[1]));
     CK(hipEventRecord(f0, s2[0])); CK(hipStreamWaitEvent(s2[1], f0, 0));
