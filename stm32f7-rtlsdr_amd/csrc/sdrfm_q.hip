@@ -283,7 +283,8 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
   // queues do the same, so the first / second / third wave of a SIMD end 20.0 / 21.8 / 23.6 us after the launch (configs[2], §4.Q of
   // DESIGN.md) and the kernel waits for the last one.  From its middle step on a wave runs at priority = its age rank (HW_ID.wave_id:
   // 0 = oldest), which closes the gap: 26.5 -> 25.7 us per call.  (For the whole run it over-corrects: the oldest waves end last.)
-  // Not for overlapped calls — two kernels share the SIMDs there and the ranks mean something else: measured +0.3 us.
+  // Not for overlapped calls — two kernels share the SIMDs there and the ranks mean something else: measured +0.3 us.  Priorities by
+  // remaining steps (a wave that is behind outranks one that is ahead), alone or on top of the rank: no better (25.9 - 26.4 us).
   const int wrank = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 4) & 15u);
   const int prio_at = p.prio_by_age ? nsteps / 2 : -1;
   for (int kk = 0; kk < nsteps; ++kk) {
