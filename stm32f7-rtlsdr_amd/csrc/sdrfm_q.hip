@@ -106,7 +106,10 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
   float* const ab = db + DBW;                                   // parked audio outputs
   const int lane = (int)threadIdx.x, n = lane & 15, g = lane >> 4;
   const uint32_t stream = blockIdx.x / p.runs, run = blockIdx.x - stream * p.runs;
-  const int s0 = (int)(((uint64_t)run * p.steps_total) / p.runs), s1 = (int)(((uint64_t)(run + 1) * p.steps_total) / p.runs);
+  // (with iq_prev the stream's first run warms up like every other run: the cuts are made over steps_total + 1 steps and moved down by
+  // one, so that every wave still walks the same number of steps)
+  const uint32_t vshift = p.iq_prev ? 1u : 0u, vsteps = p.steps_total + vshift;
+  const int s0 = run == 0 ? 0 : (int)(((uint64_t)run * vsteps) / p.runs - vshift), s1 = (int)(((uint64_t)(run + 1) * vsteps) / p.runs - vshift);
   if (s0 >= s1) return;
 #ifdef SDRFM_Q_STAMPS   // development harness (tools/qbench): per-wave time stamps, 8 words per wave
   unsigned long long* const tsp = p.dbg ? p.dbg + 16 * (size_t)blockIdx.x : nullptr;

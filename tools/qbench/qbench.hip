@@ -163,7 +163,20 @@ int main(int argc, char** argv) {
   CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   if (getenv("QBENCH_TWO")) {   // the same launches alternating between TWO streams (no dependency between consecutive launches): what would overlapping calls give?
-    hipStream_t s2[2]; CK(hipStreamCreateWithFlags(&s2[0], hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2[1], hipStreamNonBlocking));
+    hipStream_t s2[2];
+    const char* how = getenv("QBENCH_TWO");
+    if (!strcmp(how, "prio")) {                                   // the library's way: the two priorities ordinary streams do not use
+      int lo = 0, hi = 0; CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      CK(hipStreamCreateWithPriority(&s2[0], hipStreamNonBlocking, hi)); CK(hipStreamCreateWithPriority(&s2[1], hipStreamNonBlocking, lo));
+    } else if (!strcmp(how, "prio_same")) {
+      int lo = 0, hi = 0; CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      CK(hipStreamCreateWithPriority(&s2[0], hipStreamNonBlocking, hi)); CK(hipStreamCreateWithPriority(&s2[1], hipStreamNonBlocking, hi));
+    } else if (!strcmp(how, "cumask")) {                          // streams with a (full) CU mask
+      hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, 0));
+      uint32_t mask[16]; const uint32_t words = (uint32_t)((pr.multiProcessorCount + 31) / 32);
+      for (uint32_t i = 0; i < 16; ++i) mask[i] = 0xffffffffu;
+      CK(hipExtStreamCreateWithCUMask(&s2[0], words, mask)); CK(hipExtStreamCreateWithCUMask(&s2[1], words, mask));
+    } else { CK(hipStreamCreateWithFlags(&s2[0], hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2[1], hipStreamNonBlocking)); }
     hipEvent_t f0, f1, j1; CK(hipEventCreate(&f0)); CK(hipEventCreate(&f1)); CK(hipEventCreate(&j1));
     p.prio_by_age = 0;                                             // (as the library does for overlapped calls)
     for (int i = 0; i < 6; ++i) { p.iq = d_iq + (size_t)(i % NB) * batch; CK(sdrfm_q_launch(p, c0, nslot, s2[i & 1])); }
