@@ -24,11 +24,14 @@
  *   --> y = fma(f32(S0 + (S1 << 8)), q, fma(f32(S2), 65536 q, 0.5 sum h)): lane (n, g) holds (I, Q) of outputs 8 n + 2 g, +1
  *   --> y[m-1] of the lane's first output from lane - 16 (ds_bpermute) --> K3 twice (scalar code: packed f32 instructions stall
  *       the matrix pipe, profiles/ubench_r03) --> d's into an LDS buffer
- *   every 5 steps (640 d's = 128 audio outputs): K4, two consecutive outputs per lane from 19 aligned 8-byte reads --> HBM
+ *   every 5 steps (640 d's = 128 audio outputs): K4, two consecutive outputs per lane from 20 aligned 8-byte reads --> parked in LDS
+ *   after the run's last step: the parked outputs --> HBM, 8 bytes per lane (no store inside the loop: it would count in vmcnt)
  *
  * A run that does not start its stream first recomputes the step before it ("warm-up": only its last four blocks are fetched
  * and matter) for the 31 d's and the y[m-1] its first audio outputs need; the stream's first run takes them from the carried
- * state.  The wave that holds the end of the stream's chunk hands the state over.
+ * state — or, for a call made with SDRFM_F_OVERLAP, warms up the same way from the last bytes of the previous call's buffer, so
+ * that the call depends on nothing the previous call computes (bit-identical either way: y is exact).  The wave that holds the
+ * end of the stream's chunk hands the state over.
  */
 #include <hip/hip_runtime.h>
 
