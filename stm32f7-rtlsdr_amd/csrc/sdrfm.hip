@@ -1925,16 +1925,16 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
     uint32_t k = 0;
     q.iq_prev = nullptr; q.iq_prev_stride = 0; q.N_prev = 0;
     if (ovl) {
-      if (!h->ovl_in) {
-        HIP_TRY(hipEventCreateWithFlags(&h->ovl_in, hipEventDisableTiming), SDRFM_ENOMEM);
+      if (!h->ovl_done[1]) {                                      // (created piece by piece: a failure half-way leaves nothing half-used)
+        if (!h->ovl_in) HIP_TRY(hipEventCreateWithFlags(&h->ovl_in, hipEventDisableTiming), SDRFM_ENOMEM);
         // Two streams only overlap when they sit on different hardware queues, and the runtime hands streams of one priority a small
         // shared pool of queues (two streams created back to back were seen on the same one: the calls then ran one after the other).
         // Queues are pooled per priority, so the two internal streams take the two priorities ordinary streams do not use.
         int pr_least = 0, pr_greatest = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest), SDRFM_FAIL);
         for (int i = 0; i < 2; ++i) {
-          HIP_TRY(hipStreamCreateWithPriority(&h->ovl_stream[i], hipStreamNonBlocking, i == 0 ? pr_greatest : pr_least), SDRFM_ENOMEM);
-          HIP_TRY(hipEventCreateWithFlags(&h->ovl_done[i], hipEventDisableTiming), SDRFM_ENOMEM);
+          if (!h->ovl_stream[i]) HIP_TRY(hipStreamCreateWithPriority(&h->ovl_stream[i], hipStreamNonBlocking, i == 0 ? pr_greatest : pr_least), SDRFM_ENOMEM);
+          if (!h->ovl_done[i]) HIP_TRY(hipEventCreateWithFlags(&h->ovl_done[i], hipEventDisableTiming), SDRFM_ENOMEM);
         }
       }
       k = h->ovl_next; h->ovl_next ^= 1u;
