@@ -6,17 +6,16 @@
  * setting it is the bulk-IN FSM (one filled CommItf.buff per RTLSDR_XFER_COMPLETE, usbh_rtlsdr.c:1058-1101) of many dongles.
  *
  *   pipeline_main <iq.u8> <h.f32> <g.f32> <n_streams> <nbytes_per_stream_per_call> <n_calls> <pcm_out.s16> [--serial]
+ *   (no timing here: with the capture coming from pageable host memory the H2D copies set the pace; bench.py measures the calls)
  *
  * iq.u8 holds n_calls consecutive batches of [n_streams][nbytes] bytes (batch-major).  pcm_out: n_calls blocks of [n_streams][2 n_audio]
  * int16.  --serial makes the same calls without the flag (the output must be the same, bit for bit).  Prints one JSON line.
  */
-#define _POSIX_C_SOURCE 199309L
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include <time.h>
 
 #include "sdrfm.h"
 
@@ -77,8 +76,6 @@ int main(int argc, char** argv) {
   HIPC(hipMalloc((void**)&d_pcm, (size_t)n_calls * ns * 2 * astride * sizeof(short)));
   const uint32_t flags = SDRFM_F_DEVICE_PTRS | (serial ? 0u : SDRFM_F_OVERLAP);
 
-  struct timespec t0, t1;
-  clock_gettime(CLOCK_MONOTONIC, &t0);
   uint32_t na = 0;
   for (int k = 0; k < n_calls; ++k) {
     /* "the capture": batch k into ring[k % RING] on the stream.  The buffer was last read by call k - RING, which the consumer of call
@@ -93,8 +90,6 @@ int main(int argc, char** argv) {
   SDRC(sdrfm_flush(fm));
   SDRC(sdrfm_pcm_sink_process_batch(sink, d_audio[(n_calls - 1) & 1], astride, na, d_pcm + (size_t)(n_calls - 1) * ns * 2 * astride, 2 * astride, SDRFM_F_DEVICE_PTRS));
   HIPC(hipStreamSynchronize(st));
-  clock_gettime(CLOCK_MONOTONIC, &t1);
-  const double dt = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 
   short* pcm = (short*)malloc((size_t)n_calls * ns * 2 * astride * sizeof(short));
   HIPC(hipMemcpy(pcm, d_pcm, (size_t)n_calls * ns * 2 * astride * sizeof(short), hipMemcpyDeviceToHost));
@@ -103,8 +98,8 @@ int main(int argc, char** argv) {
   for (int k = 0; k < n_calls; ++k)
     for (uint32_t s = 0; s < ns; ++s) fwrite(pcm + ((size_t)k * ns + s) * 2 * astride, sizeof(short), 2 * (size_t)na, fo);
   fclose(fo);
-  printf("{\"n_streams\":%u,\"bytes_per_stream_per_call\":%u,\"n_calls\":%d,\"n_audio\":%u,\"mode\":\"%s\",\"kernel\":\"%s\",\"seconds\":%.6f}\n", ns, nbytes, n_calls,
-         na, serial ? "serial" : "overlapped", sdrfm_kernel_name(fm), dt);
+  printf("{\"n_streams\":%u,\"bytes_per_stream_per_call\":%u,\"n_calls\":%d,\"n_audio\":%u,\"mode\":\"%s\",\"kernel\":\"%s\"}\n", ns, nbytes, n_calls,
+         na, serial ? "serial" : "overlapped", sdrfm_kernel_name(fm));
 
   sdrfm_pcm_sink_destroy(sink);
   sdrfm_destroy(fm);
