@@ -109,6 +109,37 @@ __device__ __forceinline__ void fft16_dit(float (&ar)[16], float (&ai)[16]) {
   for (int k = 0; k < 16; ++k) { ar[k] = xr[k]; ai[k] = xi[k]; }
 }
 
+// K3 of the WBFM path (all three kernels, scalar / pair / eight pairs: the same operations, bit-identical to each other): the spec's
+// conjugate product (one fused, two rounded products) and the shorter atan2 of design Q — range reduction as in sdrfm_atan2f, a
+// 6-coefficient minimax polynomial in s = v^2 (|error| <= 3.9e-7 rad; sdrfm_atan2f: 8 coefficients, 6.5e-8), (0, 0) -> +-0 through a
+// clamp of the larger magnitude instead of a select.  A step runs 16 of these: they were 45 % of the step kernel's vector instructions.
+// Audio within 7e-7 of the oracle (tolerance 1e-5).
+#define WBFM_ATAN_C5 0x1.e34882p-8f
+#define WBFM_ATAN_C4 -0x1.22fc74p-5f
+#define WBFM_ATAN_C3 0x1.509024p-4f
+#define WBFM_ATAN_C2 -0x1.12688cp-3f
+#define WBFM_ATAN_C1 0x1.96c562p-3f
+#define WBFM_ATAN_C0 -0x1.554086p-2f
+__device__ __forceinline__ float wbfm_discriminate(float yr, float yi, float pr, float pi) {
+  const float re = __builtin_fmaf(yr, pr, yi * pi);
+  const float im = yi * pr - yr * pi;
+  const float ax = __builtin_fabsf(re), ay = __builtin_fabsf(im);
+  const float mx = __builtin_fmaxf(__builtin_fmaxf(ax, ay), 0x1p-120f), mn = __builtin_fminf(ax, ay);
+  const float v = mn * __builtin_amdgcn_rcpf(mx);
+  const float s2 = v * v;
+  float q = WBFM_ATAN_C5;
+  q = __builtin_fmaf(q, s2, WBFM_ATAN_C4);
+  q = __builtin_fmaf(q, s2, WBFM_ATAN_C3);
+  q = __builtin_fmaf(q, s2, WBFM_ATAN_C2);
+  q = __builtin_fmaf(q, s2, WBFM_ATAN_C1);
+  q = __builtin_fmaf(q, s2, WBFM_ATAN_C0);
+  float a = __builtin_fmaf(v, s2 * q, v);
+  if (ay > ax) a = 0x1.921fb6p+0f - a;
+  if (re < 0.0f) a = 0x1.921fb6p+1f - a;
+  return __builtin_copysignf(a, im);
+}
+
+
 // LDS: xs[NX] f32x2 | us[(NT+1)*NB] f32x2 (branch outputs, then band outputs in place) | ps[P]
 __global__ void __launch_bounds__(256) k_wbfm_chan(WParams w) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -171,7 +202,7 @@ __global__ void __launch_bounds__(256) k_wbfm_chan(WParams w) {
     const int b = idx / (t1 - t0), t = t0 + idx % (t1 - t0);   // t fastest: coalesced stores into dbuf[stream][band][t]
     const float2 c = us[(t - ta) * NB + b];
     const float2 pv = (t == 0) ? w.cprev_in[(size_t)stream * NB + b] : us[(t - 1 - ta) * NB + b];
-    w.dbuf[((size_t)stream * NB + b) * w.dcap + t] = sdrfm_discriminate(c.x, c.y, pv.x, pv.y);
+    w.dbuf[((size_t)stream * NB + b) * w.dcap + t] = wbfm_discriminate(c.x, c.y, pv.x, pv.y);
     if (t == (int)w.Tn - 1) w.cprev_out[(size_t)stream * NB + b] = c;
   }
 }
@@ -243,20 +274,18 @@ __device__ __forceinline__ void wpk_fma_v(wf2_t& acc, wf2_t tap_pair, wf2_t x) {
   else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(tap_pair), "v"(x));
 }
 
-// packed K3 for two consecutive steps of one band (same roundings as sdrfm_discriminate)
+// packed K3 for two consecutive steps of one band (same roundings as wbfm_discriminate)
 __device__ __forceinline__ wf2_t watan2_pair(wf2_t y, wf2_t x) {
   const wf2_t ax = __builtin_elementwise_abs(x), ay = __builtin_elementwise_abs(y);
-  const wf2_t mx = __builtin_elementwise_max(ax, ay), mn = __builtin_elementwise_min(ax, ay);
+  const wf2_t mx = __builtin_elementwise_max(__builtin_elementwise_max(ax, ay), wf2_t{0x1p-120f, 0x1p-120f}), mn = __builtin_elementwise_min(ax, ay);
   const wf2_t t = mn * wf2_t{__builtin_amdgcn_rcpf(mx.x), __builtin_amdgcn_rcpf(mx.y)};
   const wf2_t s = t * t;
-  wf2_t q = wf2_t{0x1.57b128p-9f, 0x1.57b128p-9f};
-  q = __builtin_elementwise_fma(q, s, wf2_t{-0x1.efda1p-7f, -0x1.efda1p-7f});
-  q = __builtin_elementwise_fma(q, s, wf2_t{0x1.50dd96p-5f, 0x1.50dd96p-5f});
-  q = __builtin_elementwise_fma(q, s, wf2_t{-0x1.2dbcfap-4f, -0x1.2dbcfap-4f});
-  q = __builtin_elementwise_fma(q, s, wf2_t{0x1.b11b74p-4f, 0x1.b11b74p-4f});
-  q = __builtin_elementwise_fma(q, s, wf2_t{-0x1.228754p-3f, -0x1.228754p-3f});
-  q = __builtin_elementwise_fma(q, s, wf2_t{0x1.99673ep-3f, 0x1.99673ep-3f});
-  q = __builtin_elementwise_fma(q, s, wf2_t{-0x1.55546cp-2f, -0x1.55546cp-2f});
+  wf2_t q = wf2_t{WBFM_ATAN_C5, WBFM_ATAN_C5};
+  q = __builtin_elementwise_fma(q, s, wf2_t{WBFM_ATAN_C4, WBFM_ATAN_C4});
+  q = __builtin_elementwise_fma(q, s, wf2_t{WBFM_ATAN_C3, WBFM_ATAN_C3});
+  q = __builtin_elementwise_fma(q, s, wf2_t{WBFM_ATAN_C2, WBFM_ATAN_C2});
+  q = __builtin_elementwise_fma(q, s, wf2_t{WBFM_ATAN_C1, WBFM_ATAN_C1});
+  q = __builtin_elementwise_fma(q, s, wf2_t{WBFM_ATAN_C0, WBFM_ATAN_C0});
   const wf2_t a = __builtin_elementwise_fma(t, s * q, t);
   float a0 = a.x, a1 = a.y;
   if (ay.x > ax.x) a0 = 0x1.921fb6p+0f - a0;
@@ -269,8 +298,7 @@ __device__ __forceinline__ wf2_t wdisc_pair(wf2_t c0, wf2_t cm1, wf2_t c1) {   /
   const wf2_t yr = {c0.x, c1.x}, yi = {c0.y, c1.y}, pr = {cm1.x, c0.x}, pi = {cm1.y, c0.y};
   const wf2_t re = __builtin_elementwise_fma(yr, pr, yi * pi);
   const wf2_t im = yi * pr - yr * pi;
-  const wf2_t a = watan2_pair(im, re);
-  return wf2_t{(re.x == 0.0f && im.x == 0.0f) ? 0.0f : a.x, (re.y == 0.0f && im.y == 0.0f) ? 0.0f : a.y};
+  return watan2_pair(im, re);
 }
 
 // One stage of the 16-point DFT across the 16 lanes of a group (a DPP row), butterfly partner = lane ^ HALF.
@@ -535,7 +563,7 @@ typedef float wf4_t __attribute__((ext_vector_type(4)));
 struct __attribute__((packed, aligned(2))) wraw16 { unsigned int w[4]; };
 
 // K3 for all 16 bands of a step, two bands per packed operation, written stage by stage over the 8 band pairs so that the eight
-// dependent chains are interleaved in program order (same roundings as sdrfm_discriminate / watan2_pair)
+// dependent chains are interleaved in program order (same roundings as wbfm_discriminate / watan2_pair)
 __device__ __forceinline__ void wdisc_bands8(const wf2_t (&yr)[8], const wf2_t (&yi)[8], const wf2_t (&pr)[8], const wf2_t (&pi)[8], wf2_t (&d)[8]) {
   wf2_t re[8], im[8], t[8], s[8], q[8], ax[8], ay[8];
 #pragma unroll
@@ -543,14 +571,14 @@ __device__ __forceinline__ void wdisc_bands8(const wf2_t (&yr)[8], const wf2_t (
 #pragma unroll
   for (int k = 0; k < 8; ++k) {                                 // atan2(y = im, x = re)
     ax[k] = __builtin_elementwise_abs(re[k]); ay[k] = __builtin_elementwise_abs(im[k]);
-    const wf2_t mx = __builtin_elementwise_max(ax[k], ay[k]), mn = __builtin_elementwise_min(ax[k], ay[k]);
+    const wf2_t mx = __builtin_elementwise_max(__builtin_elementwise_max(ax[k], ay[k]), wf2_t{0x1p-120f, 0x1p-120f}), mn = __builtin_elementwise_min(ax[k], ay[k]);
     t[k] = mn * wf2_t{__builtin_amdgcn_rcpf(mx.x), __builtin_amdgcn_rcpf(mx.y)};
     s[k] = t[k] * t[k];
-    q[k] = wf2_t{0x1.57b128p-9f, 0x1.57b128p-9f};
+    q[k] = wf2_t{WBFM_ATAN_C5, WBFM_ATAN_C5};
   }
-  constexpr float cf[7] = {-0x1.efda1p-7f, 0x1.50dd96p-5f, -0x1.2dbcfap-4f, 0x1.b11b74p-4f, -0x1.228754p-3f, 0x1.99673ep-3f, -0x1.55546cp-2f};
+  constexpr float cf[5] = {WBFM_ATAN_C4, WBFM_ATAN_C3, WBFM_ATAN_C2, WBFM_ATAN_C1, WBFM_ATAN_C0};
 #pragma unroll
-  for (int c = 0; c < 7; ++c)
+  for (int c = 0; c < 5; ++c)
 #pragma unroll
     for (int k = 0; k < 8; ++k) q[k] = __builtin_elementwise_fma(q[k], s[k], wf2_t{cf[c], cf[c]});
 #pragma unroll
@@ -561,8 +589,7 @@ __device__ __forceinline__ void wdisc_bands8(const wf2_t (&yr)[8], const wf2_t (
     if (ay[k].y > ax[k].y) a1 = 0x1.921fb6p+0f - a1;
     if (re[k].x < 0.0f) a0 = 0x1.921fb6p+1f - a0;
     if (re[k].y < 0.0f) a1 = 0x1.921fb6p+1f - a1;
-    a0 = __builtin_copysignf(a0, im[k].x); a1 = __builtin_copysignf(a1, im[k].y);
-    d[k] = wf2_t{(re[k].x == 0.0f && im[k].x == 0.0f) ? 0.0f : a0, (re[k].y == 0.0f && im[k].y == 0.0f) ? 0.0f : a1};
+    d[k] = wf2_t{__builtin_copysignf(a0, im[k].x), __builtin_copysignf(a1, im[k].y)};
   }
 }
 
