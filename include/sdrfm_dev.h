@@ -7,6 +7,8 @@
  *     sdrfm_host_atan2f, sdrfm_host_discriminate   HOST evaluation of the device's K3 arithmetic (same source, same rounding)
  *     sdrfm_debug_discriminate                     K3 evaluated ON THE DEVICE for n operand sets, both code forms
  *     sdrfm_q_build                                design Q: the channel taps as i8 matrix-pipe operand tables (csrc/qtaps.c)
+ *     sdrfm_q_guard                                design Q: the conditioning guard's thresholds for a tap set (csrc/qtaps.c; no GPU)
+ *     sdrfm_debug_q_guard                          design Q: a handle's guard thresholds and how often its repair path ran
  *   exported by the development library libsdrfm_dev.so only (built with -DSDRFM_DEV):
  *     sdrfm_debug_phase_cycles, sdrfm_debug_raw    instrumented kernels' counters (SDRFM_PHASE_PROFILE=1 at create)
  *     sdrfm_dev_read_debug                         per-wave time stamps of design S (SDRFM_STREAM_PROFILE=1)
@@ -33,6 +35,15 @@ int sdrfm_debug_discriminate(int device, const float* yr, const float* yi, const
 /* Design Q (csrc/qtaps.c): h[0..T) -> A[D/2][3][64][16] (K-chunk, digit, lane, byte) i8 operand tables, the fp32 scale q with
  * y = q (S0 + 256 S1 + 65536 S2) + cst, cst = 0.5 sum(h), and the first K-chunk holding a non-zero tap.  0 on success. */
 int sdrfm_q_build(const float* h, uint32_t T, uint32_t D, int8_t* A, float* q, float* cst, uint32_t* first_chunk);
+
+/* Design Q (csrc/qtaps.c): the conditioning guard's thresholds for channel taps h[0..T) and audio taps g[0..Ta).  0 on success. */
+int sdrfm_q_guard(const float* h, uint32_t T, const float* g, uint32_t Ta, float* guard_r, float* guard_a);
+
+/* Design Q's conditioning guard on this handle (csrc/sdrfm_q.hip): a lane is repaired — its two discriminator outputs recomputed with the
+ * definition's own fmaf chain — when one of its y's has max(|re|, |im|) < *guard_r or one of its |d|'s exceeds *guard_a; *lanes / *passes =
+ * lanes repaired / repair passes run since create (32-bit counters on the device).  Synchronises the handle.  SDRFM_NOT_SUPPORTED when the
+ * handle has no matrix-pipe kernel (SDRFM_CFG_BIT_EXACT, other geometries). */
+int sdrfm_debug_q_guard(sdrfm_t* h, float* guard_r, float* guard_a, unsigned long long* lanes, unsigned long long* passes);
 
 /* Development library only: cumulative shader cycles per phase of the instrumented design-B kernel summed over waves (out[0..4] =
  * stage, FIR, discriminator, audio, carry; out[5] = sub-tiles; out[6] = waves), reset on read; raw dump of its 560 debug words;

@@ -75,3 +75,24 @@ int sdrfm_q_build(const float* h, uint32_t T, uint32_t D, int8_t* A, float* q_ou
   *first_chunk = c0;
   return 0;
 }
+
+/* The conditioning guard's thresholds (kernel: sdrfm_q.hip; derivation: DESIGN.md 4.Q "guard").
+ * Design Q's y and the definition's fmaf chain differ by the chain's own rounding — T roundings at partial sums of up to P = 127.5 sum|h| —
+ * plus the 24-bit taps: |dy| <= E = 1.25 sqrt(T) P 2^-24 (9.5e-5 for the BASELINE 64 taps: 28 standard deviations of what uniform random
+ * bytes produce, 9 of a full-scale carrier's; the chain's worst case T P 2^-24 would need every rounding to fall the same way).  A
+ * discriminator output then moves by at most E / |y| + E / |p| and the audio by max|g| times that.  Outputs with a y below
+ * R = 2 max|g| E / 5e-6 are recomputed by the definition's own chain (ONE ill-conditioned pair may use half of the 1e-5 tolerance; everything
+ * else together is measured below 1e-6), and so are d's within 2 * 5e-6 / max|g| of +-pi, where an unrepaired pair could still land on the
+ * other side of the branch cut.  Returns 0, or -1 for taps the guard cannot serve (all-zero audio taps are served: nothing to guard). */
+int sdrfm_q_guard(const float* h, uint32_t T, const float* g, uint32_t Ta, float* guard_r, float* guard_a) {
+  if (!h || !g || !guard_r || !guard_a || T < 1 || Ta < 1) return -1;
+  double habs = 0.0, gmax = 0.0;
+  for (uint32_t k = 0; k < T; ++k) habs += fabs((double)h[k]);
+  for (uint32_t k = 0; k < Ta; ++k) if (fabs((double)g[k]) > gmax) gmax = fabs((double)g[k]);
+  if (!isfinite(habs) || !isfinite(gmax)) return -1;
+  if (gmax == 0.0) { *guard_r = 0.0f; *guard_a = 4.0f; return 0; }
+  const double E = 1.25 * sqrt((double)T) * 127.5 * habs * ldexp(1.0, -24);
+  *guard_r = (float)(2.0 * gmax * E / 5e-6);
+  *guard_a = (float)(3.14159265358979323846 - 2.0 * 5e-6 / gmax);
+  return 0;
+}

@@ -1485,6 +1485,14 @@ struct sdrfm {
   float q_scale, q_cst;
   uint32_t q_c0, q_nslot, q_waves_per_cu;
   char fast_q_name[64];
+  // design Q's conditioning guard: thresholds, the zero-padded taps of the repair path's chain, the last 64 raw samples of
+  // every stream (kept like the other state sets), statistics; and what the current state set holds: y[-1] as the definition has it
+  // (reset, or a bit-exact kernel served the previous call) or design Q's own value; hist_q written by design Q or not
+  float q_guard_r, q_guard_a;
+  float* d_hpad;
+  uint8_t* d_hist_q[2];
+  unsigned int* d_qstat;
+  bool yprev_exact, hist_q_valid;
   // SDRFM_F_OVERLAP: two internal streams taken in turn, so that consecutive calls run concurrently on the device (a call's ramp-up
   // under the previous call's tail).  ovl_in orders a call behind what the handle's stream holds when it is made; join_overlap()
   // records ovl_done[k] behind the calls put on internal stream k and makes the handle's stream wait for it.
@@ -1534,6 +1542,10 @@ static void free_handle(sdrfm* h) {
   if (h->d_audio) (void)hipFree(h->d_audio);
   if (h->d_dbg) (void)hipFree(h->d_dbg);
   if (h->d_qA) (void)hipFree(h->d_qA);
+  if (h->d_hpad) (void)hipFree(h->d_hpad);
+  if (h->d_qstat) (void)hipFree(h->d_qstat);
+  for (int i = 0; i < 2; ++i)
+    if (h->d_hist_q[i]) (void)hipFree(h->d_hist_q[i]);
   for (int k = 0; k < 2; ++k) {
     if (h->ovl_stream[k]) (void)hipStreamDestroy(h->ovl_stream[k]);
     if (h->ovl_done[k]) (void)hipEventDestroy(h->ovl_done[k]);
@@ -1692,27 +1704,39 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
       h->n_cu = (uint32_t)prop.multiProcessorCount;
       snprintf(h->fast_s_name, sizeof(h->fast_s_name), "fast-s T%u D%u S%u L%u Ta%u Da%u", v.T, v.D, v.R, v.seg, v.Ta, v.Da);
     }
-    // design Q: K2 on the i8 matrix pipe (sdrfm_q.hip).  Not bit-identical to the fmaf-chain kernels (within 7e-7 of the
-    // oracle, tolerance 1e-5), so a handle created with SDRFM_CFG_BIT_EXACT never selects it.
-    // It serves LOW-PASS channel filters only: sum|h| <= 2 |sum h| (a windowed sinc has 1.2 - 1.5).  For such taps the oracle's fp32 chain is itself within 1e-6
-    // of exact arithmetic and design Q, which is closer to exact still, lands within 1e-6 of the oracle on every input class; for tap
-    // sets with heavy cancellation (no pass band around DC: tools/fuzz_q.py feeds random ones) |y| is small against the chain's
-    // partial sums, the oracle's own rounding reaches 1e-5 in the discriminator, and only the bit-exact kernels can follow it there.
+    // design Q: K2 on the i8 matrix pipe (sdrfm_q.hip).  Not bit-identical to the fmaf-chain kernels (within 1e-6 of the
+    // oracle where the phase is well conditioned, repaired to the definition's own d where it is not: the guard below), so a handle
+    // created with SDRFM_CFG_BIT_EXACT never selects it.
+    // PERFORMANCE heuristic, not a correctness condition: it is offered LOW-PASS channel filters only, sum|h| <= 2 |sum h| (a windowed sinc
+    // has 1.2 - 1.5) — with heavy cancellation (no pass band around DC) |y| is small against the chain's partial sums for every input,
+    // the guard sends most outputs to the repair path and the bit-exact kernels are the faster way to the same numbers.
     double q_abs = 0.0, q_sum = 0.0;
     for (uint32_t k = 0; k < cfg->fir_taps; ++k) { q_abs += std::fabs((double)hc[k]); q_sum += (double)hc[k]; }
+    // The conditioning guard's thresholds (qtaps.c: sdrfm_q_guard).  A guard that would send a carrier at an eighth of full scale to the
+    // repair path makes design Q pointless for these taps: the bit-exact kernels serve them.
+    float q_R = 0.0f, q_A = 4.0f;
+    const bool q_guard_ok = sdrfm_q_guard(hc, cfg->fir_taps, gc, cfg->audio_taps, &q_R, &q_A) == 0 &&
+                            (double)q_R <= 0.125 * 127.5 * std::fabs(q_sum) && q_A > 3.0f;
     if (!(cfg->flags & SDRFM_CFG_BIT_EXACT) && cfg->fir_decim == SDRFM_Q_D && cfg->audio_taps == SDRFM_Q_TA &&
-        cfg->audio_decim == SDRFM_Q_DA && cfg->fir_taps <= 9 * SDRFM_Q_D && q_abs <= 2.0 * std::fabs(q_sum)) {
+        cfg->audio_decim == SDRFM_Q_DA && cfg->fir_taps <= SDRFM_Q_TP && q_abs <= 2.0 * std::fabs(q_sum) && q_guard_ok) {
       int8_t* tab = (int8_t*)malloc(SDRFM_Q_SPARSE_CHUNKS(SDRFM_Q_D) * SDRFM_Q_DIGITS * 64 * 16);
-      float qs = 0.f, qc = 0.f;
+      float qs = 0.f, qc = 0.f, hpad[SDRFM_Q_TP];
       uint32_t c0 = 0;
+      for (uint32_t k = 0; k < SDRFM_Q_TP; ++k) hpad[k] = k < cfg->fir_taps ? hc[k] : 0.0f;
       if (tab && sdrfm_q_build(hc, cfg->fir_taps, cfg->fir_decim, tab, &qs, &qc, &c0) == 0 &&
           hipMalloc(&h->d_qA, SDRFM_Q_SPARSE_CHUNKS(SDRFM_Q_D) * SDRFM_Q_DIGITS * 64 * 16) == hipSuccess &&
-          hipMemcpy(h->d_qA, tab, SDRFM_Q_SPARSE_CHUNKS(SDRFM_Q_D) * SDRFM_Q_DIGITS * 64 * 16, hipMemcpyHostToDevice) == hipSuccess) {
+          hipMemcpy(h->d_qA, tab, SDRFM_Q_SPARSE_CHUNKS(SDRFM_Q_D) * SDRFM_Q_DIGITS * 64 * 16, hipMemcpyHostToDevice) == hipSuccess &&
+          hipMalloc(&h->d_hpad, sizeof(hpad)) == hipSuccess && hipMemcpy(h->d_hpad, hpad, sizeof(hpad), hipMemcpyHostToDevice) == hipSuccess &&
+          hipMalloc(&h->d_hist_q[0], 2 * SDRFM_Q_TP * ns) == hipSuccess && hipMalloc(&h->d_hist_q[1], 2 * SDRFM_Q_TP * ns) == hipSuccess &&
+          hipMalloc(&h->d_qstat, 2 * sizeof(unsigned int)) == hipSuccess && hipMemset(h->d_qstat, 0, 2 * sizeof(unsigned int)) == hipSuccess) {
         h->q_scale = qs; h->q_cst = qc; h->q_c0 = c0 > 1 ? 1 : c0;
+        h->q_guard_r = q_R; h->q_guard_a = q_A;
         h->q_nslot = 5; h->q_waves_per_cu = 12;
 #ifdef SDRFM_DEV
         if (const char* e = getenv("SDRFM_Q_NSLOT")) h->q_nslot = (uint32_t)atoi(e);
         if (const char* e = getenv("SDRFM_Q_WAVES_PER_CU")) h->q_waves_per_cu = (uint32_t)atoi(e);
+        if (const char* e = getenv("SDRFM_Q_GUARD_R")) h->q_guard_r = (float)atof(e);            // 0 and 4: the guard never fires (timing / soak experiments)
+        if (const char* e = getenv("SDRFM_Q_GUARD_A")) h->q_guard_a = (float)atof(e);
         if (getenv("SDRFM_NO_Q")) { (void)hipFree(h->d_qA); h->d_qA = nullptr; }
 #endif
         h->n_cu = (uint32_t)prop.multiProcessorCount;
@@ -1792,7 +1816,10 @@ int sdrfm_reset(sdrfm_t* h) {
     HIP_TRY(hipMemsetAsync(h->d_yprev[i], 0, sizeof(float2) * ns, h->stream), SDRFM_FAIL);
     HIP_TRY(hipMemsetAsync(h->d_hist_d[i], 0, sizeof(float) * ns * hd, h->stream), SDRFM_FAIL);
     HIP_TRY(hipMemsetAsync(h->d_hist_b[i], 0, 2 * ns * hx, h->stream), SDRFM_FAIL);
+    if (h->d_hist_q[i]) HIP_TRY(hipMemsetAsync(h->d_hist_q[i], 0, 2 * SDRFM_Q_TP * ns, h->stream), SDRFM_FAIL);
   }
+  h->yprev_exact = true;                                          // y[-1] = 0, as the definition has it
+  h->hist_q_valid = false;
   HIP_TRY(hipStreamSynchronize(h->stream), SDRFM_FAIL);
   h->cur = 0;
   h->phase_x = h->phase_d = 0;
@@ -1919,6 +1946,13 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
                    h->prev_nbytes >= 2u * 10u * SDRFM_Q_STEP_OUT && (h->prev_nbytes % 16 == 0) && ((uintptr_t)h->prev_iq % 16 == 0) &&
                    (h->prev_stride % 16 == 0);
   if (!ovl) { const int jrc = join_overlap(h); if (jrc != SDRFM_OK) return jrc; }
+  if (!q_ok) {
+    // A bit-exact kernel takes over from design Q: the y[-1] it is handed must be the definition's (design Q's own is within 1e-4 of it,
+    // which a small |y| would turn into a wrong d[0]): recomputed from the 64 raw samples design Q left.
+    if (!h->yprev_exact && h->hist_q_valid)
+      HIP_TRY(sdrfm_q_fix_yprev(h->d_hist_q[h->cur], h->d_hpad, h->d_yprev[h->cur], c.n_streams, h->stream), SDRFM_FAIL);
+    h->yprev_exact = true; h->hist_q_valid = false;
+  }
   if (q_ok) {
     SdrfmQParams q;
     hipStream_t qs = h->stream;
@@ -1953,6 +1987,13 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
     q.hist_b_in = p.hist_b_in; q.hist_b_out = p.hist_b_out; q.hist_x_out = p.hist_x_out;
     q.A = h->d_qA; q.g = h->d_g; q.q0 = h->q_scale; q.q2 = 65536.0f * h->q_scale; q.cst = h->q_cst;
     q.T = c.fir_taps; q.N = N; q.M = M; q.A_out = A; q.steps_total = q_steps; q.n_streams = c.n_streams; q.dbg = nullptr; q.prio_by_age = ovl ? 0u : 1u;
+    // the guard's repair path reads the last 64 raw samples before the call: left by the previous design-Q call, or taken now from the
+    // T - 1 the other kernels keep (the 64th, which only y[-1] needs, is then not there — nor needed: their y[-1] is the definition's)
+    if (!h->hist_q_valid && !ovl && c.fir_taps > 1)
+      HIP_TRY(hipMemcpy2DAsync(h->d_hist_q[h->cur] + 2 * (SDRFM_Q_TP - (c.fir_taps - 1)), 2 * SDRFM_Q_TP, p.hist_b_in, 2 * (size_t)(c.fir_taps - 1),
+                               2 * (size_t)(c.fir_taps - 1), c.n_streams, hipMemcpyDeviceToDevice, h->stream), SDRFM_FAIL);
+    q.hpad = h->d_hpad; q.hist_q_in = h->d_hist_q[h->cur]; q.hist_q_out = h->d_hist_q[h->cur ^ 1];
+    q.guard_r = h->q_guard_r; q.guard_a = h->q_guard_a; q.yprev_exact = h->yprev_exact ? 1u : 0u; q.n_repaired = h->d_qstat;
     // runs (waves) per stream: fill the machine once; every run at least four owned steps (a run that does not start its stream
     // recomputes one step), two when the call is too small to fill the machine otherwise
     uint32_t runs = (h->q_waves_per_cu * h->n_cu) / c.n_streams;
@@ -1962,6 +2003,7 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
     q.runs = runs;
     HIP_TRY(sdrfm_q_launch(q, h->q_c0, h->q_nslot, qs), SDRFM_FAIL);
     if (ovl) h->ovl_pending[k] = true;
+    h->yprev_exact = false; h->hist_q_valid = true;
     snprintf(h->kernel_name, sizeof(h->kernel_name), "%s%s", h->fast_q_name, ovl ? " overlapped" : "");
   } else if (stream_ok) {
     const uint32_t segs = N / h->fast_s->seg;
@@ -2240,6 +2282,23 @@ int sdrfm_debug_discriminate(int device, const float* yr, const float* yi, const
   if (hipMemcpy(out_pair, d + 5 * (size_t)n, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = SDRFM_FAIL;
   (void)hipFree(d);
   return rc;
+}
+
+/* Test hook: design Q's conditioning guard on this handle — its two thresholds and how many lanes (pairs of discriminator outputs) the
+ * repair path has recomputed, in how many passes, since create.  SDRFM_NOT_SUPPORTED when the handle has no matrix-pipe kernel. */
+int sdrfm_debug_q_guard(sdrfm_t* h, float* guard_r, float* guard_a, unsigned long long* lanes, unsigned long long* passes) {
+  if (!h) return SDRFM_EINVAL;
+  if (!h->d_qA) return SDRFM_NOT_SUPPORTED;
+  HIP_TRY(hipSetDevice(h->device), SDRFM_FAIL);
+  { const int jrc = join_overlap(h); if (jrc != SDRFM_OK) return jrc; }
+  HIP_TRY(hipStreamSynchronize(h->stream), SDRFM_FAIL);
+  unsigned int st[2] = {0, 0};
+  HIP_TRY(hipMemcpy(st, h->d_qstat, sizeof(st), hipMemcpyDeviceToHost), SDRFM_FAIL);
+  if (guard_r) *guard_r = h->q_guard_r;
+  if (guard_a) *guard_a = h->q_guard_a;
+  if (lanes) *lanes = st[0];
+  if (passes) *passes = st[1];
+  return SDRFM_OK;
 }
 
 #ifdef SDRFM_DEV

@@ -34,6 +34,15 @@ struct SdrfmQParams {
   uint32_t runs;                // runs (waves) per stream
   uint32_t n_streams;
   uint32_t prio_by_age;         // 1: from the middle of its run a wave's issue priority is its age rank in the SIMD (calls one after the other)
+  // ---- the conditioning guard and its repair path (DESIGN.md 4.Q "guard"): where the phase of y[m] conj(y[m-1]) is ill-conditioned the d's are
+  // recomputed with the definition's own fmaf chain from the raw bytes, so that they equal the bit-exact kernels' d's exactly
+  const float* hpad;            // [SDRFM_Q_TP] channel taps h[k], zero for k >= T
+  const uint8_t* hist_q_in;     // [n_streams][2 SDRFM_Q_TP] raw I/Q bytes of the last SDRFM_Q_TP samples before the call (16-byte aligned rows)
+  uint8_t* hist_q_out;
+  float guard_r;                // a lane is repaired when max(|re|, |im|) of one of its three y's is below this ...
+  float guard_a;                // ... or one of its two |d|'s is above this (the branch cut); guard_r = 0 and guard_a = 4 switch the guard off
+  uint32_t yprev_exact;         // yprev_in holds the definition's y[-1] (reset, or the previous call ran on a bit-exact kernel): hist_q_in[0] is not valid then
+  unsigned int* n_repaired;     // statistics (device, two words: repaired lanes, repair passes) or nullptr
   unsigned long long* dbg;      // development build: per-wave time stamps (else nullptr)
 };
 
@@ -42,6 +51,7 @@ struct SdrfmQParams {
 #define SDRFM_Q_TA 32u           /* audio taps */
 #define SDRFM_Q_DA 5u            /* audio decimation */
 #define SDRFM_Q_STEP_OUT 128u    /* decimated outputs per wave step (16 columns x 8 outputs) */
+#define SDRFM_Q_TP 64u           /* the repair path's chain length: channel taps padded with zeros to this many (design Q serves T <= 64) */
 
 // LDS bytes of one wave for a ring of `nslot` KiB (nslot = 5, 10 or 15)
 uint32_t sdrfm_q_lds_bytes(uint32_t nslot);
@@ -50,6 +60,8 @@ int sdrfm_q_blocks_per_cu(uint32_t first_chunk, uint32_t nslot);
 // Enqueue one call: grid = n_streams * runs one-wave workgroups.  first_chunk = 0 or 1 (from sdrfm_q_build).
 // Returns hipSuccess or the launch error.
 hipError_t sdrfm_q_launch(const SdrfmQParams& p, uint32_t first_chunk, uint32_t nslot, hipStream_t stream);
+// yprev[s] = the definition's y[-1] of stream s from the SDRFM_Q_TP raw samples in hist_q (a bit-exact kernel takes over from design Q)
+hipError_t sdrfm_q_fix_yprev(const uint8_t* hist_q, const float* hpad, float2* yprev, uint32_t n_streams, hipStream_t stream);
 // One-time per-process kernel attribute set-up (dynamic LDS above 64 KiB is never needed; kept for symmetry): returns 0.
 const char* sdrfm_q_kernel_symbol(uint32_t first_chunk, uint32_t nslot);
 

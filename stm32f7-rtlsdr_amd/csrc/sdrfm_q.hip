@@ -59,6 +59,10 @@ constexpr int DB0 = 128;                        // d buffer: word DB0 + sigma = 
 constexpr int DBW = DB0 + 656;                  // words
 constexpr int ABS = 4;                          // audio stages (128 outputs each) parked in LDS before they are stored
 constexpr int ABW = 128 * ABS;                  // words, after the d buffer
+constexpr int FLW = 64;                         // words, after the parked audio: up to 128 two-byte entries of lanes waiting for the repair path
+constexpr int QTP = (int)SDRFM_Q_TP;            // the repair path's chain length (taps padded with zeros)
+constexpr int RWIN = QTP + 2 * QD;              // samples under the three outputs y[m0 - 1], y[m0], y[m0 + 1] a repaired lane recomputes
+static_assert(QTP % 4 == 0 && (2 * QD) % 4 == 0, "the repair path loads whole groups of four samples, none of which straddles the call's first sample");
 #ifndef SDRFM_Q_AUX
 #define SDRFM_Q_AUX 2   // cache policy of the ring's fetches: 2 = nt (streamed once; measured 0.4-1 us per launch better than the default policy)
 #endif
@@ -101,12 +105,13 @@ __device__ __forceinline__ void wait_vmcnt() {
 #endif
 
 template <int C0, int NSLOT>
-__global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_mfir(SdrfmQParams p) {
   constexpr int RINGB = NSLOT * 1024;
   static_assert(RINGB % (2 * STEPB) == 0 && NSLOT >= 5 && NSLOT - 4 < 16, "ring: whole pairs of steps");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* const db = reinterpret_cast<float*>(smem + PRE + RINGB);
   float* const ab = db + DBW;                                   // parked audio outputs
+  unsigned short* const fl16 = reinterpret_cast<unsigned short*>(ab + ABW);   // lanes waiting for the repair path: (step slot + 1) << 6 | lane
   const int lane = (int)threadIdx.x, n = lane & 15, g = lane >> 4;
   const uint32_t stream = blockIdx.x / p.runs, run = blockIdx.x - stream * p.runs;
   // (with iq_prev the stream's first run warms up like every other run: the cuts are made over steps_total + 1 steps and moved down by
@@ -209,6 +214,7 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
     if (lane + 64 < HT) *reinterpret_cast<unsigned short*>(smem + PRE - 2 * HT + 2 * (lane + 64)) = hb1;
     if (lane < QTA - 1) db[DB0 + sigma - (QTA - 1) + lane] = hd0;
   }
+  __builtin_amdgcn_wave_barrier();                              // (one wave per workgroup: lanes exchange data through LDS in program order; this only pins that order for the compiler)
   int slot = 0;                                                 // ring slot of the next chunk
   int ringoff = 0;                                              // ring byte offset of the current step
   int osm = warm ? -1 : 0;                                      // owned steps in the d buffer since the last audio stage
@@ -242,6 +248,7 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
         const qi4_t hcp = *reinterpret_cast<const qi4_t*>(smem + PRE + RINGB - BLKB + 16 * lane);
         *reinterpret_cast<qi4_t*>(smem + 16 * lane) = hcp;
       }
+      __builtin_amdgcn_wave_barrier();
     }
     ringoff = (ringoff + STEPB == RINGB) ? 0 : ringoff + STEPB;
   };
@@ -263,6 +270,7 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
   // after the run's last step (every ABS stages in a long run), whole 8-byte pairs when the row allows.
   int npend = 0, jfl = j0;                                      // parked stages; first parked output
   auto flush_audio = [&]() {
+    __builtin_amdgcn_wave_barrier();
 #if defined(SDRFM_Q_ABLATE) && (SDRFM_Q_ABLATE & 256)   // every wave stores to the same 2 KiB (same instructions, no write traffic to speak of)
     float* out = p.audio;
 #else
@@ -285,12 +293,122 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
     jfl += 128 * npend;
     npend = 0;
   };
+  // ---- the repair path (rare: see the guard in the loop).  Every listed lane (one per lane of the wave, 64 at a time) recomputes the three
+  // outputs under its two d's — y[m0 - 1], y[m0], y[m0 + 1], m0 = the lane's first output of that step — with the definition's chain:
+  // acc = fmaf(h[k], x, acc), oldest sample first, x = byte - 127.5, from the raw bytes in global memory (the ring's slots have been
+  // refilled by now): RWIN = 84 consecutive samples, 21 aligned 8-byte loads.  Samples before the call come from the previous call's
+  // buffer (SDRFM_F_OVERLAP) or from the 64 raw samples the previous design-Q call left in hist_q.  The taps are wave-uniform: lane k holds
+  // h[k] (zero for k >= T: fmaf(0, x, acc) = acc bit for bit, acc is never -0) and v_readlane hands them out.  Then the definition's own
+  // discriminator (sdrfm_math.h) — the d's are the bit-exact kernels' d's, a fixed function of the bytes like everything else here.
+  int nflag = 0;
+  auto repair_flagged = [&]() {
+    // Everything this path needs is derived here, from opaque copies of the lane and stream numbers, so that none of it is hoisted into
+    // the step loop (whose scalar registers are all taken); and the wave constants are loaded again at the end (L2) instead of being kept
+    // across it: their 36 VGPRs and 32 SGPRs are what the chains run in.
+    int ln = lane;
+    uint32_t st = stream;
+    typedef const __attribute__((address_space(4))) SdrfmQParams* KargPtr;
+    KargPtr pp = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();                                            // (read again from the kernel arguments:
+    asm volatile("" : "+v"(ln), "+s"(st), "+s"(pp));                                                            //  not kept in registers across the loop)
+    const unsigned char* const row = pp->iq + (size_t)st * pp->iq_stride;
+    const unsigned char* const pre = from_prev ? pp->iq_prev + (size_t)st * pp->iq_prev_stride + 2 * (size_t)pp->N_prev
+                                               : pp->hist_q_in + (size_t)(2 * QTP) * ((size_t)st + 1);
+    // tap vectors: lane j of tA[o] holds the tap that meets window sample j in output m0 - 1 + o (tap QTP - 1 + QD o - j, or none),
+    // lane j of tB[o] the one for sample QTP + j
+    int tA[3], tB[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      const int kA = QTP - 1 + QD * o - ln, kB = kA - QTP;
+      const float vA = pp->hpad[kA < 0 ? 0 : (kA > QTP - 1 ? QTP - 1 : kA)], vB = pp->hpad[kB < 0 ? 0 : kB];
+      tA[o] = __builtin_bit_cast(int, (kA >= 0 && kA < QTP) ? vA : 0.0f);
+      tB[o] = __builtin_bit_cast(int, kB >= 0 ? vB : 0.0f);
+    }
+    __builtin_amdgcn_wave_barrier();                            // (the list was written by other lanes)
+    unsigned nrep = 0;
+    for (int e0 = 0; e0 < nflag; e0 += 64) {
+      const int e = e0 + ln;
+      int l = 0, slot = 0, m0 = (int)pp->M;
+      if (e < nflag) {
+        const unsigned ent = fl16[e];
+        l = (int)(ent & 63u);
+        slot = (int)(ent >> 6) - 1;
+        m0 = mbase + 128 * slot + 8 * (l & 15) + 2 * (l >> 4);
+      }
+      const bool act = m0 < (int)pp->M;                           // (not the lanes beyond the call's last output in a partly filled last step)
+      nrep += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act));
+      if (act) {
+        const int n0 = QD * m0 - QTP;                           // first sample under y[m0 - 1]; a multiple of 4
+        uint2 w[RWIN / 4];
+#pragma unroll
+        for (int c = 0; c < RWIN / 4; ++c) {
+          const int n = n0 + 4 * c;
+          w[c] = *reinterpret_cast<const uint2*>((n >= 0 ? row : pre) + 2 * (ptrdiff_t)n);
+        }
+        float a[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        auto sample = [&](int ii, float& xr, float& xi) {      // sample ii of the 16 at the front of w
+          const unsigned wd = (ii & 2) ? w[ii >> 2].y : w[ii >> 2].x;
+          xr = (float)((wd >> ((ii & 1) ? 16 : 0)) & 0xffu) - 127.5f;   // (v_cvt_f32_ubyteN: exact)
+          xi = (float)((wd >> ((ii & 1) ? 24 : 8)) & 0xffu) - 127.5f;
+        };
+        // samples 0 .. QTP - 1: four rounds of 16, the window slides down by 16 samples after each (a rolled loop: code size, registers)
+#pragma unroll 1
+        for (int g = 0; g < QTP / 16; ++g) {
+#pragma unroll
+          for (int ii = 0; ii < 16; ++ii) {
+            float xr, xi;
+            sample(ii, xr, xi);
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+              const float t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(tA[o], 16 * g + ii));
+              a[2 * o] = __builtin_fmaf(t, xr, a[2 * o]);
+              a[2 * o + 1] = __builtin_fmaf(t, xi, a[2 * o + 1]);
+            }
+          }
+#pragma unroll
+          for (int c = 0; c + 4 < RWIN / 4; ++c) w[c] = w[c + 4];
+        }
+        // samples QTP .. QTP + 2 QD - 1 (under y[m0] and y[m0 + 1] only)
+#pragma unroll
+        for (int ii = 0; ii < 2 * QD; ++ii) {
+          float xr, xi;
+          sample(ii, xr, xi);
+#pragma unroll
+          for (int o = 1; o < 3; ++o) {
+            if (QD * o - 1 - ii < 0) continue;                  // (no tap of this output meets the sample)
+            const float t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(tB[o], ii));
+            a[2 * o] = __builtin_fmaf(t, xr, a[2 * o]);
+            a[2 * o + 1] = __builtin_fmaf(t, xi, a[2 * o + 1]);
+          }
+        }
+        if (m0 == 0 && !warm && pp->yprev_exact) {                // the call's first output after a reset or a bit-exact kernel: y[-1] is the carried one
+          const float2 yp = pp->yprev_in[st];
+          a[0] = yp.x; a[1] = yp.y;
+        }
+        float* dst = db + DB0 + sigma + 128 * slot + 8 * (l & 15) + 2 * (l >> 4);
+        dst[0] = sdrfm_discriminate(a[2], a[3], a[0], a[1]);
+        dst[1] = sdrfm_discriminate(a[4], a[5], a[2], a[3]);
+      }
+    }
+    if (pp->n_repaired && ln == 0) { atomicAdd(pp->n_repaired, nrep); atomicAdd(pp->n_repaired + 1, 1u); }
+    nflag = 0;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = C0; c < NSC; ++c)
+#pragma unroll
+      for (int t = 0; t < SDRFM_Q_DIGITS; ++t)
+        At[c - C0][t] = *reinterpret_cast<const qi4_t*>(pp->A + ((size_t)((c * SDRFM_Q_DIGITS + t) * 64 + ln)) * 16);
+#pragma unroll
+    for (int k = 0; k < QTA; ++k)
+      gr[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pp->g[QTA - 1 - k])));
+  };
   // Issue priority by age, from the middle of the run on.  The arbiter serves the oldest wave of a SIMD first and the memory pipeline's
   // queues do the same, so the first / second / third wave of a SIMD end 20.0 / 21.8 / 23.6 us after the launch (configs[2], §4.Q of
   // DESIGN.md) and the kernel waits for the last one.  From its middle step on a wave runs at priority = its age rank (HW_ID.wave_id:
   // 0 = oldest), which closes the gap: 26.5 -> 25.7 us per call.  (For the whole run it over-corrects: the oldest waves end last.)
   // Not for overlapped calls — two kernels share the SIMDs there and the ranks mean something else: measured +0.3 us.  Priorities by
   // remaining steps (a wave that is behind outranks one that is ahead), alone or on top of the rank: no better (25.9 - 26.4 us).
+  float guard_r = p.guard_r, guard_a = p.guard_a;             // (in VGPRs: the loop's scalar registers are all taken)
+  asm volatile("" : "+v"(guard_r), "+v"(guard_a));
   const int wrank = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 4) & 15u);
   const int prio_at = p.prio_by_age ? nsteps / 2 : -1;
   for (int kk = 0; kk < nsteps; ++kk) {
@@ -360,10 +478,45 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
       dst[1] = d1;
     }
     if (last_run && ks + kk == ylast_step && lane == ylast_lane) p.yprev_out[stream] = make_float2(y[2], y[3]);
+#if !(defined(SDRFM_Q_ABLATE) && (SDRFM_Q_ABLATE & 512))
+    // ---- the conditioning guard: design Q's y is within E ~ 1e-4 (absolute) of the definition's fmaf chain, so its d is within
+    // E / |y| + E / |p| of the definition's — fine while both magnitudes are large, not at a deep fade, and near d = +-pi the two may land
+    // on different sides of the branch cut.  A lane one of whose three y's is small (max norm below guard_r) or one of whose d's is
+    // within reach of the cut (above guard_a) is put on a list; its two d's are recomputed by the definition's own chain before anything
+    // reads them (repair_flagged).  An FM carrier never gets here; noise-only input does, a few lanes per step.
+    {
+      float t0, t1, t2;
+      unsigned long long fm, fm2;
+      asm("v_max_f32_e64 %[t0], |%[y0]|, |%[y1]|\n\t"
+          "v_max_f32_e64 %[t1], |%[y2]|, |%[y3]|\n\t"
+          "v_max_f32_e64 %[t2], |%[pr]|, |%[pi]|\n\t"
+          "v_min3_f32 %[t0], %[t0], %[t1], %[t2]\n\t"
+          "v_max_f32_e64 %[t1], |%[d0]|, |%[d1]|\n\t"
+          "v_cmp_lt_f32_e64 %[fm], %[t0], %[gr]\n\t"
+          "v_cmp_gt_f32_e64 %[fm2], %[t1], %[ga]\n\t"
+          "s_or_b64 %[fm], %[fm], %[fm2]"
+          : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [fm] "=&s"(fm), [fm2] "=&s"(fm2)
+          : [y0] "v"(y[0]), [y1] "v"(y[1]), [y2] "v"(y[2]), [y3] "v"(y[3]), [pr] "v"(pr), [pi] "v"(pi), [d0] "v"(d0), [d1] "v"(d1),
+            [gr] "v"(guard_r), [ga] "v"(guard_a)
+          : "scc");
+      if (fm) {                                                                                // wave-uniform, rare
+        if (warm && kk == 0) fm &= 0xF000F000F000F000ull;       // a warm-up step: only blocks 12..15 were fetched and matter
+        if (fm) {
+          const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(fm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fm, 0u));
+          if ((fm >> lane) & 1ull) fl16[nflag + rank] = (unsigned short)(((osm + 1) << 6) | lane);
+          nflag += __builtin_popcountll(fm);
+        }
+      }
+    }
+#endif
+    ++osm;
+    // everything the list holds is repaired before the d's are read: at every audio stage, at the run's last step (the d history below), and
+    // whenever another step's worth of lanes might not fit
+    if (nflag > 0 && (osm == 5 || kk == nsteps - 1 || nflag > 64)) repair_flagged();
+    __builtin_amdgcn_wave_barrier();                            // (the d's are read by other lanes from here on)
     // the stream's last 31 d's, taken before the audio stage below may move the buffer on (the call's last step need not be full)
     if (last_run && kk == nsteps - 1 && lane < QTA - 1)
       p.hist_d_out[(size_t)stream * (QTA - 1) + lane] = db[DB0 + sigma + ((int)p.M - (QTA - 1) + lane - mbase)];
-    ++osm;
 #ifdef SDRFM_Q_PHASES
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
@@ -399,6 +552,7 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
           const float hv = db[DB0 + sigma + 640 - QTA + lane];
           db[DB0 + sigma - QTA + lane] = hv;
         }
+        __builtin_amdgcn_wave_barrier();
         osm = 0;
         mbase += 640;
       }
@@ -420,6 +574,9 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
       reinterpret_cast<unsigned short*>(p.hist_b_out)[(size_t)stream * HT + k] = (unsigned short)raw;
       p.hist_x_out[(size_t)stream * HT + k] = make_float2((float)(raw & 0xffu) - 127.5f, (float)(raw >> 8) - 127.5f);
     }
+    if (lane < 2 * QTP / 16)                                    // the last 64 raw samples, for the next call's repair path
+      *reinterpret_cast<qi4_t*>(p.hist_q_out + (size_t)(2 * QTP) * stream + 16 * lane) =
+          *reinterpret_cast<const qi4_t*>(row + 2 * (size_t)p.N - 2 * QTP + 16 * lane);
   }
 #ifdef SDRFM_Q_STAMPS
   if (tsp && lane == 0) {
@@ -431,6 +588,21 @@ __global__ void __launch_bounds__(64) k_mfir(SdrfmQParams p) {
     tsp[6] = (unsigned long long)nsteps; tsp[7] = __builtin_readcyclecounter() - c_entry;   // word 5: XCC_ID | HW_ID << 8
   }
 #endif
+}
+
+// y[-1] as the definition has it, from the 64 raw samples before the next call (hist_q) — for a bit-exact kernel that takes over from
+// design Q (whose own carried y[-1] is only within 1e-4 of it).  One lane per stream; the chain of sdrfm_math.h / DESIGN.md "Frozen spec".
+__global__ void __launch_bounds__(64) k_q_fix_yprev(const uint8_t* hist_q, const float* hpad, float2* yprev, uint32_t n_streams) {
+  const uint32_t s = blockIdx.x * 64 + threadIdx.x;
+  if (s >= n_streams) return;
+  const uint8_t* b = hist_q + (size_t)(2 * QTP) * s;
+  float ar = 0.0f, ai = 0.0f;
+  for (int i = 0; i < QTP; ++i) {                               // oldest sample first: sample -QTP + i meets tap QTP - 1 - i
+    const float t = hpad[QTP - 1 - i];
+    ar = __builtin_fmaf(t, (float)b[2 * i] - 127.5f, ar);
+    ai = __builtin_fmaf(t, (float)b[2 * i + 1] - 127.5f, ai);
+  }
+  yprev[s] = make_float2(ar, ai);
 }
 
 typedef void (*QKernel)(SdrfmQParams);
@@ -447,7 +619,7 @@ const QVariant* q_find(uint32_t c0, uint32_t nslot) {
 
 }  // namespace
 
-uint32_t sdrfm_q_lds_bytes(uint32_t nslot) { return (uint32_t)(PRE + 1024 * (int)nslot + 4 * (DBW + ABW)); }
+uint32_t sdrfm_q_lds_bytes(uint32_t nslot) { return (uint32_t)(PRE + 1024 * (int)nslot + 4 * (DBW + ABW + FLW)); }
 
 const char* sdrfm_q_kernel_symbol(uint32_t first_chunk, uint32_t nslot) {
   const QVariant* v = q_find(first_chunk, nslot);
@@ -459,6 +631,11 @@ int sdrfm_q_blocks_per_cu(uint32_t first_chunk, uint32_t nslot) {
   int nb = 0;
   if (!v || hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(v->k), 64, sdrfm_q_lds_bytes(nslot)) != hipSuccess) return 0;
   return nb;
+}
+
+hipError_t sdrfm_q_fix_yprev(const uint8_t* hist_q, const float* hpad, float2* yprev, uint32_t n_streams, hipStream_t stream) {
+  hipLaunchKernelGGL(k_q_fix_yprev, dim3((n_streams + 63) / 64), dim3(64), 0, stream, hist_q, hpad, yprev, n_streams);
+  return hipGetLastError();
 }
 
 hipError_t sdrfm_q_launch(const SdrfmQParams& p, uint32_t first_chunk, uint32_t nslot, hipStream_t stream) {

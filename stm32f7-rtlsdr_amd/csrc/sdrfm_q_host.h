@@ -23,6 +23,10 @@ extern "C" {
  * Returns 0, or -1 when the geometry / taps cannot be served (T > 9 D, D odd, non-finite or all-zero taps). */
 int sdrfm_q_build(const float* h, uint32_t T, uint32_t D, int8_t* A, float* q, float* cst, uint32_t* first_chunk);
 
+/* The conditioning guard's thresholds for channel taps h[0..T) and audio taps g[0..Ta) (see qtaps.c): a lane is repaired when one of its y's
+ * has max(|re|, |im|) < *guard_r or one of its |d|'s exceeds *guard_a.  Returns 0 or -1. */
+int sdrfm_q_guard(const float* h, uint32_t T, const float* g, uint32_t Ta, float* guard_r, float* guard_a);
+
 #ifdef __cplusplus
 }
 #endif

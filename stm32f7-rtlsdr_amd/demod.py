@@ -91,6 +91,16 @@ class FmDemod:
     def synchronize(self):
         self._ck(self._lib.sdrfm_synchronize(self._h), "sdrfm_synchronize")
 
+    def q_guard(self):
+        """sdrfm_debug_q_guard (include/sdrfm_dev.h): the matrix-pipe kernel's conditioning guard on this handle — dict with its two
+        thresholds and the lanes repaired / repair passes run since create; None when the handle has no matrix-pipe kernel."""
+        r, a, lanes, passes = C.c_float(), C.c_float(), C.c_uint64(), C.c_uint64()
+        st = self._lib.sdrfm_debug_q_guard(self._h, C.byref(r), C.byref(a), C.byref(lanes), C.byref(passes))
+        if st == 3:
+            return None
+        self._ck(st, "sdrfm_debug_q_guard")
+        return {"guard_r": r.value, "guard_a": a.value, "lanes": lanes.value, "passes": passes.value}
+
     def phase_cycles(self):
         """sdrfm_debug_phase_cycles: dict of cumulative shader cycles per kernel phase (profiling builds only)."""
         out = (C.c_uint64 * 8)()

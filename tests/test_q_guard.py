@@ -1,0 +1,75 @@
+"""CPU tests of design Q's conditioning guard (csrc/sdrfm_q.hip, thresholds: csrc/qtaps.c sdrfm_q_guard): the numpy emulation of the
+matrix-pipe arithmetic (tools/q_emulate.py) with and without the guard, against the oracle, on the two round-3 soak cases in which an
+unguarded design Q left the 1e-5 tolerance (tests/golden/q_guard_*.npz, make_golden_q_guard.py) and on the input classes of SURVEY.md 8d.
+The GPU twin of this file is tests/test_q_guard_gpu.py."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import TOL
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def guard_of(pkg, h, g):
+    lib = pkg.load_library()
+    r, a = C.c_float(), C.c_float()
+    h, g = np.ascontiguousarray(h, np.float32), np.ascontiguousarray(g, np.float32)
+    assert lib.sdrfm_q_guard(h.ctypes.data, h.size, g.ctypes.data, g.size, C.byref(r), C.byref(a)) == 0
+    return r.value, a.value
+
+
+def _emulate(z, guard):
+    import q_emulate as qe
+    sizes = [int(x) for x in z["sizes"]]
+    # (the emulation runs one stream from reset: the branch-cut case's second call stands alone behind its reset)
+    iq, ref = (z["iq"][2 * sizes[0]:], z["audio"][sizes[0] // 50:]) if len(z["reset_before"]) else (z["iq"], z["audio"])
+    stats = {}
+    got, want, _ = qe.design_q_audio(iq, z["h"], z["g"], guard=guard, stats=stats)
+    assert np.array_equal(ref, want.astype(np.float32)), "the fixture's expected audio is the oracle's"
+    e = np.abs(got.astype(np.float64) - want) / np.maximum(np.abs(want), 1.0)
+    return e, stats
+
+
+def test_guard_thresholds_of_the_baseline_taps(pkg):
+    for T, lo, hi in ((64, 4.0, 5.5), (32, 2.3, 3.2), (16, 1.9, 2.7)):
+        h, g = pkg.default_config(T)
+        r, a = guard_of(pkg, h, g)
+        assert lo < r < hi, (T, r)                         # a carrier at 4 % of full scale already clears it
+        assert 5e-5 < np.pi - a < 1.2e-4, (T, a)
+    # audio taps of zero: nothing to guard
+    assert guard_of(pkg, pkg.default_config(64)[0], np.zeros(32, np.float32)) == (0.0, 4.0)
+
+
+@pytest.mark.parametrize("name,n_bad,worst", [("q_guard_branch_cut_T64", 7, 0.7), ("q_guard_deep_fade_T32", 1, 1.1e-5)])
+def test_the_soak_cases_fail_without_the_guard_and_pass_with_it(pkg, name, n_bad, worst):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    e, _ = _emulate(z, None)
+    assert int((e > TOL).sum()) == n_bad and e.max() > worst     # what round 3's kernel did (profiles/r03b_fuzz_q.txt)
+    e, st = _emulate(z, guard_of(pkg, z["h"], z["g"]))
+    assert e.max() <= 1e-6, e.max()                               # repaired: two orders inside the tolerance again
+    assert 0 < st["repaired"] < st["pairs"] // 4
+
+
+@pytest.mark.parametrize("T", [16, 64])
+@pytest.mark.parametrize("mode", ["fm", "random", "const", "counter"])
+def test_guarded_emulation_on_every_input_class(pkg, T, mode):
+    import q_emulate as qe
+    h, g = pkg.default_config(T)
+    guard = guard_of(pkg, h, g)
+    iq = pkg.make_iq(2, 120000, mode=mode, first_id=31)
+    st = {}
+    for s in range(2):
+        got, want, _ = qe.design_q_audio(iq[s], h, g, guard=guard, stats=st)
+        e = np.abs(got.astype(np.float64) - want) / np.maximum(np.abs(want), 1.0)
+        assert e.max() <= 1e-6, (mode, s, e.max())
+    frac = st["repaired"] / st["pairs"]
+    if mode == "fm":
+        assert frac < 1e-3, frac                               # a carrier never meets the guard (but for the stream's first outputs)
+    if mode == "const":
+        assert frac == 1.0                                     # |y| = 0.5 |sum h| sqrt 2: everything goes the definition's way

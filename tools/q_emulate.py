@@ -50,9 +50,12 @@ def fma32(a, b, c):
     return f32(f32(a).astype(np.float64) * f32(b).astype(np.float64) + f32(c).astype(np.float64))
 
 
-def design_q_audio(iq, h, g, ndig=3, D=10, Da=5):
+def design_q_audio(iq, h, g, ndig=3, D=10, Da=5, guard=None, stats=None):
     """One stream from reset, zero history handled like the product does: the first outputs come from the exact spec (the
-    generic kernel patches them), so only steady-state arithmetic is judged here."""
+    generic kernel patches them), so only steady-state arithmetic is judged here.
+    guard = (guard_r, guard_a) emulates the kernel's conditioning guard (csrc/sdrfm_q.hip): outputs are held in pairs (2 i, 2 i + 1) by one
+    lane; a pair one of whose three y's (y[2 i - 1], y[2 i], y[2 i + 1]) has max(|re|, |im|) < guard_r, or one of whose |d|'s exceeds
+    guard_a, gets both d's from the definition's own y's (the oracle's).  stats (a dict) receives the number of repaired pairs."""
     T, Ta = len(h), len(g)
     b = iq.astype(np.int64)
     xi8 = np.stack([b[0::2] - 128, b[1::2] - 128], axis=1)          # [N, 2]
@@ -91,6 +94,23 @@ def design_q_audio(iq, h, g, ndig=3, D=10, Da=5):
     re = fma32(yr, pr, f32(yi * pi))
     im = f32(f32(yi * pr) - f32(yr * pi))
     d = np.where((re == 0) & (im == 0), np.float32(0), np.arctan2(im, re).astype(np.float32))
+    if guard is not None:
+        gr_, ga_ = np.float32(guard[0]), np.float32(guard[1])
+        linf = np.maximum(np.abs(y[:, 0]), np.abs(y[:, 1]))
+        linf_p = np.maximum(np.abs(prev[:, 0]), np.abs(prev[:, 1]))
+        Mp = (M // 2) * 2
+        small = np.minimum(np.minimum(linf_p[0:Mp:2], linf[0:Mp:2]), linf[1:Mp:2]) < gr_
+        cut = np.maximum(np.abs(d[0:Mp:2]), np.abs(d[1:Mp:2])) > ga_
+        flag = np.repeat(small | cut, 2)
+        yprev_o = np.vstack([np.zeros((1, 2), np.float32), yo[:-1]])
+        re_o = fma32(yo[:, 0], yprev_o[:, 0], f32(yo[:, 1] * yprev_o[:, 1]))
+        im_o = f32(f32(yo[:, 1] * yprev_o[:, 0]) - f32(yo[:, 0] * yprev_o[:, 1]))
+        d_o = np.where((re_o == 0) & (im_o == 0), np.float32(0), np.arctan2(im_o, re_o).astype(np.float32))
+        d[:Mp][flag] = d_o[:Mp][flag]
+        if stats is not None:
+            stats["pairs"] = stats.get("pairs", 0) + Mp // 2
+            stats["repaired"] = stats.get("repaired", 0) + int((small | cut).sum())
+            stats["branch_cut"] = stats.get("branch_cut", 0) + int(cut.sum())
     # K4 (spec chain, oldest first)
     A = M // Da
     dd = np.concatenate([np.zeros(Ta - 1, np.float32), d])

@@ -92,6 +92,26 @@ int main(int argc, char** argv) {
   p.yprev_in = d_ypi; p.yprev_out = d_ypo; p.hist_d_in = d_hdi; p.hist_d_out = d_hdo; p.hist_b_in = d_hbi; p.hist_b_out = d_hbo; p.hist_x_out = d_hxo;
   p.A = d_A; p.g = d_g; p.q0 = q; p.q2 = 65536.0f * q; p.cst = cst;
   p.T = T; p.N = nsamp; p.M = M; p.A_out = A; p.steps_total = (M + 127) / 128; p.runs = runs; p.n_streams = ns; p.dbg = nullptr; p.prio_by_age = getenv("QBENCH_NOPRIO") ? 0u : 1u;
+  unsigned int* d_st = nullptr;
+  // the conditioning guard (csrc/sdrfm.hip, sdrfm_create): thresholds as the library derives them; QBENCH_GUARD=0 switches it off.
+  // hist_q (the 64 raw samples before the call) = the random history bytes above, y[-1] taken as carried (yprev_exact).
+  {
+    std::vector<float> hp(SDRFM_Q_TP, 0.0f);
+    double sabs = 0, gmax = 0;
+    for (int k = 0; k < T; ++k) { hp[k] = h[k]; sabs += fabs((double)h[k]); }
+    for (int k = 0; k < Ta; ++k) gmax = fmax(gmax, fabs((double)g[k]));
+    const double E = 1.25 * sqrt((double)T) * 127.5 * sabs * ldexp(1.0, -24);
+    p.guard_r = (float)(2.0 * gmax * E / 5e-6); p.guard_a = (float)(M_PI - 2.0 * 5e-6 / gmax);
+    if (getenv("QBENCH_GUARD") && !atoi(getenv("QBENCH_GUARD"))) { p.guard_r = 0.0f; p.guard_a = 4.0f; }
+    if (getenv("QBENCH_GUARD_R")) p.guard_r = (float)atof(getenv("QBENCH_GUARD_R"));
+    float* d_hp; uint8_t *d_hqi, *d_hqo;
+    CK(hipMalloc(&d_hp, SDRFM_Q_TP * 4)); CK(hipMemcpy(d_hp, hp.data(), SDRFM_Q_TP * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&d_hqi, (size_t)ns * 2 * SDRFM_Q_TP)); CK(hipMalloc(&d_hqo, (size_t)ns * 2 * SDRFM_Q_TP));
+    CK(hipMemset(d_hqi, 0x80, (size_t)ns * 2 * SDRFM_Q_TP));
+    CK(hipMemcpy2D(d_hqi + 2 * (SDRFM_Q_TP - HT), 2 * SDRFM_Q_TP, d_hbi, 2 * HT, 2 * HT, ns, hipMemcpyDeviceToDevice));
+    CK(hipMalloc(&d_st, 8)); CK(hipMemset(d_st, 0, 8));
+    p.hpad = d_hp; p.hist_q_in = d_hqi; p.hist_q_out = d_hqo; p.yprev_exact = 1; p.n_repaired = d_st;
+  }
   hipStream_t st; CK(hipStreamCreate(&st));
   CK(sdrfm_q_launch(p, c0, nslot, st));
   CK(hipStreamSynchronize(st));
@@ -221,6 +241,9 @@ int main(int argc, char** argv) {
            mn[3], sum[3] / cnt, mx[3], waitc / steps, steps / cnt, clk_cyc / clk_us * 1e-3);
   }
   const double us = ms * 1e3 / iters, bytes = (double)ns * nsamp * 2.08;
+  unsigned int gst[2] = {0, 0};
+  CK(hipMemcpy(gst, d_st, 8, hipMemcpyDeviceToHost));
+  printf("{\"guard\":{\"r\":%.4g,\"a\":%.7g,\"lanes_repaired_all_launches\":%u,\"repair_passes_all_launches\":%u}}\n", p.guard_r, p.guard_a, gst[0], gst[1]);
   printf("{\"blocks_per_cu_api\":%d}\n", sdrfm_q_blocks_per_cu(c0, nslot));
   printf("{\"kernel\":\"%s\",\"ns\":%d,\"nsamp\":%d,\"T\":%d,\"nslot\":%d,\"runs\":%d,\"mode\":\"%s\",\"first_chunk\":%u,\"checked_streams\":%zu,"
          "\"max_scaled_err\":%.3g,\"worst_at\":[%d,%d],\"n_over_tol\":%ld,\"nonfinite\":%ld,\"state_err\":%.3g,\"us_per_launch\":%.2f,\"frac_of_8TBs\":%.4f,\"batches\":%d}\n",
