@@ -59,7 +59,7 @@ constexpr int DB0 = 128;                        // d buffer: word DB0 + sigma = 
 constexpr int DBW = DB0 + 656;                  // words
 constexpr int ABS = 4;                          // audio stages (128 outputs each) parked in LDS before they are stored
 constexpr int ABW = 128 * ABS;                  // words, after the d buffer
-constexpr int FLW = 64;                         // words, after the parked audio: up to 128 two-byte entries of lanes waiting for the repair path
+constexpr int FLW = 64 + 2;                     // words, after the parked audio: up to 128 two-byte entries of lanes waiting for the repair path, two counters
 constexpr int QTP = (int)SDRFM_Q_TP;            // the repair path's chain length (taps padded with zeros)
 constexpr int RWIN = QTP + 2 * QD;              // samples under the three outputs y[m0 - 1], y[m0], y[m0 + 1] a repaired lane recomputes
 static_assert(QTP % 4 == 0 && (2 * QD) % 4 == 0, "the repair path loads whole groups of four samples, none of which straddles the call's first sample");
@@ -119,6 +119,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
   const uint32_t vshift = p.iq_prev ? 1u : 0u, vsteps = p.steps_total + vshift;
   const int s0 = run == 0 ? 0 : (int)(((uint64_t)run * vsteps) / p.runs - vshift), s1 = (int)(((uint64_t)(run + 1) * vsteps) / p.runs - vshift);
   if (s0 >= s1) return;
+  if (lane == 0) *reinterpret_cast<uint2*>(fl16 + 128) = make_uint2(0u, 0u);   // repair statistics of this wave (before any LDS-DMA is in flight: no wait)
 #ifdef SDRFM_Q_STAMPS   // development harness (tools/qbench): per-wave time stamps, 8 words per wave
   unsigned long long* const tsp = p.dbg ? p.dbg + 16 * (size_t)blockIdx.x : nullptr;
   unsigned long long t_wait = 0, t_first = 0;
@@ -297,9 +298,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
   // outputs under its two d's — y[m0 - 1], y[m0], y[m0 + 1], m0 = the lane's first output of that step — with the definition's chain:
   // acc = fmaf(h[k], x, acc), oldest sample first, x = byte - 127.5, from the raw bytes in global memory (the ring's slots have been
   // refilled by now): RWIN = 84 consecutive samples, 21 aligned 8-byte loads.  Samples before the call come from the previous call's
-  // buffer (SDRFM_F_OVERLAP) or from the 64 raw samples the previous design-Q call left in hist_q.  The taps are wave-uniform: lane k holds
-  // h[k] (zero for k >= T: fmaf(0, x, acc) = acc bit for bit, acc is never -0) and v_readlane hands them out.  Then the definition's own
+  // buffer (SDRFM_F_OVERLAP) or from the 64 raw samples the previous design-Q call left in hist_q.  The taps are wave-uniform LDS reads
+  // (h[k] = 0 for k >= T: fmaf(0, x, acc) = acc bit for bit, acc is never -0).  Then the definition's own
   // discriminator (sdrfm_math.h) — the d's are the bit-exact kernels' d's, a fixed function of the bytes like everything else here.
+  // Kernel arguments that only rare branches and the epilogue need are read again from the argument segment there (scalar loads through
+  // an opaque pointer), not kept in scalar registers across the step loop: those are all taken, and every one more costs a reload per step.
+  typedef const __attribute__((address_space(4))) SdrfmQParams* KargPtr;
+  auto kargs = [&]() -> KargPtr {
+    KargPtr pp = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(pp));
+    return pp;
+  };
   int nflag = 0;
   auto repair_flagged = [&]() {
     // Everything this path needs is derived here, from opaque copies of the lane and stream numbers, so that none of it is hoisted into
@@ -307,23 +316,29 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
     // across it: their 36 VGPRs and 32 SGPRs are what the chains run in.
     int ln = lane;
     uint32_t st = stream;
-    typedef const __attribute__((address_space(4))) SdrfmQParams* KargPtr;
-    KargPtr pp = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();                                            // (read again from the kernel arguments:
-    asm volatile("" : "+v"(ln), "+s"(st), "+s"(pp));                                                            //  not kept in registers across the loop)
+    asm volatile("" : "+v"(ln), "+s"(st));
+    const KargPtr pp = kargs();
+#ifdef SDRFM_Q_PHASES   // development harness: cycles of a repair call by part, two 32-bit sums per word (t_ph[0]: set-up | data wait, t_ph[7]: chains | reload)
+    unsigned long long r_t0 = __builtin_readcyclecounter(), r_t1;
+#define R_PHASE(word, shift, waitfirst) do { if (waitfirst) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); r_t1 = __builtin_readcyclecounter(); \
+                                             t_ph[word] += ((r_t1 - r_t0) & 0xffffffffull) << shift; r_t0 = r_t1; } while (0)
+#else
+#define R_PHASE(word, shift, waitfirst) do { } while (0)
+#endif
     const unsigned char* const row = pp->iq + (size_t)st * pp->iq_stride;
     const unsigned char* const pre = from_prev ? pp->iq_prev + (size_t)st * pp->iq_prev_stride + 2 * (size_t)pp->N_prev
                                                : pp->hist_q_in + (size_t)(2 * QTP) * ((size_t)st + 1);
-    // tap vectors: lane j of tA[o] holds the tap that meets window sample j in output m0 - 1 + o (tap QTP - 1 + QD o - j, or none),
-    // lane j of tB[o] the one for sample QTP + j
-    int tA[3], tB[3];
-#pragma unroll
-    for (int o = 0; o < 3; ++o) {
-      const int kA = QTP - 1 + QD * o - ln, kB = kA - QTP;
-      const float vA = pp->hpad[kA < 0 ? 0 : (kA > QTP - 1 ? QTP - 1 : kA)], vB = pp->hpad[kB < 0 ? 0 : kB];
-      tA[o] = __builtin_bit_cast(int, (kA >= 0 && kA < QTP) ? vA : 0.0f);
-      tB[o] = __builtin_bit_cast(int, kB >= 0 ? vB : 0.0f);
+    // The taps, as a table in LDS: hz[u] = h[QTP + 2 QD - 1 - u] for u >= 2 QD, zero below — sample i of a repaired lane's window meets
+    // output m0 - 1 + o through hz[i - QD o + 2 QD].  It sits in the d buffer's first words, which nothing reads (a warm-up step's unused
+    // d's are parked there, behind us by now), and is written on every call of this path.
+    static_assert(QTP + 2 * QD <= DB0 - QTA, "the tap table of the repair path sits below the d history");
+    {
+      const float hz0 = ln >= 2 * QD ? pp->hpad[QTP + 2 * QD - 1 - ln] : 0.0f;
+      const float hz1 = ln < 2 * QD ? pp->hpad[2 * QD - 1 - ln] : 0.0f;
+      db[ln] = hz0;
+      if (ln < 2 * QD) db[64 + ln] = hz1;
     }
-    __builtin_amdgcn_wave_barrier();                            // (the list was written by other lanes)
+    __builtin_amdgcn_wave_barrier();                            // (the list and the table were written by other lanes)
     unsigned nrep = 0;
     for (int e0 = 0; e0 < nflag; e0 += 64) {
       const int e = e0 + ln;
@@ -344,52 +359,42 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
           const int n = n0 + 4 * c;
           w[c] = *reinterpret_cast<const uint2*>((n >= 0 ? row : pre) + 2 * (ptrdiff_t)n);
         }
-        float a[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        auto sample = [&](int ii, float& xr, float& xi) {      // sample ii of the 16 at the front of w
-          const unsigned wd = (ii & 2) ? w[ii >> 2].y : w[ii >> 2].x;
-          xr = (float)((wd >> ((ii & 1) ? 16 : 0)) & 0xffu) - 127.5f;   // (v_cvt_f32_ubyteN: exact)
-          xi = (float)((wd >> ((ii & 1) ? 24 : 8)) & 0xffu) - 127.5f;
-        };
-        // samples 0 .. QTP - 1: four rounds of 16, the window slides down by 16 samples after each (a rolled loop: code size, registers)
-#pragma unroll 1
-        for (int g = 0; g < QTP / 16; ++g) {
+        R_PHASE(0, 0, 0);
+        R_PHASE(0, 32, 1);
+        // (I, Q) pairs: v_pk_fma_f32 / v_pk_add_f32 — per lane the same IEEE operations as the scalar chain, half the instructions.  Sample i
+        // meets output m0 - 1 + o through tap hz[i - QD o + 2 QD] (wave-uniform LDS reads: broadcasts), where that index is >= 2 QD and below
+        // QTP + 2 QD; indices below 2 QD read zeros, which leave the accumulator as it is (fmaf(0, x, acc) = acc bit for bit; acc is never -0).
+        qf2_t a[3] = {qf2_t{0.0f, 0.0f}, qf2_t{0.0f, 0.0f}, qf2_t{0.0f, 0.0f}};
+        const float* const hz = db;
 #pragma unroll
-          for (int ii = 0; ii < 16; ++ii) {
-            float xr, xi;
-            sample(ii, xr, xi);
+        for (int i = 0; i < RWIN; ++i) {
+          const unsigned wd = (i & 2) ? w[i >> 2].y : w[i >> 2].x;
+          const qf2_t b = {(float)((wd >> ((i & 1) ? 16 : 0)) & 0xffu), (float)((wd >> ((i & 1) ? 24 : 8)) & 0xffu)};   // v_cvt_f32_ubyteN
+          const qf2_t x = b - qf2_t{127.5f, 127.5f};
 #pragma unroll
-            for (int o = 0; o < 3; ++o) {
-              const float t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(tA[o], 16 * g + ii));
-              a[2 * o] = __builtin_fmaf(t, xr, a[2 * o]);
-              a[2 * o + 1] = __builtin_fmaf(t, xi, a[2 * o + 1]);
-            }
+          for (int o = 0; o < 3; ++o) {
+            const int u = i - QD * o + 2 * QD;
+            if (u < 2 * QD || u >= QTP + 2 * QD) continue;      // (no tap of this output meets the sample: nothing issued)
+            const float t = hz[u];
+            a[o] = __builtin_elementwise_fma(qf2_t{t, t}, x, a[o]);
           }
-#pragma unroll
-          for (int c = 0; c + 4 < RWIN / 4; ++c) w[c] = w[c + 4];
-        }
-        // samples QTP .. QTP + 2 QD - 1 (under y[m0] and y[m0 + 1] only)
-#pragma unroll
-        for (int ii = 0; ii < 2 * QD; ++ii) {
-          float xr, xi;
-          sample(ii, xr, xi);
-#pragma unroll
-          for (int o = 1; o < 3; ++o) {
-            if (QD * o - 1 - ii < 0) continue;                  // (no tap of this output meets the sample)
-            const float t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(tB[o], ii));
-            a[2 * o] = __builtin_fmaf(t, xr, a[2 * o]);
-            a[2 * o + 1] = __builtin_fmaf(t, xi, a[2 * o + 1]);
-          }
+          if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // (keeps the scheduler from converting the whole window up front: registers)
         }
         if (m0 == 0 && !warm && pp->yprev_exact) {                // the call's first output after a reset or a bit-exact kernel: y[-1] is the carried one
           const float2 yp = pp->yprev_in[st];
-          a[0] = yp.x; a[1] = yp.y;
+          a[0] = qf2_t{yp.x, yp.y};
         }
         float* dst = db + DB0 + sigma + 128 * slot + 8 * (l & 15) + 2 * (l >> 4);
-        dst[0] = sdrfm_discriminate(a[2], a[3], a[0], a[1]);
-        dst[1] = sdrfm_discriminate(a[4], a[5], a[2], a[3]);
+        dst[0] = sdrfm_discriminate(a[1].x, a[1].y, a[0].x, a[0].y);
+        dst[1] = sdrfm_discriminate(a[2].x, a[2].y, a[1].x, a[1].y);
       }
     }
-    if (pp->n_repaired && ln == 0) { atomicAdd(pp->n_repaired, nrep); atomicAdd(pp->n_repaired + 1, 1u); }
+    R_PHASE(7, 0, 1);
+    if (ln == 0) {                                              // statistics: per wave in LDS (an atomic per pass from every wave queues up at one L2 address)
+      unsigned* const cnt = reinterpret_cast<unsigned*>(fl16 + 128);
+      cnt[0] += nrep;
+      cnt[1] += 1u;
+    }
     nflag = 0;
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -400,6 +405,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
 #pragma unroll
     for (int k = 0; k < QTA; ++k)
       gr[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pp->g[QTA - 1 - k])));
+    R_PHASE(7, 32, 1);
   };
   // Issue priority by age, from the middle of the run on.  The arbiter serves the oldest wave of a SIMD first and the memory pipeline's
   // queues do the same, so the first / second / third wave of a SIMD end 20.0 / 21.8 / 23.6 us after the launch (configs[2], §4.Q of
@@ -477,7 +483,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
       dst[0] = d0;
       dst[1] = d1;
     }
-    if (last_run && ks + kk == ylast_step && lane == ylast_lane) p.yprev_out[stream] = make_float2(y[2], y[3]);
+    if (last_run && ks + kk == ylast_step && lane == ylast_lane) kargs()->yprev_out[stream] = make_float2(y[2], y[3]);
 #if !(defined(SDRFM_Q_ABLATE) && (SDRFM_Q_ABLATE & 512))
     // ---- the conditioning guard: design Q's y is within E ~ 1e-4 (absolute) of the definition's fmaf chain, so its d is within
     // E / |y| + E / |p| of the definition's — fine while both magnitudes are large, not at a deep fade, and near d = +-pi the two may land
@@ -512,11 +518,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
     ++osm;
     // everything the list holds is repaired before the d's are read: at every audio stage, at the run's last step (the d history below), and
     // whenever another step's worth of lanes might not fit
-    if (nflag > 0 && (osm == 5 || kk == nsteps - 1 || nflag > 64)) repair_flagged();
+    if (nflag > 0 && (osm == 5 || kk == nsteps - 1 || nflag > 64)) {
+      __builtin_amdgcn_s_setprio(3);                            // a wave in the repair path is behind its SIMD's others: first in line until it is through
+      repair_flagged();
+      if (prio_at >= 0 && kk >= prio_at) {
+        if (wrank == 0) __builtin_amdgcn_s_setprio(0);
+        else if (wrank == 1) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(2);
+      } else {
+        __builtin_amdgcn_s_setprio(0);
+      }
+    }
     __builtin_amdgcn_wave_barrier();                            // (the d's are read by other lanes from here on)
     // the stream's last 31 d's, taken before the audio stage below may move the buffer on (the call's last step need not be full)
-    if (last_run && kk == nsteps - 1 && lane < QTA - 1)
-      p.hist_d_out[(size_t)stream * (QTA - 1) + lane] = db[DB0 + sigma + ((int)p.M - (QTA - 1) + lane - mbase)];
+    if (last_run && kk == nsteps - 1 && lane < QTA - 1) {
+      const KargPtr pp = kargs();
+      pp->hist_d_out[(size_t)stream * (QTA - 1) + lane] = db[DB0 + sigma + ((int)pp->M - (QTA - 1) + lane - mbase)];
+    }
 #ifdef SDRFM_Q_PHASES
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
@@ -565,18 +583,25 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
 #endif
   wait_vmcnt<0>();                                              // nothing may still be in flight towards this wave's LDS when it ends
   flush_audio();
+  const KargPtr pe = kargs();
+  if (pe->n_repaired && lane == 0) {
+    const uint2 cnt = *reinterpret_cast<const uint2*>(fl16 + 128);
+    if (cnt.y) { atomicAdd(pe->n_repaired, cnt.x); atomicAdd(pe->n_repaired + 1, cnt.y); }
+  }
 
   // ---- state hand-over by the wave that holds the end of the stream's chunk --------------------------------------------------
   if (last_run) {
-    const unsigned char* row = p.iq + (size_t)stream * p.iq_stride;
-    for (int k = lane; k < HT; k += 64) {
-      const unsigned raw = *reinterpret_cast<const unsigned short*>(row + 2 * ((size_t)p.N - HT + k));
-      reinterpret_cast<unsigned short*>(p.hist_b_out)[(size_t)stream * HT + k] = (unsigned short)raw;
-      p.hist_x_out[(size_t)stream * HT + k] = make_float2((float)(raw & 0xffu) - 127.5f, (float)(raw >> 8) - 127.5f);
+    const unsigned char* row = pe->iq + (size_t)stream * pe->iq_stride;
+    const int HTe = (int)pe->T - 1;
+    const size_t Ne = pe->N;
+    for (int k = lane; k < HTe; k += 64) {
+      const unsigned raw = *reinterpret_cast<const unsigned short*>(row + 2 * (Ne - HTe + k));
+      reinterpret_cast<unsigned short*>(pe->hist_b_out)[(size_t)stream * HTe + k] = (unsigned short)raw;
+      pe->hist_x_out[(size_t)stream * HTe + k] = make_float2((float)(raw & 0xffu) - 127.5f, (float)(raw >> 8) - 127.5f);
     }
     if (lane < 2 * QTP / 16)                                    // the last 64 raw samples, for the next call's repair path
-      *reinterpret_cast<qi4_t*>(p.hist_q_out + (size_t)(2 * QTP) * stream + 16 * lane) =
-          *reinterpret_cast<const qi4_t*>(row + 2 * (size_t)p.N - 2 * QTP + 16 * lane);
+      *reinterpret_cast<qi4_t*>(pe->hist_q_out + (size_t)(2 * QTP) * stream + 16 * lane) =
+          *reinterpret_cast<const qi4_t*>(row + 2 * Ne - 2 * QTP + 16 * lane);
   }
 #ifdef SDRFM_Q_STAMPS
   if (tsp && lane == 0) {

@@ -81,7 +81,7 @@ def test_six_million_random_class_outputs_against_a_bit_exact_twin(pkg, T):
         lanes = fast.q_guard()["lanes"]
     assert worst <= TOL, worst
     assert worst <= 2e-6, worst                                       # the measured margin, not only the tolerance
-    assert lanes > 100000                                             # noise-only input does meet the guard (about one lane in ten at T = 64)
+    assert lanes > 30000                                              # noise-only input does meet the guard (one lane in ten at T = 64, one in forty at T = 16)
 
 
 def test_guard_at_call_boundaries_and_kernel_changes(pkg, oracle_mod):

@@ -43,6 +43,11 @@ static void fill_row(uint8_t* row, int nsamp, int mode, unsigned id) {
   }
 }
 
+static int gst_passes_hint(const unsigned long long* hd16, size_t nw) {   // any wave with repair stamps?
+  for (size_t w = 0; w < nw; ++w) if (hd16[16 * w + 8] || hd16[16 * w + 15]) return 1;
+  return 0;
+}
+
 int main(int argc, char** argv) {
   const int ns = argc > 1 ? atoi(argv[1]) : 256, nsamp = argc > 2 ? atoi(argv[2]) : 240000, T = argc > 3 ? atoi(argv[3]) : 64;
   const int nslot = argc > 4 ? atoi(argv[4]) : 10, runs = argc > 5 ? atoi(argv[5]) : 12, iters = argc > 6 ? atoi(argv[6]) : 40;
@@ -232,6 +237,13 @@ int main(int argc, char** argv) {
     {
       double ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st = 0;
       for (size_t w = 0; w < nw; ++w) { if (!hd[8 * w + 6]) continue; st += (double)hd[8 * w + 6]; for (int i = 0; i < 8; ++i) ph[i] += (double)hd16[16 * w + 8 + i]; }
+      if (ph[1] + ph[3] > 0 && gst_passes_hint(hd16.data(), nw) > 0) {
+        double r[4] = {0, 0, 0, 0};
+        for (size_t w = 0; w < nw; ++w) { if (!hd[8 * w + 6]) continue; r[0] += (double)(hd16[16 * w + 8] & 0xffffffffull); r[1] += (double)(hd16[16 * w + 8] >> 32);
+                                          r[2] += (double)(hd16[16 * w + 15] & 0xffffffffull); r[3] += (double)(hd16[16 * w + 15] >> 32); }
+        printf("{\"repair_cycles_all_waves_one_launch\":{\"setup_and_issue\":%.0f,\"data_wait\":%.0f,\"chains_and_writeback\":%.0f,\"reload_constants\":%.0f,\"waves\":%.0f}}\n", r[0], r[1], r[2], r[3], (double)nw);
+        ph[0] = 0;
+      }
       if (ph[0] + ph[1] + ph[3] > 0)
         printf("{\"phase_cycles_per_step\":{\"data_wait\":%.0f,\"b_reads\":%.0f,\"refill_issue\":%.0f,\"xor_mfma_combine\":%.0f,\"neighbour\":%.0f,\"disc_dwrite\":%.0f,\"audio\":%.0f}}\n",
                ph[0] / st, ph[1] / st, ph[2] / st, ph[3] / st, ph[4] / st, ph[5] / st, ph[6] / st);
