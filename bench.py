@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic streams generated on the host per rank; the other "
                     "rows and the other rotated batches are byte-rotations of them made on the device (0 = generate every row)")
     ap.add_argument("--batches", type=int, default=0, help="input batches the timed loop rotates over (0 = as many as exceed the L3, >= 3)")
+    ap.add_argument("--iq-class", choices=["fm", "random"], default="fm", help="fm workload: the synthetic input class — fm = the FM test signal of "
+                    "SURVEY.md 8d (default, the headline); random = uniform random bytes, its worst-case class (noise only: the matrix-pipe kernel's "
+                    "conditioning guard sends about one lane in ten to the repair path); a comparison figure, labelled as such")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--check", action="store_true", help="also verify a few streams against the oracle (not timed)")
@@ -158,27 +161,46 @@ def cpu_baseline(pkg, h, g, iq_host, seconds, threads):
     return out
 
 
-def make_batches(torch, pkg, stream, ns, nsamp, fs, rank, distinct, nbatches):
-    """nbatches device-resident input batches [ns, 2*nsamp] u8.  `distinct` rows come from the host generator (FM test signal,
-    own PRNG stream per (rank, row)); every other row of every batch is one of them rotated by a different whole number of I/Q
-    pairs on the device: the same signal statistics at different bytes, so no two rows (or batches) share a cache line."""
+def make_batches(torch, pkg, stream, ns, nsamp, fs, rank, distinct, nbatches, mode="fm"):
+    """nbatches device-resident input batches [ns, 2*nsamp] u8 that are CONSECUTIVE pieces of every stream: batch b holds samples
+    [b nsamp, (b + 1) nsamp) of a capture nbatches x nsamp samples long, as the buffers of a front end that hands over a running
+    capture are (the reference re-arms the same pipe again and again: usbh_rtlsdr.c:1058-1101).  `distinct` captures come from the
+    host generator (own PRNG stream per (rank, row)); every other row is one of them rotated by a different whole number of I/Q pairs
+    over its whole length on the device: the same signal statistics at different bytes, so no two rows (or batches) share a cache
+    line.  A stream's signal is therefore continuous from call to call, but for the one place per nbatches calls where the rotation
+    wraps and the one where the timed loop starts the capture over (rounds 1 - 3 drew every batch independently: two phase jumps per
+    stream and call, which a demodulator fed by a running capture never sees)."""
     import numpy as np
     distinct = ns if distinct <= 0 else min(distinct, ns)
+    total = nbatches * nsamp
     t0 = time.perf_counter()
-    base_host = pkg.make_iq(distinct, nsamp, mode="fm", fs=fs, first_id=rank * ns)
+    base_host = pkg.make_iq(distinct, total, mode=mode, fs=fs, first_id=rank * ns)
     t_gen = time.perf_counter() - t0
-    batches = []
     with torch.cuda.stream(stream):
         base = torch.from_numpy(base_host).cuda()
-        for b in range(nbatches):
-            rows = []
-            for r0 in range(0, ns, distinct):
-                k = b * ((ns + distinct - 1) // distinct) + r0 // distinct
-                rows.append(base if k == 0 else torch.roll(base, shifts=2 * (7919 * k % nsamp), dims=1))
-            batches.append(torch.cat(rows)[:ns].contiguous())
+        batches = [torch.empty((ns, 2 * nsamp), dtype=torch.uint8, device="cuda") for _ in range(nbatches)]
+        for r0 in range(0, ns, distinct):
+            k = r0 // distinct
+            rows = base if k == 0 else torch.roll(base, shifts=2 * (7919 * k % total), dims=1)
+            n = min(distinct, ns - r0)
+            for b in range(nbatches):
+                batches[b][r0:r0 + n] = rows[:n, 2 * b * nsamp:2 * (b + 1) * nsamp]
+            del rows
+        del base
     stream.synchronize()
-    first_host = batches[0][: min(ns, 64)].cpu().numpy() if distinct < min(ns, 64) else base_host[: min(ns, 64)]
+    first_host = np.ascontiguousarray(base_host[: min(ns, 64), : 2 * nsamp]) if distinct >= min(ns, 64) else batches[0][: min(ns, 64)].cpu().numpy()
     return batches, np.ascontiguousarray(first_host), t_gen
+
+
+def read_ceiling(pkg, batches, local_rank, passes=60):
+    """GB/s of a read-only LDS-DMA stream with the headline kernel's access pattern over the same rotated batches (a hook of the library:
+    include/sdrfm_dev.h sdrfm_debug_read_ceiling) — the measured ceiling beside the 8 TB/s specification.  ~2 ms of GPU time."""
+    import ctypes as C
+    lib = pkg.load_library()
+    ptrs = (C.c_void_p * len(batches))(*[b.data_ptr() for b in batches])
+    out = C.c_double()
+    rc = lib.sdrfm_debug_read_ceiling(local_rank, ptrs, len(batches), batches[0].numel(), passes, C.byref(out))
+    return out.value if rc == 0 else None
 
 
 def pick_batches(args, bytes_per_batch):
@@ -269,7 +291,7 @@ def main():
     stream = torch.cuda.Stream()
     dm.set_stream(stream.cuda_stream)
     nb = pick_batches(args, ns * nbytes)
-    batches, iq_host, t_gen = make_batches(torch, pkg, stream, ns, nsamp, fs, rank, args.distinct, nb)
+    batches, iq_host, t_gen = make_batches(torch, pkg, stream, ns, nsamp, fs, rank, args.distinct, nb, mode=args.iq_class)
     n_audio_max = nsamp // D // Da + 1
     with torch.cuda.stream(stream):
         audio = torch.zeros((ns, n_audio_max), dtype=torch.float32, device="cuda")
@@ -357,6 +379,18 @@ def main():
         step_res(i)
     elapsed_res, kernel_ms_res = timed(torch, dist, use_dist, stream, step_res, res_steps) if e2e is None else (None, None)
 
+    # measured read ceiling (a read-only stream with the kernel's own access pattern over the same rotated batches), and how much of the
+    # timed work went through the matrix-pipe kernel's repair path
+    time.sleep(REST_S)
+    peak_measured = read_ceiling(pkg, batches, local_rank) if e2e is None else None
+    guard = dm.q_guard()
+    per_rank = None
+    if use_dist:
+        t = torch.tensor([kernel_ms_avg], dtype=torch.float64, device="cuda")
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        per_rank = [round(float(x.item()), 4) for x in gathered]
+
     ok = None
     if args.check and rank == 0:
         from oracle.oracle import Oracle
@@ -383,7 +417,9 @@ def main():
             "n_gpus": world, "rccl_world": rccl_world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": ("f32 audio; K2 = u8 x 24-bit fixed-point taps on the i8 matrix pipe, exact i32 sums, one f32 recombination (design Q); K3 / K4 f32; "
+                      "ill-conditioned phases recomputed with the f32 fmaf chain" if dm.kernel_name.startswith("fast-q") else "f32 (fmaf chains throughout)"),
+            "data": "synthetic" if args.iq_class == "fm" else "synthetic, uniform random bytes (SURVEY.md 8d's worst-case class: NOT the headline input)",
             "mode": "end-to-end (RCCL scatter of IQ from rank 0 + gather of audio every step)" if args.end_to_end else
                     ("compute-only (IQ resident per GPU); timed calls made with SDRFM_F_OVERLAP: consecutive calls may run concurrently on the device"
                      if overlap else "compute-only (IQ resident per GPU); calls one after the other"),
@@ -399,6 +435,10 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "frac_sustained": round(alg_bytes / (kernel_ms_sus * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                          "sustained_steps": sus_steps, "kernel_ms_sustained": round(kernel_ms_sus, 4),
+                         "peak_measured": round(peak_measured, 1) if peak_measured else None,
+                         "frac_of_measured": round(achieved / peak_measured, 4) if peak_measured else None,
+                         "frac_sustained_of_measured": round(alg_bytes / (kernel_ms_sus * 1e-3) / 1e9 / peak_measured, 4) if peak_measured else None,
+                         "peak_measured_note": "read-only LDS-DMA stream with this kernel's access pattern (12 one-wave workgroups per CU, 5 KiB in flight each, nt) over the same rotated batches, 60 passes in this run (sdrfm_debug_read_ceiling)",
                          "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
                          "traffic_source": ("profiles/%s (rocprofv3 --pmc TCC_EA0 read/write request passes at commit %s; same kernel, same workload size)" % (traffic["file"], traffic.get("commit", "?"))) if traffic else None,
                          "kernel": dm.kernel_name, "kernel_ms_avg": round(kernel_ms_avg, 4),
@@ -410,6 +450,12 @@ def main():
                             if serial_regions and len(serial_regions) > 1 else {})},
             "gen_seconds": round(t_gen, 2),
         }
+        if guard:
+            res["guard"] = {"guard_r": round(guard["guard_r"], 4), "pi_minus_guard_a": round(3.141592653589793 - guard["guard_a"], 7),
+                            "lanes_repaired_since_create": guard["lanes"], "repair_passes_since_create": guard["passes"],
+                            "note": "design Q's conditioning guard (DESIGN.md 4.Q): lanes (pairs of discriminator outputs) recomputed with the definition's fmaf chain, over every call this handle served in this run"}
+        if per_rank:
+            res["roofline"]["per_rank_kernel_ms"] = {"min": min(per_rank), "max": max(per_rank), "all": per_rank}
         if overlap:
             # `roofline` above: calls one after the other = the kernel's own duration.  This: the timed region itself (overlapped calls);
             # event span / K is then shorter than a kernel's duration, because consecutive kernels run side by side.
@@ -472,7 +518,9 @@ def main_wbfm(args, pkg, world, rank, local_rank, use_dist, rccl_world):
         res = {"metric": "IQ MSamples/s through FIR+FM-demod+resample", "value": round(world * ns * nsamp * args.steps / elapsed / 1e6, 1),
                "unit": "MSamples/s", "n_gpus": world, "rccl_world": rccl_world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic",
+               "dtype": ("f32 audio; K2 = u8 x 24-bit fixed-point taps on the i8 matrix pipe, exact i32 sums, one f32 recombination (design Q); K3 / K4 f32; "
+                      "ill-conditioned phases recomputed with the f32 fmaf chain" if dm.kernel_name.startswith("fast-q") else "f32 (fmaf chains throughout)"),
+            "data": "synthetic" if args.iq_class == "fm" else "synthetic, uniform random bytes (SURVEY.md 8d's worst-case class: NOT the headline input)",
                "config": {"workload": "BASELINE configs[4]: %d x 3.2 MS/s uint8 IQ streams per GPU x %.1f s, 128-tap prototype, 16-band polyphase "
                                       "channelizer + per-band FM demod + 6/25 resampler -> 16 x 48 kHz; %d input batches rotated (%.0f MB, cold HBM reads)"
                                       % (ns, args.seconds, nb, nb * ns * 2 * nsamp / 1e6),
@@ -519,7 +567,9 @@ def main_spectrum(args, pkg, world, rank, local_rank, use_dist, rccl_world):
         res = {"metric": "IQ MSamples/s through the windowed-FFT spectrum view", "value": round(world * ns * frames * nfft * args.steps / elapsed / 1e6, 1),
                "unit": "MSamples/s", "n_gpus": world, "rccl_world": rccl_world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic",
+               "dtype": ("f32 audio; K2 = u8 x 24-bit fixed-point taps on the i8 matrix pipe, exact i32 sums, one f32 recombination (design Q); K3 / K4 f32; "
+                      "ill-conditioned phases recomputed with the f32 fmaf chain" if dm.kernel_name.startswith("fast-q") else "f32 (fmaf chains throughout)"),
+            "data": "synthetic" if args.iq_class == "fm" else "synthetic, uniform random bytes (SURVEY.md 8d's worst-case class: NOT the headline input)",
                "config": {"workload": "spectrum view (SURVEY 8f-3) of BASELINE configs[2] buffers: %d x 2.4 MS/s uint8 IQ streams per GPU x %.1f s, "
                                       "%d-point Hann FFT, %d frames averaged per stream; %d input batches rotated (cold HBM reads)" % (ns, args.seconds, nfft, frames, nb),
                           "streams_per_gpu": ns, "bytes_per_stream": 2 * nsamp, "kernel": kname, "input_batches_rotated": nb},

@@ -9,6 +9,7 @@
  *     sdrfm_q_build                                design Q: the channel taps as i8 matrix-pipe operand tables (csrc/qtaps.c)
  *     sdrfm_q_guard                                design Q: the conditioning guard's thresholds for a tap set (csrc/qtaps.c; no GPU)
  *     sdrfm_debug_q_guard                          design Q: a handle's guard thresholds and how often its repair path ran
+ *     sdrfm_debug_read_ceiling                     what a read-only stream with design Q's access pattern gets out of the memory system
  *   exported by the development library libsdrfm_dev.so only (built with -DSDRFM_DEV):
  *     sdrfm_debug_phase_cycles, sdrfm_debug_raw    instrumented kernels' counters (SDRFM_PHASE_PROFILE=1 at create)
  *     sdrfm_dev_read_debug                         per-wave time stamps of design S (SDRFM_STREAM_PROFILE=1)
@@ -44,6 +45,11 @@ int sdrfm_q_guard(const float* h, uint32_t T, const float* g, uint32_t Ta, float
  * lanes repaired / repair passes run since create (32-bit counters on the device).  Synchronises the handle.  SDRFM_NOT_SUPPORTED when the
  * handle has no matrix-pipe kernel (SDRFM_CFG_BIT_EXACT, other geometries). */
 int sdrfm_debug_q_guard(sdrfm_t* h, float* guard_r, float* guard_a, unsigned long long* lanes, unsigned long long* passes);
+
+/* The measured read ceiling bench.py prints beside the 8 TB/s specification: a read-only LDS-DMA stream with design Q's access
+ * pattern (one-wave workgroups, 12 per CU, 5 KiB in flight each, non-temporal) over nbufs device buffers of bytes_each bytes, `passes` passes
+ * taken in turn over the buffers, timed with HIP events on a stream of its own (synchronous).  *gbytes_per_s = bytes read / elapsed. */
+int sdrfm_debug_read_ceiling(int device, const void* const* bufs, uint32_t nbufs, size_t bytes_each, uint32_t passes, double* gbytes_per_s);
 
 /* Development library only: cumulative shader cycles per phase of the instrumented design-B kernel summed over waves (out[0..4] =
  * stage, FIR, discriminator, audio, carry; out[5] = sub-tiles; out[6] = waves), reset on read; raw dump of its 560 debug words;

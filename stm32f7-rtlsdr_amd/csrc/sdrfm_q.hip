@@ -205,6 +205,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
   for (int k = 0; k < QTA; ++k)                                 // wave-uniform: kept in SGPRs (the tap tables take 60 VGPRs; four waves per SIMD need the rest)
     gr[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.g[QTA - 1 - k])));
 
+  // the repair path's taps (rare; see repair_flagged) as a table in LDS: hz[u] = h[QTP + 2 QD - 1 - u] for u >= 2 QD, zero below — sample i
+  // of a repaired lane's window meets output m0 - 1 + o through hz[i - QD o + 2 QD].  It sits in the d buffer's first words, which nothing
+  // reads or writes (a warm-up step parks only the d's of its last four blocks there: below).
+  static_assert(QTP + 2 * QD <= 96 && DB0 == 128, "the tap table of the repair path sits below the d's a warm-up step keeps");
+  const float hz0 = lane >= 2 * QD ? p.hpad[QTP + 2 * QD - 1 - lane] : 0.0f;
+  const float hz1 = lane < 2 * QD ? p.hpad[2 * QD - 1 - lane] : 0.0f;
   __builtin_amdgcn_sched_barrier(0);
   asm volatile("" ::: "memory");
 #pragma unroll
@@ -215,6 +221,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
     if (lane + 64 < HT) *reinterpret_cast<unsigned short*>(smem + PRE - 2 * HT + 2 * (lane + 64)) = hb1;
     if (lane < QTA - 1) db[DB0 + sigma - (QTA - 1) + lane] = hd0;
   }
+  db[lane] = hz0;
+  if (lane < 2 * QD) db[64 + lane] = hz1;
   __builtin_amdgcn_wave_barrier();                              // (one wave per workgroup: lanes exchange data through LDS in program order; this only pins that order for the compiler)
   int slot = 0;                                                 // ring slot of the next chunk
   int ringoff = 0;                                              // ring byte offset of the current step
@@ -328,17 +336,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
     const unsigned char* const row = pp->iq + (size_t)st * pp->iq_stride;
     const unsigned char* const pre = from_prev ? pp->iq_prev + (size_t)st * pp->iq_prev_stride + 2 * (size_t)pp->N_prev
                                                : pp->hist_q_in + (size_t)(2 * QTP) * ((size_t)st + 1);
-    // The taps, as a table in LDS: hz[u] = h[QTP + 2 QD - 1 - u] for u >= 2 QD, zero below — sample i of a repaired lane's window meets
-    // output m0 - 1 + o through hz[i - QD o + 2 QD].  It sits in the d buffer's first words, which nothing reads (a warm-up step's unused
-    // d's are parked there, behind us by now), and is written on every call of this path.
-    static_assert(QTP + 2 * QD <= DB0 - QTA, "the tap table of the repair path sits below the d history");
-    {
-      const float hz0 = ln >= 2 * QD ? pp->hpad[QTP + 2 * QD - 1 - ln] : 0.0f;
-      const float hz1 = ln < 2 * QD ? pp->hpad[2 * QD - 1 - ln] : 0.0f;
-      db[ln] = hz0;
-      if (ln < 2 * QD) db[64 + ln] = hz1;
-    }
-    __builtin_amdgcn_wave_barrier();                            // (the list and the table were written by other lanes)
+    unsigned* const cnt = reinterpret_cast<unsigned*>(fl16 + 128);
+    __builtin_amdgcn_wave_barrier();                            // (the list was written by other lanes)
     unsigned nrep = 0;
     for (int e0 = 0; e0 < nflag; e0 += 64) {
       const int e = e0 + ln;
@@ -391,20 +390,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
     }
     R_PHASE(7, 0, 1);
     if (ln == 0) {                                              // statistics: per wave in LDS (an atomic per pass from every wave queues up at one L2 address)
-      unsigned* const cnt = reinterpret_cast<unsigned*>(fl16 + 128);
       cnt[0] += nrep;
       cnt[1] += 1u;
     }
     nflag = 0;
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int c = C0; c < NSC; ++c)
-#pragma unroll
-      for (int t = 0; t < SDRFM_Q_DIGITS; ++t)
-        At[c - C0][t] = *reinterpret_cast<const qi4_t*>(pp->A + ((size_t)((c * SDRFM_Q_DIGITS + t) * 64 + ln)) * 16);
-#pragma unroll
-    for (int k = 0; k < QTA; ++k)
-      gr[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pp->g[QTA - 1 - k])));
     R_PHASE(7, 32, 1);
   };
   // Issue priority by age, from the middle of the run on.  The arbiter serves the oldest wave of a SIMD first and the memory pipeline's
@@ -478,7 +467,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
     const float d1 = q_discriminate(y[2], y[3], y[0], y[1]);   // (the pair that needs no neighbour first: its chain runs while the exchange is in flight)
     const float d0 = q_discriminate(y[0], y[1], pr, pi);
 #endif
-    {
+    if (osm >= 0 || n >= 12) {                                  // (a warm-up step: only the d's of its last four blocks are kept — the words below them hold the repair path's taps)
       float* dst = db + DB0 + sigma + 128 * osm + dlane;
       dst[0] = d0;
       dst[1] = d1;
@@ -630,6 +619,35 @@ __global__ void __launch_bounds__(64) k_q_fix_yprev(const uint8_t* hist_q, const
   yprev[s] = make_float2(ar, ai);
 }
 
+// What the memory system delivers to design Q's access pattern with nothing else going on: every wave streams its own contiguous
+// region through the same LDS-DMA ring (1 KiB per instruction, NSLOT KiB in flight, nt), reads one word per chunk, computes nothing.
+// The measured ceiling bench.py prints beside the 8 TB/s specification ("the fraction against both").
+template <int NSLOT>
+__global__ void __launch_bounds__(64) k_q_read_stream(const uint8_t* base, unsigned total_kib, unsigned kib_per_wave, unsigned* sink) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned w = blockIdx.x, lane = threadIdx.x;
+  const unsigned long long ga = (unsigned long long)base + ((unsigned long long)w * kib_per_wave << 10);
+  const unsigned left = total_kib > w * kib_per_wave ? total_kib - w * kib_per_wave : 0u;
+  const unsigned mine = left < kib_per_wave ? left : kib_per_wave;
+  const qi4_t rsrc = {(int)(unsigned)ga, (int)(unsigned)(ga >> 32), (int)(mine << 10), 0x00020000};   // past the region: out of range, no traffic
+  auto slot_ptr = [&](int slot) { return (__attribute__((address_space(3))) void*)(smem + 1024 * slot); };
+  unsigned issued = 0;
+#pragma unroll
+  for (int q = 0; q < NSLOT; ++q) { q_raw_buffer_load_lds(rsrc, slot_ptr(q), 16, (int)((issued << 10) + 16 * lane), 0, 0, SDRFM_Q_AUX); ++issued; }
+  unsigned acc = 0;
+  int slot = 0;
+  for (unsigned q = 0; q < kib_per_wave; ++q) {
+    wait_vmcnt<NSLOT - 1>();                                    // the oldest chunk has landed
+    acc += *reinterpret_cast<const unsigned*>(smem + 1024 * slot + 4 * lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    q_raw_buffer_load_lds(rsrc, slot_ptr(slot), 16, (int)((issued << 10) + 16 * lane), 0, 0, SDRFM_Q_AUX);
+    ++issued;
+    slot = (slot + 1 == NSLOT) ? 0 : slot + 1;
+  }
+  wait_vmcnt<0>();
+  if (acc == 0x12345678u) sink[0] = acc;
+}
+
 typedef void (*QKernel)(SdrfmQParams);
 struct QVariant { uint32_t c0, nslot; QKernel k; const char* name; };
 #define QV(C0_, NS_) { C0_, NS_, k_mfir<C0_, NS_>, "k_mfir<" #C0_ "," #NS_ ">" }
@@ -668,4 +686,42 @@ hipError_t sdrfm_q_launch(const SdrfmQParams& p, uint32_t first_chunk, uint32_t 
   if (!v) return hipErrorInvalidValue;
   hipLaunchKernelGGL(v->k, dim3(p.n_streams * p.runs), dim3(64), sdrfm_q_lds_bytes(nslot), stream, p);
   return hipGetLastError();
+}
+
+// Test / measurement hook (include/sdrfm_dev.h): read-only LDS-DMA stream over nbufs device buffers of bytes_each bytes, `passes` passes
+// taken in turn over the buffers (so that a pass reads cold HBM when the buffers together exceed the Infinity Cache), timed with HIP
+// events on a stream of its own.  *gbytes_per_s = bytes read / elapsed.  Computes nothing on behalf of a caller.
+extern "C" int sdrfm_debug_read_ceiling(int device, const void* const* bufs, uint32_t nbufs, size_t bytes_each, uint32_t passes, double* gbytes_per_s) {
+  if (!bufs || !nbufs || !gbytes_per_s || bytes_each < (1u << 20) || bytes_each >= (1ull << 41) || !passes) return 16;   // SDRFM_EINVAL
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev || hipSetDevice(device) != hipSuccess) return 19;   // SDRFM_NO_DEVICE
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 19;
+  const unsigned waves = 12u * (unsigned)prop.multiProcessorCount;          // design Q's residency
+  const unsigned total_kib = (unsigned)(bytes_each >> 10), kpw = (total_kib + waves - 1) / waves;
+  hipStream_t st = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  unsigned* sink = nullptr;
+  int rc = 2;                                                               // SDRFM_FAIL
+  if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess &&
+      hipMalloc(&sink, 64) == hipSuccess) {
+    auto pass = [&](uint32_t k) {
+      hipLaunchKernelGGL(k_q_read_stream<5>, dim3(waves), dim3(64), 5 * 1024, st, static_cast<const uint8_t*>(bufs[k % nbufs]), total_kib, kpw, sink);
+    };
+    for (uint32_t k = 0; k < (passes < 5 ? passes : 5u); ++k) pass(k);
+    float ms = 0.0f;
+    if (hipStreamSynchronize(st) == hipSuccess && hipEventRecord(e0, st) == hipSuccess) {
+      for (uint32_t k = 0; k < passes; ++k) pass(k);
+      if (hipEventRecord(e1, st) == hipSuccess && hipEventSynchronize(e1) == hipSuccess && hipGetLastError() == hipSuccess &&
+          hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0.0f) {
+        *gbytes_per_s = (double)(total_kib) * 1024.0 * passes / (ms * 1e-3) * 1e-9;
+        rc = 0;
+      }
+    }
+  }
+  if (sink) (void)hipFree(sink);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (st) (void)hipStreamDestroy(st);
+  return rc;
 }
