@@ -1493,6 +1493,12 @@ struct sdrfm {
   uint8_t* d_hist_q[2];
   unsigned int* d_qstat;
   bool yprev_exact, hist_q_valid;
+  // Which kernel serves a stream is also a matter of what the stream holds: noise-only input sends design Q to its repair path at
+  // almost every audio stage (3 x the time of a carrier's call; the bit-exact kernels: 1.4 x).  Every eighth wave reports its repair
+  // passes to a host-mapped word; when more than a quarter of the audio stages of the last SDRFM_Q_ADAPT_WINDOW design-Q calls needed
+  // one, the next SDRFM_Q_ADAPT_BACKOFF eligible calls go to the bit-exact kernels, after which design Q is tried again.
+  unsigned int* q_adapt_host; unsigned int* q_adapt_dev;
+  uint64_t q_stages_sampled, q_stages_mark; uint32_t q_passes_mark, q_calls_in_window, q_backoff;
   // SDRFM_F_OVERLAP: two internal streams taken in turn, so that consecutive calls run concurrently on the device (a call's ramp-up
   // under the previous call's tail).  ovl_in orders a call behind what the handle's stream holds when it is made; join_overlap()
   // records ovl_done[k] behind the calls put on internal stream k and makes the handle's stream wait for it.
@@ -1506,6 +1512,8 @@ struct sdrfm {
 
 static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nbytes, float* d_audio, size_t audio_stride,
                    uint32_t* n_audio, uint32_t call_flags = 0);
+#define SDRFM_Q_ADAPT_WINDOW 8u      /* design-Q calls between two looks at the sampled repair statistics */
+#define SDRFM_Q_ADAPT_BACKOFF 256u   /* eligible calls served by the bit-exact kernels after a window of noise-like input */
 static int join_overlap(sdrfm* h);
 
 #define HIP_TRY(expr, code)                                                                          \
@@ -1543,6 +1551,7 @@ static void free_handle(sdrfm* h) {
   if (h->d_dbg) (void)hipFree(h->d_dbg);
   if (h->d_qA) (void)hipFree(h->d_qA);
   if (h->d_hpad) (void)hipFree(h->d_hpad);
+  if (h->q_adapt_host) (void)hipHostFree(h->q_adapt_host);
   if (h->d_qstat) (void)hipFree(h->d_qstat);
   for (int i = 0; i < 2; ++i)
     if (h->d_hist_q[i]) (void)hipFree(h->d_hist_q[i]);
@@ -1728,7 +1737,10 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
           hipMemcpy(h->d_qA, tab, SDRFM_Q_SPARSE_CHUNKS(SDRFM_Q_D) * SDRFM_Q_DIGITS * 64 * 16, hipMemcpyHostToDevice) == hipSuccess &&
           hipMalloc(&h->d_hpad, sizeof(hpad)) == hipSuccess && hipMemcpy(h->d_hpad, hpad, sizeof(hpad), hipMemcpyHostToDevice) == hipSuccess &&
           hipMalloc(&h->d_hist_q[0], 2 * SDRFM_Q_TP * ns) == hipSuccess && hipMalloc(&h->d_hist_q[1], 2 * SDRFM_Q_TP * ns) == hipSuccess &&
-          hipMalloc(&h->d_qstat, 2 * sizeof(unsigned int)) == hipSuccess && hipMemset(h->d_qstat, 0, 2 * sizeof(unsigned int)) == hipSuccess) {
+          hipMalloc(&h->d_qstat, 2 * sizeof(unsigned int)) == hipSuccess && hipMemset(h->d_qstat, 0, 2 * sizeof(unsigned int)) == hipSuccess &&
+          hipHostMalloc(reinterpret_cast<void**>(&h->q_adapt_host), 64, hipHostMallocMapped) == hipSuccess &&
+          hipHostGetDevicePointer(reinterpret_cast<void**>(&h->q_adapt_dev), h->q_adapt_host, 0) == hipSuccess) {
+        memset(h->q_adapt_host, 0, 64);
         h->q_scale = qs; h->q_cst = qc; h->q_c0 = c0 > 1 ? 1 : c0;
         h->q_guard_r = q_R; h->q_guard_a = q_A;
         h->q_nslot = 5; h->q_waves_per_cu = 12;
@@ -1738,6 +1750,7 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
         if (const char* e = getenv("SDRFM_Q_GUARD_R")) h->q_guard_r = (float)atof(e);            // 0 and 4: the guard never fires (timing / soak experiments)
         if (const char* e = getenv("SDRFM_Q_GUARD_A")) h->q_guard_a = (float)atof(e);
         if (getenv("SDRFM_NO_Q")) { (void)hipFree(h->d_qA); h->d_qA = nullptr; }
+        if (getenv("SDRFM_Q_NO_ADAPT")) h->q_adapt_dev = nullptr;                                 // design Q whatever the stream holds (timing experiments)
 #endif
         h->n_cu = (uint32_t)prop.multiProcessorCount;
         snprintf(h->fast_q_name, sizeof(h->fast_q_name), "fast-q T%u D%u Ta%u Da%u %s", cfg->fir_taps, cfg->fir_decim, cfg->audio_taps,
@@ -1820,6 +1833,8 @@ int sdrfm_reset(sdrfm_t* h) {
   }
   h->yprev_exact = true;                                          // y[-1] = 0, as the definition has it
   h->hist_q_valid = false;
+  h->q_backoff = 0; h->q_calls_in_window = 0; h->q_stages_mark = h->q_stages_sampled;
+  if (h->q_adapt_host) h->q_passes_mark = *reinterpret_cast<volatile unsigned int*>(h->q_adapt_host);
   HIP_TRY(hipStreamSynchronize(h->stream), SDRFM_FAIL);
   h->cur = 0;
   h->phase_x = h->phase_d = 0;
@@ -1935,10 +1950,12 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
   // hands over holds no output computed from the (inexpressible in bytes) zero history.  It also serves one dongle's second of IQ
   // (BASELINE configs[1]: 1875 steps cut into two-step runs, 5.7 us against 9.6 - 13 us for design B).
   const uint32_t q_steps = (M + SDRFM_Q_STEP_OUT - 1) / SDRFM_Q_STEP_OUT;
-  const bool q_ok = h->d_qA && A > 0 && h->phase_x == 0 && h->phase_d == 0 && (N % (SDRFM_Q_D * SDRFM_Q_DA * 8u)) == 0 &&
+  const bool q_fit = h->d_qA && A > 0 && h->phase_x == 0 && h->phase_d == 0 && (N % (SDRFM_Q_D * SDRFM_Q_DA * 8u)) == 0 &&
                     ((uintptr_t)d_iq % 16 == 0) && (iq_stride % 16 == 0) && N < (1u << 30) && M >= c.audio_taps &&
                     (h->n_seen + 1 >= c.fir_taps || M >= y_aff + c.audio_taps) &&
                     (uint64_t)c.n_streams * q_steps >= 2ull * h->n_cu;
+  const bool q_ok = q_fit && h->q_backoff == 0;
+  if (q_fit && h->q_backoff) --h->q_backoff;
   // SDRFM_F_OVERLAP: the call goes to one of two internal streams and warms every stream up from the previous call's buffer instead
   // of reading the carried state, so that it depends on nothing the previous call computes (the state sets are still written, for
   // whatever call comes next without the flag).  Any other call first orders the handle's stream behind the overlapped ones.
@@ -1994,6 +2011,7 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
                                2 * (size_t)(c.fir_taps - 1), c.n_streams, hipMemcpyDeviceToDevice, h->stream), SDRFM_FAIL);
     q.hpad = h->d_hpad; q.hist_q_in = h->d_hist_q[h->cur]; q.hist_q_out = h->d_hist_q[h->cur ^ 1];
     q.guard_r = h->q_guard_r; q.guard_a = h->q_guard_a; q.yprev_exact = h->yprev_exact ? 1u : 0u; q.n_repaired = h->d_qstat;
+    q.n_adapt = h->q_adapt_dev;
     // runs (waves) per stream: fill the machine once; every run at least four owned steps (a run that does not start its stream
     // recomputes one step), two when the call is too small to fill the machine otherwise
     uint32_t runs = (h->q_waves_per_cu * h->n_cu) / c.n_streams;
@@ -2004,6 +2022,14 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
     HIP_TRY(sdrfm_q_launch(q, h->q_c0, h->q_nslot, qs), SDRFM_FAIL);
     if (ovl) h->ovl_pending[k] = true;
     h->yprev_exact = false; h->hist_q_valid = true;
+    // the stream's content decides too (see the handle): sampled repair passes against sampled audio stages over the last window of calls
+    // (the word lags by the calls still in flight: the ratio errs on design Q's side)
+    h->q_stages_sampled += ((uint64_t)c.n_streams * runs * ((q_steps / runs + 4) / 5) + SDRFM_Q_ADAPT_SAMPLE - 1) / SDRFM_Q_ADAPT_SAMPLE;
+    if (h->q_adapt_dev && ++h->q_calls_in_window >= SDRFM_Q_ADAPT_WINDOW) {
+      const uint32_t passes = *reinterpret_cast<volatile unsigned int*>(h->q_adapt_host);
+      if ((uint64_t)(passes - h->q_passes_mark) * 4u > h->q_stages_sampled - h->q_stages_mark) h->q_backoff = SDRFM_Q_ADAPT_BACKOFF;
+      h->q_passes_mark = passes; h->q_stages_mark = h->q_stages_sampled; h->q_calls_in_window = 0;
+    }
     snprintf(h->kernel_name, sizeof(h->kernel_name), "%s%s", h->fast_q_name, ovl ? " overlapped" : "");
   } else if (stream_ok) {
     const uint32_t segs = N / h->fast_s->seg;

@@ -43,6 +43,7 @@ struct SdrfmQParams {
   float guard_a;                // ... or one of its two |d|'s is above this (the branch cut); guard_r = 0 and guard_a = 4 switch the guard off
   uint32_t yprev_exact;         // yprev_in holds the definition's y[-1] (reset, or the previous call ran on a bit-exact kernel): hist_q_in[0] is not valid then
   unsigned int* n_repaired;     // statistics (device, two words: repaired lanes, repair passes) or nullptr
+  unsigned int* n_adapt;        // host-mapped word or nullptr: repair passes of every eighth wave (SDRFM_Q_ADAPT_SAMPLE), for the host's choice of kernel
   unsigned long long* dbg;      // development build: per-wave time stamps (else nullptr)
 };
 
@@ -51,6 +52,7 @@ struct SdrfmQParams {
 #define SDRFM_Q_TA 32u           /* audio taps */
 #define SDRFM_Q_DA 5u            /* audio decimation */
 #define SDRFM_Q_STEP_OUT 128u    /* decimated outputs per wave step (16 columns x 8 outputs) */
+#define SDRFM_Q_ADAPT_SAMPLE 8u  /* one wave in this many reports its repair passes to the host */
 #define SDRFM_Q_TP 64u           /* the repair path's chain length: channel taps padded with zeros to this many (design Q serves T <= 64) */
 
 // LDS bytes of one wave for a ring of `nslot` KiB (nslot = 5, 10 or 15)

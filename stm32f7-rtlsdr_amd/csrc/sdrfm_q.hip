@@ -575,7 +575,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
   const KargPtr pe = kargs();
   if (pe->n_repaired && lane == 0) {
     const uint2 cnt = *reinterpret_cast<const uint2*>(fl16 + 128);
-    if (cnt.y) { atomicAdd(pe->n_repaired, cnt.x); atomicAdd(pe->n_repaired + 1, cnt.y); }
+    if (cnt.y) {
+      atomicAdd(pe->n_repaired, cnt.x);
+      atomicAdd(pe->n_repaired + 1, cnt.y);
+      if (pe->n_adapt && blockIdx.x % SDRFM_Q_ADAPT_SAMPLE == 3u)       // (host memory: only waves that did repair, only a sample of them)
+        __hip_atomic_fetch_add(pe->n_adapt, cnt.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 
   // ---- state hand-over by the wave that holds the end of the stream's chunk --------------------------------------------------

@@ -138,3 +138,36 @@ def test_guard_does_not_touch_a_carrier(pkg):
             dm.process_batch_device(iq, audio)
         assert dm.q_guard()["lanes"] == first
         assert first <= 8 * ns
+
+
+def test_noise_only_streams_move_to_the_bit_exact_kernels_and_back(pkg, oracle_mod):
+    """The repair path at every audio stage costs three times a carrier's call; the bit-exact kernels cost 1.4 times.  A handle whose
+    last window of design-Q calls was mostly repair work is served by them for a while (csrc/sdrfm.hip: SDRFM_Q_ADAPT_*), then design Q
+    is tried again; a handle fed carriers never leaves design Q.  The audio is the oracle's throughout, across both changes of kernel."""
+    import torch
+    h, g = pkg.default_config(64)
+    ns, nsamp, ncalls = 256, 24000, 40
+    for mode, expect_switch in (("random", True), ("fm", False)):
+        rows = pkg.make_iq(8, ncalls * nsamp, mode=mode, first_id=4242)
+        dev = torch.from_numpy(np.tile(rows, (ns // 8, 1))).cuda()
+        out = torch.zeros((ncalls, ns, nsamp // 50), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        names = []
+        with pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=ns, max_bytes_per_call=2 * nsamp)) as dm:
+            for k in range(ncalls):
+                assert dm.process_batch_device(dev[:, 2 * k * nsamp:], out[k], nbytes=2 * nsamp) == nsamp // 50
+                names.append(dm.kernel_name.split()[0])
+                if k % 4 == 3:
+                    dm.synchronize()                                  # (a caller that looks at its audio now and then: the statistics arrive)
+            dm.synchronize()
+        assert names[0] == "fast-q", names
+        if expect_switch:
+            first = min(k for k, n in enumerate(names) if n != "fast-q")
+            assert 8 <= first <= 24, names                            # after the first window(s) of design-Q calls
+            assert all(n in ("fast-s", "fast-b") for n in names[first:]), names   # ... and for the 256 calls that follow
+        else:
+            assert all(n == "fast-q" for n in names), names
+        got = out.cpu().numpy()
+        for s in range(8):
+            want = oracle_mod.Oracle(h, g).process(rows[s])
+            assert scaled_err(np.concatenate([got[k, s] for k in range(ncalls)]), want) <= TOL, (mode, s)
