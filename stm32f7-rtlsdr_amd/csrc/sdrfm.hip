@@ -1508,6 +1508,8 @@ struct sdrfm {
   uint32_t ovl_next;
   // the previous call's device buffer (valid after a SDRFM_F_DEVICE_PTRS call): what an overlapped call warms its streams up from
   const uint8_t* prev_iq; size_t prev_stride; uint32_t prev_nbytes;
+  // the audio buffer the most recent overlapped call writes (it may still be running when the next call is made)
+  const float* prev_ovl_audio; size_t prev_ovl_audio_stride; uint32_t prev_ovl_audio_n;
 };
 
 static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nbytes, float* d_audio, size_t audio_stride,
@@ -1900,6 +1902,26 @@ int sdrfm_synchronize(sdrfm_t* h) {
 
 const char* sdrfm_kernel_name(const sdrfm_t* h) { return h ? h->kernel_name : ""; }
 
+// Do rows [a + i sa, a + i sa + la) and [b + j sb, b + j sb + lb), i, j < n, share a byte?  Exact for equal strides (two views of one
+// buffer at different offsets do not); otherwise the two whole ranges are compared.
+static bool rows_overlap(const uint8_t* a, size_t sa, size_t la, const uint8_t* b, size_t sb, size_t lb, uint32_t n) {
+  if (!a || !b || n == 0 || la == 0 || lb == 0) return false;
+  const uintptr_t ua = (uintptr_t)a, ub = (uintptr_t)b;
+  if (n == 1 || sa != sb || sa == 0) {
+    const uintptr_t ea = ua + (uintptr_t)(n - 1) * sa + la, eb = ub + (uintptr_t)(n - 1) * sb + lb;
+    return ua < eb && ub < ea;
+  }
+  // row i of a and row j of b start d - (i - j) s apart (d = b - a): they share a byte iff that distance lies in (-lb, la)
+  const long long s = (long long)sa, d = (long long)(ub - ua);
+  long long k = d / s;                                          // i - j candidates: floor(d / s) and its neighbours
+  for (long long kk = k - 1; kk <= k + 1; ++kk) {
+    if (kk <= -(long long)n || kk >= (long long)n) continue;
+    const long long r = d - kk * s;
+    if (r > -(long long)lb && r < (long long)la) return true;
+  }
+  return false;
+}
+
 // Enqueue one call on device-resident buffers and advance the host-side phases / state set.
 static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nbytes, float* d_audio, size_t audio_stride,
                    uint32_t* n_audio, uint32_t call_flags) {
@@ -1959,9 +1981,15 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
   // SDRFM_F_OVERLAP: the call goes to one of two internal streams and warms every stream up from the previous call's buffer instead
   // of reading the carried state, so that it depends on nothing the previous call computes (the state sets are still written, for
   // whatever call comes next without the flag).  Any other call first orders the handle's stream behind the overlapped ones.
+  // What the flag asks of the caller is checked where that is cheap: a call whose rows overlap the previous call's rows (one buffer used
+  // for every call) or whose audio buffer is the one the previous overlapped call may still be writing runs as if the flag were absent.
   const bool ovl = q_ok && (call_flags & SDRFM_F_OVERLAP) && h->prev_iq && h->n_seen + 1 >= c.fir_taps &&
                    h->prev_nbytes >= 2u * 10u * SDRFM_Q_STEP_OUT && (h->prev_nbytes % 16 == 0) && ((uintptr_t)h->prev_iq % 16 == 0) &&
-                   (h->prev_stride % 16 == 0);
+                   (h->prev_stride % 16 == 0) &&
+                   !rows_overlap(h->prev_iq, h->prev_stride, h->prev_nbytes, d_iq, iq_stride, nbytes, c.n_streams) &&
+                   !(h->prev_ovl_audio && rows_overlap(reinterpret_cast<const uint8_t*>(h->prev_ovl_audio), h->prev_ovl_audio_stride * sizeof(float),
+                                                       h->prev_ovl_audio_n * sizeof(float), reinterpret_cast<const uint8_t*>(d_audio),
+                                                       audio_stride * sizeof(float), (size_t)A * sizeof(float), c.n_streams));
   if (!ovl) { const int jrc = join_overlap(h); if (jrc != SDRFM_OK) return jrc; }
   if (!q_ok) {
     // A bit-exact kernel takes over from design Q: the y[-1] it is handed must be the definition's (design Q's own is within 1e-4 of it,
@@ -1969,6 +1997,7 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
     if (!h->yprev_exact && h->hist_q_valid)
       HIP_TRY(sdrfm_q_fix_yprev(h->d_hist_q[h->cur], h->d_hpad, h->d_yprev[h->cur], c.n_streams, h->stream), SDRFM_FAIL);
     h->yprev_exact = true; h->hist_q_valid = false;
+    h->prev_ovl_audio = nullptr;
   }
   if (q_ok) {
     SdrfmQParams q;
@@ -2021,6 +2050,7 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
     q.runs = runs;
     HIP_TRY(sdrfm_q_launch(q, h->q_c0, h->q_nslot, qs), SDRFM_FAIL);
     if (ovl) h->ovl_pending[k] = true;
+    h->prev_ovl_audio = ovl ? d_audio : nullptr; h->prev_ovl_audio_stride = audio_stride; h->prev_ovl_audio_n = A;
     h->yprev_exact = false; h->hist_q_valid = true;
     // the stream's content decides too (see the handle): sampled repair passes against sampled audio stages over the last window of calls
     // (the word lags by the calls still in flight: the ratio errs on design Q's side)

@@ -147,3 +147,41 @@ def test_pipeline_with_the_pcm_sink_on_the_handles_stream(pkg):
         for k in range(nb):
             want, state = pkg.pcm_deemph_s16_host(want_audio[k][s], alpha, gain, state)
             assert np.array_equal(pcm[k].cpu().numpy()[s], want), (s, k)
+
+
+def test_broken_promises_fall_back_to_serial_calls(pkg, oracle_mod, tol):
+    """SDRFM_F_OVERLAP asks the caller to keep the previous call's input intact and to alternate the audio buffers.  Where the library can
+    see that the promise does not hold — this call's rows overlap the previous call's (ONE buffer re-used for every call), or the audio
+    buffer is the one the previous overlapped call is still writing — the call runs as if the flag were absent, and the audio is right."""
+    import torch
+    from conftest import scaled_err
+    ns, nsamp = 256, 24000
+    h, g = pkg.default_config(64)
+    host = [pkg.make_iq(ns, nsamp, mode="fm", first_id=500 + 300 * b) for b in range(4)]
+    one_buf = torch.zeros((ns, 2 * nsamp), dtype=torch.uint8, device="cuda")
+    two_bufs = [torch.zeros_like(one_buf) for _ in range(2)]
+    audio = [torch.zeros((ns, nsamp // 50), dtype=torch.float32, device="cuda") for _ in range(4)]
+    tmp = torch.zeros_like(audio[0])
+    torch.cuda.synchronize()
+    with pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=ns)) as dm:
+        names = []
+        for b in range(2):                                            # (a) one input buffer for every call, refilled in between
+            dm.synchronize()
+            one_buf.copy_(torch.from_numpy(host[b])); torch.cuda.synchronize()
+            dm.process_batch_device(one_buf, audio[b], overlap=True)
+            names.append(dm.kernel_name)
+        dm.synchronize()
+        for b in (2, 3):                                              # (b) two input buffers, but the SAME audio buffer twice in a row
+            two_bufs[b & 1].copy_(torch.from_numpy(host[b])); torch.cuda.synchronize()
+            dm.process_batch_device(two_bufs[b & 1], tmp, overlap=True)
+            names.append(dm.kernel_name)
+            dm.synchronize()
+            audio[b].copy_(tmp); torch.cuda.synchronize()
+    assert all(n.startswith("fast-q") for n in names), names
+    assert "overlapped" not in names[1], names                        # same rows as the previous call's: serial
+    assert "overlapped" in names[2], names                            # a fresh buffer behind call 1: the promise holds
+    assert "overlapped" not in names[3], names                        # the audio buffer call 2 may still be writing: serial
+    got = np.concatenate([a.cpu().numpy() for a in audio], axis=1)
+    for s in (0, 100, 255):
+        want = oracle_mod.Oracle(h, g).process(np.concatenate([x[s] for x in host]))
+        assert scaled_err(got[s], want) <= tol

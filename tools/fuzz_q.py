@@ -2,9 +2,9 @@
 """Randomised soak of design Q (the matrix-pipe kernel, csrc/sdrfm_q.hip): batches of every size class (machine-filling, one dongle,
 more streams than waves), tap counts 16 / 32 / 64 and random taps, call sizes that are / are not whole audio periods, resets in
 mid-stream, device-resident buffers with odd row strides.  Every call is compared with the bit-exact kernels on a twin handle
-and, for the distinct rows, with the oracle (both 1e-5 scaled; on the BASELINE taps the worst is 7e-7, a random narrow filter that attenuates the test
-signal by 40 dB makes every fp32 implementation noisier: worst seen 6.8e-6).  Outputs whose window holds an ill-conditioned phase — |y| below 2e-2
-or a discriminator input on the branch cut; rows of uniform random bytes only — are judged as the comment in the loop says.  usage: fuzz_q.py [seconds] [seed]"""
+and, for the distinct rows, with the oracle — both at the PLAIN criterion |a - b| <= 1e-5 max(|b|, 1), every output, nothing scaled and nothing left
+out (round 3's version excused ill-conditioned phases; since round 4 the kernel's conditioning guard repairs them: csrc/sdrfm_q.hip).  Rows of
+uniform random bytes are in every case.  usage: fuzz_q.py [seconds] [seed]"""
 import importlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -14,7 +14,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 t_end, cases, calls_q, fails, worst_exact, worst_oracle = time.time() + budget, 0, 0, 0, 0.0, 0.0
-n_scaled = n_cut = calls_ovl = 0
+calls_ovl = 0; lanes_repaired = 0
 while time.time() < t_end:
     T = int(rng.choice([16, 32, 64, 64, 48, 90, 33]))
     g = pkg.default_config(64)[1]
@@ -49,10 +49,9 @@ while time.time() < t_end:
     fast = pkg.FmDemod(pkg.FmConfig(**kw)); exact = pkg.FmDemod(pkg.FmConfig(bit_exact=True, **kw))
     orcs = [Oracle(h, g) for _ in range(nd)]
     pos, log, bad = 0, [], False
-    yprev = [np.zeros(2) for _ in range(nd)]
     for n in sizes:
         if rng.random() < 0.15:
-            fast.reset(); exact.reset(); [o.reset() for o in orcs]; log.append("reset"); yprev = [np.zeros(2) for _ in range(nd)]
+            fast.reset(); exact.reset(); [o.reset() for o in orcs]; log.append("reset")
         cap = fast.audio_count(2 * n) + 1
         a1 = torch.full((ns, cap), 3.0, dtype=torch.float32, device="cuda"); a2 = torch.full((ns, cap), 5.0, dtype=torch.float32, device="cuda")
         torch.cuda.synchronize()
@@ -70,43 +69,16 @@ while time.time() < t_end:
         elif n1:
             if ns >= 2 * nd and not np.array_equal(g1[:nd], g1[nd:2 * nd]):
                 bad = True; log.append("rows-differ")
-        tolrow = []
         for s in range(nd):
             w = orcs[s].process(rows[s, 2 * pos:2 * (pos + n)]).astype(np.float64)
-            tj = np.ones(w.size)
-            if w.size and name == "fast-q":
-                # Where the phase is ill-conditioned NO fp32 evaluation of the FIR is within 1e-5 of another: (a) at a deep fade, |y| below
-                # 2e-2 (-75 dB re full scale: uniform random bytes get there about once per 1e8 samples, an FM signal never) the
-                # discriminator divides the FIR's absolute rounding error (~4e-6) by |y|; (b) at the branch cut, re < 0 and im = +-0, the two
-                # answers +pi and -pi are the same angle and 2 pi g[k] apart in the audio.  The tolerance of the outputs whose window holds
-                # such a d is scaled by the conditioning (a: at most x100), or the output is left out (b); both are counted.
-                yy, _ = orcs[s].last_stage()
-                yy = yy.astype(np.float64)
-                if yy.shape[0] == 5 * w.size:                                              # a design-Q call starts at decimator phase 0
-                    pr = np.vstack([yprev[s][None, :], yy[:-1]])
-                    re, im = yy[:, 0] * pr[:, 0] + yy[:, 1] * pr[:, 1], yy[:, 1] * pr[:, 0] - yy[:, 0] * pr[:, 1]
-                    mag = np.minimum(np.hypot(yy[:, 0], yy[:, 1]), np.hypot(pr[:, 0], pr[:, 1]))
-                    cd = np.maximum(1.0, 2e-2 / np.maximum(mag, 1e-30))
-                    cd = np.minimum(cd, 100.0)
-                    cd[(re < 0) & (np.abs(im) <= 8e-6 * (np.hypot(yy[:, 0], yy[:, 1]) + np.hypot(pr[:, 0], pr[:, 1])))] = np.inf   # |im| within the FIR's own error
-                    pad = np.concatenate([np.ones(31), cd])                                    # d's before the call: not judged here
-                    tj = np.array([pad[5 * j + 4:5 * j + 36].max() for j in range(w.size)])
-                    n_scaled += int(np.isfinite(tj).sum() - (tj == 1.0).sum()); n_cut += int(np.isinf(tj).sum())
-            if orcs[s].last_stage()[0].shape[0]:
-                yprev[s] = orcs[s].last_stage()[0][-1].astype(np.float64)
-            tolrow.append(tj)
             if w.size:
-                ok = np.isfinite(tj)
-                ev = np.abs(g1[s] - w) / np.maximum(np.abs(w), 1.0)
-                e = float((ev[ok] / tj[ok]).max()) if ok.any() else 0.0; worst_oracle = max(worst_oracle, e); bad |= e > 1e-5
+                e = float((np.abs(g1[s] - w) / np.maximum(np.abs(w), 1.0)).max()); worst_oracle = max(worst_oracle, e); bad |= e > 1e-5
                 if e > 1e-5: log.append(("vs-oracle", s, e))
-        if n1 and n1 == n2 and np.isfinite(g1).all():                                     # against the bit-exact kernels, same per-output tolerance
-            ev = np.abs(g1 - g2) / np.maximum(np.abs(g2), 1.0)
-            tj = np.tile(np.stack(tolrow), ((ns + nd - 1) // nd, 1))[:ns]
-            ok = np.isfinite(tj)
-            e = float((ev[ok] / tj[ok]).max()) if ok.any() else 0.0; worst_exact = max(worst_exact, e); bad |= e > 1e-5
+        if n1 and n1 == n2 and np.isfinite(g1).all():                                     # against the bit-exact kernels
+            e = float((np.abs(g1 - g2) / np.maximum(np.abs(g2), 1.0)).max()); worst_exact = max(worst_exact, e); bad |= e > 1e-5
             if e > 1e-5: log.append(("vs-exact", e))
         pos += n
+    st = fast.q_guard(); lanes_repaired += st["lanes"] if st else 0
     fast.close(); exact.close()
     cases += 1
     if bad:
@@ -115,7 +87,6 @@ while time.time() < t_end:
             os.makedirs(os.environ["FUZZ_DUMP"], exist_ok=True)
             np.savez_compressed(os.path.join(os.environ["FUZZ_DUMP"], "case_%d_%d.npz" % (seed, cases)), h=h, g=g, ns=ns, stride=stride, rows=rows,
                                 sizes=np.array(sizes), resets=np.array([i for i, x in enumerate([e for e in log if e == "reset" or (isinstance(e, tuple) and isinstance(e[0], int))]) if x == "reset"]))
-print("design-Q soak: cases %d  calls served by fast-q %d (%d of them overlapped)  failures %d  worst vs bit-exact kernels %.3g  worst vs oracle %.3g  (seed %d, %.0f s); "
-      "ill-conditioned outputs of the distinct rows: %d judged with a tolerance scaled by 2e-2 / |y| (deep fades), %d left out (branch cut)"
-      % (cases, calls_q, calls_ovl, fails, worst_exact, worst_oracle, seed, budget, n_scaled, n_cut))
+print("design-Q soak: cases %d  calls served by fast-q %d (%d of them overlapped)  failures %d  worst vs bit-exact kernels %.3g  worst vs oracle %.3g  "
+      "lanes through the repair path %d  (seed %d, %.0f s; plain criterion, every output)" % (cases, calls_q, calls_ovl, fails, worst_exact, worst_oracle, lanes_repaired, seed, budget))
 sys.exit(1 if fails else 0)
