@@ -95,17 +95,44 @@ def test_ragged_chunks_equal_one_shot_bitwise_and_oracle(pkg, oracle_mod):
 @pytest.mark.parametrize("T,D,Ta,Da", [(1, 1, 1, 1), (7, 3, 5, 4), (16, 10, 32, 5), (128, 16, 64, 6), (256, 10, 256, 5),
                                        (33, 64, 3, 2)])
 def test_odd_geometries(pkg, oracle_mod, T, D, Ta, Da):
+    """Any (T <= 256, D <= 64, Ta <= 256, Da <= 64) with random taps, at the PLAIN tolerance.  The audio taps have unit absolute sum: the
+    tolerance is stated for an audio filter of about unit gain (the BASELINE one: 1.13); what a larger one does to it is the next test."""
     rng = np.random.default_rng(T + D)
     h = (rng.standard_normal(T) / np.sqrt(T)).astype(np.float32)
-    g = (rng.standard_normal(Ta) / np.sqrt(Ta)).astype(np.float32)
+    g = rng.standard_normal(Ta)
+    g = (g / np.abs(g).sum()).astype(np.float32)
     dm, _, _ = _demod(pkg, h=h, g=g, D=D, Da=Da)
     iq = pkg.make_iq(1, 30000, mode="fm", first_id=9)[0]
     o = oracle_mod.Oracle(h, g, D, Da)
     got = np.concatenate([dm.process(iq[:20002]), dm.process(iq[20002:])])
     want = np.concatenate([o.process(iq[:20002]), o.process(iq[20002:])])
     assert got.size == want.size
-    assert scaled_err(got, want) <= TOL * max(1.0, float(np.abs(g).sum()))
+    assert scaled_err(got, want) <= TOL
     dm.close()
+
+
+def test_audio_taps_of_large_absolute_sum_scale_the_discriminators_last_ulps(pkg, oracle_mod):
+    """Why the tolerance presupposes an audio filter of about unit gain: K1 / K2 and the conjugate product are bit-exact in these kernels,
+    so the ONLY difference to the oracle is the device's own atan2 against libm's (<= 8e-7 rad, DESIGN.md "Frozen spec"), and an audio
+    filter multiplies that by up to sum|g|.  With 256 random audio taps of absolute sum 13 the audio agrees to 8e-7 x 13 = 1.04e-5 — the
+    discriminator's budget scaled by the filter, nothing else: the same bytes through the same handle with the taps divided by their absolute
+    sum agree to the plain tolerance, and the two outputs are the same numbers up to that factor."""
+    rng = np.random.default_rng(266)
+    h = (rng.standard_normal(256) / 16.0).astype(np.float32)
+    g = (rng.standard_normal(256) / 16.0).astype(np.float32)
+    G = float(np.abs(g.astype(np.float64)).sum())
+    assert 10.0 < G < 16.0
+    iq = pkg.make_iq(1, 30000, mode="fm", first_id=9)[0]
+    dm, _, _ = _demod(pkg, h=h, g=g)
+    got = dm.process(iq)
+    dm.close()
+    want = oracle_mod.Oracle(h, g).process(iq)
+    assert scaled_err(got, want) <= 8e-7 * G + 1e-6             # the discriminator's last ulps times the filter's absolute sum
+    gn = (g.astype(np.float64) / G).astype(np.float32)
+    dm, _, _ = _demod(pkg, h=h, g=gn)
+    got_n = dm.process(iq)
+    dm.close()
+    assert scaled_err(got_n, oracle_mod.Oracle(h, gn).process(iq)) <= TOL
 
 
 def test_batch_of_streams_matches_per_stream_oracle(pkg, oracle_mod):
@@ -177,9 +204,9 @@ def test_device_resident_batch_full_size_config3(pkg, oracle_mod, bit_exact):
     assert n == 4800
     assert dm.kernel_name.startswith("fast-s" if bit_exact else "fast-q"), dm.kernel_name
     got = audio.cpu().numpy()
-    for s in (0, 5, 15, 16, 255):
+    for s in list(range(16)) + [16, 255]:                       # every distinct row, and two of the copies
         want = oracle_mod.Oracle(h, g).process(iq_host[s])
-        assert scaled_err(got[s], want) <= TOL
+        assert scaled_err(got[s], want) <= TOL, s
     # identical input rows give bit-identical output rows wherever they sit in the batch
     assert np.array_equal(got[:16].view(np.uint32), got[240:].view(np.uint32))
     # two halves == one shot, bitwise
@@ -480,3 +507,58 @@ def test_zero_copy_small_calls_bitwise_equal_staged_path(pkg, monkeypatch):
         dm.close()
     assert outs[0].size > 2000
     assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+
+
+def test_matrix_pipe_kernel_at_the_edge_of_its_tap_rule(pkg, oracle_mod):
+    """Channel taps with sum|h| = 1.9 |sum h| (design Q's performance rule admits up to 2): a low-pass with deep negative side lobes — the
+    difference of two windowed sincs.  Partial sums run at twice the output's magnitude, so the guard meets more outputs; carriers, noise,
+    constant and counter rows all against the oracle at the plain tolerance, on the matrix-pipe kernel."""
+    wide, narrow = pkg.lowpass_taps(64, 0.055).astype(np.float64), pkg.lowpass_taps(64, 0.012).astype(np.float64)
+    lo, hi = 0.0, 3.0
+    for _ in range(60):                                         # h = (1 + b) wide - b narrow: sum h = 1, sum|h| grows with b
+        b = 0.5 * (lo + hi)
+        ratio = np.abs((1 + b) * wide - b * narrow).sum()
+        lo, hi = (b, hi) if ratio < 1.9 else (lo, b)
+    h = ((1 + lo) * wide - lo * narrow).astype(np.float32)
+    ratio = float(np.abs(h.astype(np.float64)).sum() / abs(h.astype(np.float64).sum()))
+    assert 1.85 <= ratio <= 1.95, ratio
+    g = pkg.default_config(64)[1]
+    ns, n = 264, 48000
+    rows = np.concatenate([pkg.make_iq(6, n, mode="fm", first_id=60), pkg.make_iq(4, n, mode="random", first_id=70),
+                           pkg.make_iq(1, n, mode="const", first_id=80), pkg.make_iq(1, n, mode="counter", first_id=90)])
+    iq = np.tile(rows, (ns // 12, 1))
+    with pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=ns, max_bytes_per_call=2 * n)) as dm:
+        got = np.concatenate([dm.process_batch(iq[:, :n]), dm.process_batch(iq[:, n:])], axis=1)
+        assert dm.kernel_name.startswith("fast-q"), dm.kernel_name
+        st = dm.q_guard()
+    assert st["guard_r"] > 6.0 and st["lanes"] > 0, st           # (the BASELINE taps: 4.7)
+    for s in range(12):
+        assert scaled_err(got[s], oracle_mod.Oracle(h, g).process(rows[s])) <= TOL, s
+    assert np.array_equal(got[:12].view(np.uint32), got[12:24].view(np.uint32))
+
+
+def test_configs3_share_with_overlapped_calls_against_the_oracle(pkg, oracle_mod):
+    """BASELINE configs[3], one GPU's share (512 streams x 480 000 B) as the bench makes its calls: SDRFM_F_OVERLAP, two audio buffers in turn,
+    three input buffers.  Every distinct row (48 carriers, 16 rows of noise) of all three calls against the oracle's running stream."""
+    import torch
+    ns, nsamp, nd = 512, 240000, 64
+    h, g = pkg.default_config(64)
+    host = [np.concatenate([pkg.make_iq(48, nsamp, mode="fm", first_id=5000 + 100 * b), pkg.make_iq(16, nsamp, mode="random", first_id=5050 + 100 * b)])
+            for b in range(3)]
+    dev = [torch.from_numpy(np.tile(x, (ns // nd, 1))).cuda() for x in host]
+    audio = [torch.zeros((ns, 4800), dtype=torch.float32, device="cuda") for _ in range(3)]
+    torch.cuda.synchronize()
+    names = []
+    with pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=ns)) as dm:
+        for b in range(3):
+            assert dm.process_batch_device(dev[b], audio[b], overlap=True) == 4800
+            names.append(dm.kernel_name)
+        dm.flush()
+        dm.synchronize()
+    assert all(n.startswith("fast-q") for n in names) and "overlapped" in names[1] and "overlapped" in names[2], names
+    got = np.concatenate([a.cpu().numpy() for a in audio], axis=1)
+    for s in range(nd):
+        want = oracle_mod.Oracle(h, g).process(np.concatenate([x[s] for x in host]))
+        assert scaled_err(got[s], want) <= TOL, s
+    for rep in range(1, ns // nd):
+        assert np.array_equal(got[nd * rep:nd * rep + nd].view(np.uint32), got[:nd].view(np.uint32)), rep
