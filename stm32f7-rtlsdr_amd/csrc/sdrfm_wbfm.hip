@@ -61,6 +61,8 @@ struct WParams {
 #ifdef SDRFM_DEV
   unsigned long long* dbg;      // development build: 256 words per wave of phase time stamps (nullptr = off)
   uint32_t dbg_light;           // ... only the entry / exit times (no per-phase waits: the kernel runs at full speed)
+  uint32_t ablate;              // timing experiments, WRONG results (SDRFM_WBFM_ABLATE): 1 = the FIR reads 3 of its 8 step groups from LDS and
+                                // re-uses registers for the rest — the LDS traffic "several steps per lane" would leave (2.75 group reads per step)
 #endif
   uint32_t P, Tg, L, M, HD, dcap;
   uint32_t N;                   // new IQ samples per stream
@@ -820,6 +822,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
       const wf4_t* gp = group_of(Q - 1 - d);
+#ifdef SDRFM_DEV
+      if ((w.ablate & 1u) && d > 0) {                           // (timing experiment: groups Q-2, Q-3 re-use group Q-1's registers)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { xr[d][m] = xr[0][m]; xi[d][m] = xi[0][m]; }
+        continue;
+      }
+#endif
 #pragma unroll
       for (int m = 0; m < 4; ++m) { xr[d][m] = gp[m]; xi[d][m] = gp[4 + m]; }
     }
@@ -828,8 +837,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     for (int q = Q - 1; q >= 0; --q) {
       if (q - DEPTH >= 0) {
         const wf4_t* gp = group_of(q - DEPTH);
+#ifdef SDRFM_DEV
+        if ((w.ablate & 1u) && (q - DEPTH) % 3 != 1) {          // (timing experiment: only groups 4 and 1 are read here)
 #pragma unroll
-        for (int m = 0; m < 4; ++m) { xr[DEPTH][m] = gp[m]; xi[DEPTH][m] = gp[4 + m]; }
+          for (int m = 0; m < 4; ++m) { xr[DEPTH][m] = xr[DEPTH - 1][m]; xi[DEPTH][m] = xi[DEPTH - 1][m]; }
+        } else
+#endif
+        {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) { xr[DEPTH][m] = gp[m]; xi[DEPTH][m] = gp[4 + m]; }
+        }
       }
       const wf16_t tq = q >= 4 ? th[Q - 1 - q] : tl[3 - q];
 #pragma unroll
@@ -1203,6 +1220,7 @@ static int wenqueue(sdrfm_wbfm* h, const uint8_t* d_iq, size_t iq_stride, uint32
   w.dbuf = h->d_dbuf; w.p = h->d_p; w.g = h->d_g; w.pperm = h->d_pperm;
 #ifdef SDRFM_DEV
   w.dbg = nullptr; w.dbg_light = 0;
+  w.ablate = getenv("SDRFM_WBFM_ABLATE") ? (uint32_t)atoi(getenv("SDRFM_WBFM_ABLATE")) : 0u;
 #endif
   w.swap_pct = 40u;   // measured on configs[4]: swap at 0 / 30 / 35 / 40 / 45 / 50 / 60 / 100 % -> 106 / 102 / 101 / 100 / 100.6 / 101 / 104 / 104.5 us
   w.inv_L32 = c.resamp_up >= 2 ? (uint32_t)((1ull << 32) / c.resamp_up) + 1u : 0u;

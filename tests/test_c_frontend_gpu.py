@@ -67,7 +67,7 @@ def test_c_views_program_matches_oracles(pkg, oracle_mod, tmp_path):
     assert scaled_err(got0, want[0]) <= TOL
 
 
-@pytest.mark.parametrize("transport", ["rccl", "peer-copy"])
+@pytest.mark.parametrize("transport", ["rccl", "peer-copy", "rccl-overlap"])
 def test_c_multi_gpu_host_on_the_devices_present(pkg, oracle_mod, tmp_path, transport):
     """examples/multi_gpu_main.c: ONE C process, one sdrfm_t per device, contiguous stream shards (sdrfm_shard_range), fan-out of the IQ
     batch and fan-in of the audio over RCCL send / recv (or peer copies).  Runs on however many devices the box has (the GPU box:
@@ -88,20 +88,25 @@ def test_c_multi_gpu_host_on_the_devices_present(pkg, oracle_mod, tmp_path, tran
     (tmp_path / "h.f32").write_bytes(h.tobytes())
     (tmp_path / "g.f32").write_bytes(g_.tobytes())
     out = tmp_path / "audio.f32"
-    cmd = [exe, str(tmp_path / "iq.u8"), str(tmp_path / "h.f32"), str(tmp_path / "g.f32"), str(ns), str(2 * nsamp), "0", str(out), "--reps", "2"]
+    reps = 3 if transport == "rccl-overlap" else 2
+    cmd = [exe, str(tmp_path / "iq.u8"), str(tmp_path / "h.f32"), str(tmp_path / "g.f32"), str(ns), str(2 * nsamp), "0", str(out), "--reps", str(reps)]
     if transport == "peer-copy":
         cmd.append("--peer-copy")
+    if transport == "rccl-overlap":                             # SDRFM_F_OVERLAP calls, two buffers per device, the fan-in one call behind
+        cmd.append("--overlap")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr
     info = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert info["n_gpus"] == torch.cuda.device_count() and info["n_streams"] == ns and info["n_audio"] == 480
     assert sum(c for _, c in info["shards"]) == ns and info["kernel"].startswith("fast-q")
+    assert ("overlapped" in info["kernel"]) == (transport == "rccl-overlap"), info
     got = np.fromfile(out, dtype=np.float32).reshape(ns, 480)
-    # two repetitions ran on carried state: the second call's audio is what was written (streams continue: feed the oracle twice)
+    # the repetitions ran on carried state: the last call's audio is what was written (streams continue: feed the oracle as often)
     for s_ in range(8):
         o = oracle_mod.Oracle(h, g_)
-        o.process(iq[s_])
+        for _ in range(reps - 1):
+            o.process(iq[s_])
         assert scaled_err(got[s_], o.process(iq[s_])) <= TOL, s_
     for rep in range(1, ns // 8):
         assert np.array_equal(got[8 * rep:8 * rep + 8].view(np.uint32), got[:8].view(np.uint32)), rep
