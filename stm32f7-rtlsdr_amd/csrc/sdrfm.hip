@@ -1728,15 +1728,18 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
     float q_R = 0.0f, q_A = 4.0f;
     const bool q_guard_ok = sdrfm_q_guard(hc, cfg->fir_taps, gc, cfg->audio_taps, &q_R, &q_A) == 0 &&
                             (double)q_R <= 0.125 * 127.5 * std::fabs(q_sum) && q_A > 3.0f;
-    if (!(cfg->flags & SDRFM_CFG_BIT_EXACT) && cfg->fir_decim == SDRFM_Q_D && cfg->audio_taps == SDRFM_Q_TA &&
-        cfg->audio_decim == SDRFM_Q_DA && cfg->fir_taps <= SDRFM_Q_TP && q_abs <= 2.0 * std::fabs(q_sum) && q_guard_ok) {
-      int8_t* tab = (int8_t*)malloc(SDRFM_Q_SPARSE_CHUNKS(SDRFM_Q_D) * SDRFM_Q_DIGITS * 64 * 16);
+    // instances: (D, Da) = (10, 5) — the 2.4 MS/s front end of BASELINE —, (8, 8) and (16, 5): the 2.048 and 3.2 MS/s rates
+    // RTLSDR_set_sample_rate accepts (usbh_rtlsdr.c:676-678); 32 audio taps each
+    const size_t q_tab_bytes = (size_t)SDRFM_Q_SPARSE_CHUNKS(cfg->fir_decim) * SDRFM_Q_DIGITS * 64 * 16;
+    if (!(cfg->flags & SDRFM_CFG_BIT_EXACT) && sdrfm_q_geometry_ok(cfg->fir_decim, cfg->audio_decim) && cfg->audio_taps == SDRFM_Q_TA &&
+        cfg->fir_taps <= SDRFM_Q_TP && cfg->fir_taps <= 9 * cfg->fir_decim && q_abs <= 2.0 * std::fabs(q_sum) && q_guard_ok) {
+      int8_t* tab = (int8_t*)malloc(q_tab_bytes);
       float qs = 0.f, qc = 0.f, hpad[SDRFM_Q_TP];
       uint32_t c0 = 0;
       for (uint32_t k = 0; k < SDRFM_Q_TP; ++k) hpad[k] = k < cfg->fir_taps ? hc[k] : 0.0f;
       if (tab && sdrfm_q_build(hc, cfg->fir_taps, cfg->fir_decim, tab, &qs, &qc, &c0) == 0 &&
-          hipMalloc(&h->d_qA, SDRFM_Q_SPARSE_CHUNKS(SDRFM_Q_D) * SDRFM_Q_DIGITS * 64 * 16) == hipSuccess &&
-          hipMemcpy(h->d_qA, tab, SDRFM_Q_SPARSE_CHUNKS(SDRFM_Q_D) * SDRFM_Q_DIGITS * 64 * 16, hipMemcpyHostToDevice) == hipSuccess &&
+          hipMalloc(&h->d_qA, q_tab_bytes) == hipSuccess &&
+          hipMemcpy(h->d_qA, tab, q_tab_bytes, hipMemcpyHostToDevice) == hipSuccess &&
           hipMalloc(&h->d_hpad, sizeof(hpad)) == hipSuccess && hipMemcpy(h->d_hpad, hpad, sizeof(hpad), hipMemcpyHostToDevice) == hipSuccess &&
           hipMalloc(&h->d_hist_q[0], 2 * SDRFM_Q_TP * ns) == hipSuccess && hipMalloc(&h->d_hist_q[1], 2 * SDRFM_Q_TP * ns) == hipSuccess &&
           hipMalloc(&h->d_qstat, 2 * sizeof(unsigned int)) == hipSuccess && hipMemset(h->d_qstat, 0, 2 * sizeof(unsigned int)) == hipSuccess &&
@@ -1745,7 +1748,8 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
         memset(h->q_adapt_host, 0, 64);
         h->q_scale = qs; h->q_cst = qc; h->q_c0 = c0 > 1 ? 1 : c0;
         h->q_guard_r = q_R; h->q_guard_a = q_A;
-        h->q_nslot = 5; h->q_waves_per_cu = 12;
+        h->q_nslot = sdrfm_q_default_nslot(cfg->fir_decim); h->q_waves_per_cu = 12;
+        { const uint32_t lb = sdrfm_q_lds_bytes(h->q_nslot, cfg->fir_decim, cfg->audio_decim); if (lb && 163840u / lb < h->q_waves_per_cu) h->q_waves_per_cu = 163840u / lb; }   // (D = 16: 11 one-wave workgroups fit a CU's LDS)
 #ifdef SDRFM_DEV
         if (const char* e = getenv("SDRFM_Q_NSLOT")) h->q_nslot = (uint32_t)atoi(e);
         if (const char* e = getenv("SDRFM_Q_WAVES_PER_CU")) h->q_waves_per_cu = (uint32_t)atoi(e);
@@ -1756,7 +1760,7 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
 #endif
         h->n_cu = (uint32_t)prop.multiProcessorCount;
         snprintf(h->fast_q_name, sizeof(h->fast_q_name), "fast-q T%u D%u Ta%u Da%u %s", cfg->fir_taps, cfg->fir_decim, cfg->audio_taps,
-                 cfg->audio_decim, sdrfm_q_kernel_symbol(h->q_c0, h->q_nslot));
+                 cfg->audio_decim, sdrfm_q_kernel_symbol(h->q_c0, h->q_nslot, cfg->fir_decim, cfg->audio_decim));
       } else if (h->d_qA) { (void)hipFree(h->d_qA); h->d_qA = nullptr; }
       free(tab);
     }
@@ -1972,7 +1976,7 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
   // hands over holds no output computed from the (inexpressible in bytes) zero history.  It also serves one dongle's second of IQ
   // (BASELINE configs[1]: 1875 steps cut into two-step runs, 5.7 us against 9.6 - 13 us for design B).
   const uint32_t q_steps = (M + SDRFM_Q_STEP_OUT - 1) / SDRFM_Q_STEP_OUT;
-  const bool q_fit = h->d_qA && A > 0 && h->phase_x == 0 && h->phase_d == 0 && (N % (SDRFM_Q_D * SDRFM_Q_DA * 8u)) == 0 &&
+  const bool q_fit = h->d_qA && A > 0 && h->phase_x == 0 && h->phase_d == 0 && (N % (c.fir_decim * c.audio_decim * 8u)) == 0 &&
                     ((uintptr_t)d_iq % 16 == 0) && (iq_stride % 16 == 0) && N < (1u << 30) && M >= c.audio_taps &&
                     (h->n_seen + 1 >= c.fir_taps || M >= y_aff + c.audio_taps) &&
                     (uint64_t)c.n_streams * q_steps >= 2ull * h->n_cu;
@@ -1984,7 +1988,7 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
   // What the flag asks of the caller is checked where that is cheap: a call whose rows overlap the previous call's rows (one buffer used
   // for every call) or whose audio buffer is the one the previous overlapped call may still be writing runs as if the flag were absent.
   const bool ovl = q_ok && (call_flags & SDRFM_F_OVERLAP) && h->prev_iq && h->n_seen + 1 >= c.fir_taps &&
-                   h->prev_nbytes >= 2u * 10u * SDRFM_Q_STEP_OUT && (h->prev_nbytes % 16 == 0) && ((uintptr_t)h->prev_iq % 16 == 0) &&
+                   h->prev_nbytes >= 2u * c.fir_decim * SDRFM_Q_STEP_OUT && (h->prev_nbytes % 16 == 0) && ((uintptr_t)h->prev_iq % 16 == 0) &&
                    (h->prev_stride % 16 == 0) &&
                    !rows_overlap(h->prev_iq, h->prev_stride, h->prev_nbytes, d_iq, iq_stride, nbytes, c.n_streams) &&
                    !(h->prev_ovl_audio && rows_overlap(reinterpret_cast<const uint8_t*>(h->prev_ovl_audio), h->prev_ovl_audio_stride * sizeof(float),
@@ -2048,13 +2052,13 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
     if (runs > q_steps / min_steps) runs = q_steps / min_steps;
     if (runs < 1) runs = 1;
     q.runs = runs;
-    HIP_TRY(sdrfm_q_launch(q, h->q_c0, h->q_nslot, qs), SDRFM_FAIL);
+    HIP_TRY(sdrfm_q_launch(q, h->q_c0, h->q_nslot, c.fir_decim, c.audio_decim, qs), SDRFM_FAIL);
     if (ovl) h->ovl_pending[k] = true;
     h->prev_ovl_audio = ovl ? d_audio : nullptr; h->prev_ovl_audio_stride = audio_stride; h->prev_ovl_audio_n = A;
     h->yprev_exact = false; h->hist_q_valid = true;
     // the stream's content decides too (see the handle): sampled repair passes against sampled audio stages over the last window of calls
     // (the word lags by the calls still in flight: the ratio errs on design Q's side)
-    h->q_stages_sampled += ((uint64_t)c.n_streams * runs * ((q_steps / runs + 4) / 5) + SDRFM_Q_ADAPT_SAMPLE - 1) / SDRFM_Q_ADAPT_SAMPLE;
+    h->q_stages_sampled += ((uint64_t)c.n_streams * runs * ((q_steps / runs + c.audio_decim - 1) / c.audio_decim) + SDRFM_Q_ADAPT_SAMPLE - 1) / SDRFM_Q_ADAPT_SAMPLE;
     if (h->q_adapt_dev && ++h->q_calls_in_window >= SDRFM_Q_ADAPT_WINDOW) {
       const uint32_t passes = *reinterpret_cast<volatile unsigned int*>(h->q_adapt_host);
       if ((uint64_t)(passes - h->q_passes_mark) * 4u > h->q_stages_sampled - h->q_stages_mark) h->q_backoff = SDRFM_Q_ADAPT_BACKOFF;

@@ -48,20 +48,24 @@ struct SdrfmQParams {
 };
 
 // geometry the host needs
-#define SDRFM_Q_D 10u            /* FIR decimation this kernel is built for */
-#define SDRFM_Q_TA 32u           /* audio taps */
-#define SDRFM_Q_DA 5u            /* audio decimation */
+#define SDRFM_Q_D 10u            /* FIR decimation of the BASELINE front end (2.4 MS/s); instances exist for D = 8 (2.048 MS/s) and 16 (3.2 MS/s) too */
+#define SDRFM_Q_TA 32u           /* audio taps (every instance) */
+#define SDRFM_Q_DA 5u            /* audio decimation of the BASELINE front end */
 #define SDRFM_Q_STEP_OUT 128u    /* decimated outputs per wave step (16 columns x 8 outputs) */
 #define SDRFM_Q_ADAPT_SAMPLE 8u  /* one wave in this many reports its repair passes to the host */
 #define SDRFM_Q_TP 64u           /* the repair path's chain length: channel taps padded with zeros to this many (design Q serves T <= 64) */
 
-// LDS bytes of one wave for a ring of `nslot` KiB (nslot = 5, 10 or 15)
-uint32_t sdrfm_q_lds_bytes(uint32_t nslot);
+// is there an instance for FIR decimation d and audio decimation da (with SDRFM_Q_TA audio taps)?  its ring size in KiB
+bool sdrfm_q_geometry_ok(uint32_t d, uint32_t da);
+uint32_t sdrfm_q_default_nslot(uint32_t d);
+// LDS bytes of one wave for a ring of `nslot` KiB
+uint32_t sdrfm_q_lds_bytes(uint32_t nslot, uint32_t d, uint32_t da);
 // one-wave workgroups of this variant the runtime says a CU can hold at once (0 = unknown)
-int sdrfm_q_blocks_per_cu(uint32_t first_chunk, uint32_t nslot);
+int sdrfm_q_blocks_per_cu(uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da);
 // Enqueue one call: grid = n_streams * runs one-wave workgroups.  first_chunk = 0 or 1 (from sdrfm_q_build).
 // Returns hipSuccess or the launch error.
-hipError_t sdrfm_q_launch(const SdrfmQParams& p, uint32_t first_chunk, uint32_t nslot, hipStream_t stream);
+hipError_t sdrfm_q_launch(const SdrfmQParams& p, uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da, hipStream_t stream);
+const char* sdrfm_q_kernel_symbol(uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da);
 // yprev[s] = the definition's y[-1] of stream s from the SDRFM_Q_TP raw samples in hist_q (a bit-exact kernel takes over from design Q)
 hipError_t sdrfm_q_fix_yprev(const uint8_t* hist_q, const float* hpad, float2* yprev, uint32_t n_streams, hipStream_t stream);
 // One-time per-process kernel attribute set-up (dynamic LDS above 64 KiB is never needed; kept for symmetry): returns 0.

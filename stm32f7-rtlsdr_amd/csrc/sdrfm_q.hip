@@ -24,7 +24,7 @@
  *   --> y = fma(f32(S0 + (S1 << 8)), q, fma(f32(S2), 65536 q, 0.5 sum h)): lane (n, g) holds (I, Q) of outputs 8 n + 2 g, +1
  *   --> y[m-1] of the lane's first output from lane - 16 (ds_bpermute) --> K3 twice (scalar code: packed f32 instructions stall
  *       the matrix pipe, profiles/ubench_r03) --> d's into an LDS buffer
- *   every 5 steps (640 d's = 128 audio outputs): K4, two consecutive outputs per lane from 20 aligned 8-byte reads --> parked in LDS
+ *   every DA = 5 steps (640 d's = 128 audio outputs): K4, two consecutive outputs per lane from 20 aligned 8-byte reads --> parked in LDS
  *   after the run's last step: the parked outputs --> HBM, 8 bytes per lane (no store inside the loop: it would count in vmcnt)
  *
  * A run that does not start its stream first recomputes the step before it ("warm-up": only its last four blocks are fetched
@@ -49,20 +49,34 @@ __device__ void q_raw_buffer_load_lds(qi4_t rsrc, __attribute__((address_space(3
 
 namespace {
 
-constexpr int QD = (int)SDRFM_Q_D, QTA = (int)SDRFM_Q_TA, QDA = (int)SDRFM_Q_DA;
-constexpr int NCH = QD / 2;                     // 64-byte pieces of a window (two blocks of 16 D bytes): one ds_read_b128 per lane each
-constexpr int NSC = (int)SDRFM_Q_SPARSE_CHUNKS(SDRFM_Q_D);   // K-chunks of 128 window bytes: one v_smfmac_i32_16x16x128_i8 per digit each
-constexpr int BLKB = 16 * QD;                   // bytes per block of 8 outputs
-constexpr int STEPB = 16 * BLKB;                // bytes per step
-constexpr int PRE = BLKB;                       // pre-halo: the block before the ring's first byte
+constexpr int QTA = (int)SDRFM_Q_TA;            // audio taps (every instance)
 constexpr int DB0 = 128;                        // d buffer: word DB0 + sigma = first d of the current audio stage
-constexpr int DBW = DB0 + 656;                  // words
 constexpr int ABS = 4;                          // audio stages (128 outputs each) parked in LDS before they are stored
 constexpr int ABW = 128 * ABS;                  // words, after the d buffer
 constexpr int FLW = 64 + 2;                     // words, after the parked audio: up to 128 two-byte entries of lanes waiting for the repair path, two counters
 constexpr int QTP = (int)SDRFM_Q_TP;            // the repair path's chain length (taps padded with zeros)
-constexpr int RWIN = QTP + 2 * QD;              // samples under the three outputs y[m0 - 1], y[m0], y[m0 + 1] a repaired lane recomputes
-static_assert(QTP % 4 == 0 && (2 * QD) % 4 == 0, "the repair path loads whole groups of four samples, none of which straddles the call's first sample");
+// geometry of an instance: FIR decimation D (even), audio decimation DA
+template <int D, int DA>
+struct QGeo {
+  static constexpr int NCH = D / 2;             // 64-byte pieces of a window (two blocks of 16 D bytes): one ds_read_b128 per lane each
+  static constexpr int NSC = (D + 3) / 4;       // K-chunks of 128 window bytes: one v_smfmac_i32_16x16x128_i8 per digit each
+  static constexpr int BLKB = 16 * D;           // bytes per block of 8 outputs
+  static constexpr int STEPB = 16 * BLKB;       // bytes per step
+  static constexpr int PRE = BLKB;              // pre-halo: the block before the ring's first byte
+  static constexpr int DBW = DB0 + 128 * DA + 16;   // words of the d buffer: history, one audio stage (128 outputs = DA steps), slack
+  static constexpr int RWIN = QTP + 2 * D;      // samples under the three outputs y[m0 - 1], y[m0], y[m0 + 1] a repaired lane recomputes
+  // Steps that are whole KiB chunks (D = 8, 16): the ring is two steps, refilled a step at a time, and — because a block is then 128 or 256
+  // bytes, so that the 16 window reads of a lane group would all fall on the same LDS banks — kept SWIZZLED: ring byte L sits at
+  // L ^ (((L / BLKB) & 7) << 4).  The LDS-DMA writes lane l's 16 bytes at chunk + 16 l whatever they are, so the swizzle is applied to the
+  // GLOBAL offset a lane fetches (the pieces of a chunk are permuted within the chunk: same lines, same traffic).  D = 10: steps of 2.5
+  // chunks, blocks of 160 bytes: conflict-free as they are (the layout of rounds 3 - 4, untouched).
+  static constexpr bool ALIGNED = (STEPB % 1024) == 0;
+  static constexpr int CS = STEPB / 1024;       // (ALIGNED) chunks per step
+  static constexpr int WB = (STEPB - 5 * BLKB) & ~127;   // a warm-up step needs its bytes from here on (its last four blocks and the one before them, whole lines)
+  static_assert(QTP % 4 == 0 && (2 * D) % 4 == 0, "the repair path loads whole groups of four samples, none of which straddles the call's first sample");
+  static_assert(QTP + 2 * D <= 96, "the tap table of the repair path sits below the d's a warm-up step keeps");
+  static_assert(D % 2 == 0 && D <= 16 && (ALIGNED || D == 10), "geometries the ring logic is written for");
+};
 #ifndef SDRFM_Q_AUX
 #define SDRFM_Q_AUX 2   // cache policy of the ring's fetches: 2 = nt (streamed once; measured 0.4-1 us per launch better than the default policy)
 #endif
@@ -104,10 +118,14 @@ __device__ __forceinline__ void wait_vmcnt() {
 #define Q_PHASE(i) do { } while (0)
 #endif
 
-template <int C0, int NSLOT>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_mfir(SdrfmQParams p) {
+template <int C0, int NSLOT, int D, int DA>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16 ? 3 : 4))) k_mfir(SdrfmQParams p) {
+  using G = QGeo<D, DA>;
+  constexpr int QD = D, QDA = DA, NCH = G::NCH, NSC = G::NSC, BLKB = G::BLKB, STEPB = G::STEPB, PRE = G::PRE, DBW = G::DBW, RWIN = G::RWIN;
+  constexpr bool ALIGNED = G::ALIGNED;
+  constexpr int CS = G::CS, WB = G::WB;
   constexpr int RINGB = NSLOT * 1024;
-  static_assert(RINGB % (2 * STEPB) == 0 && NSLOT >= 5 && NSLOT - 4 < 16, "ring: whole pairs of steps");
+  static_assert(RINGB % (2 * STEPB) == 0 && (ALIGNED ? NSLOT == 2 * CS : (NSLOT >= 5 && NSLOT - 4 < 16)), "ring: whole pairs of steps");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* const db = reinterpret_cast<float*>(smem + PRE + RINGB);
   float* const ab = db + DBW;                                   // parked audio outputs
@@ -160,16 +178,32 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
   uint32_t hi = (uint32_t)STEPB * (uint32_t)s1;                 // bytes of the row this run may touch: [.., hi)
   if (hi > 2u * p.N) hi = 2u * p.N;
   const qi4_t rsrc = {(int)(unsigned)gaddr, (int)(unsigned)(gaddr >> 32), (int)hi, 0x00020000};
-  int vpos = STEPB * ks + 16 * lane;                            // this lane's byte offset in the row for the next chunk
+  // (ALIGNED) the lane's 16 bytes of a chunk, swizzled: the piece that belongs at chunk + 16 lane of the ring is logical piece
+  // lane ^ key, key = the block's index mod 8 (a chunk holds 1024 / BLKB blocks; D = 16: two variants, by the parity of the chunk)
+  const int lsw0 = ALIGNED ? ((16 * lane) ^ (((((16 * lane) / BLKB)) & 7) << 4)) : 16 * lane;
+  const int lsw1 = ALIGNED ? ((16 * lane) ^ (((((1024 + 16 * lane) / BLKB)) & 7) << 4)) : 16 * lane;   // odd chunks (differs for BLKB = 256 only)
+  int vpos = STEPB * ks + (ALIGNED ? 0 : 16 * lane);            // row offset of the next chunk (ALIGNED: without the lane's part)
   auto slot_ptr = [&](int slot) { return (__attribute__((address_space(3))) void*)(smem + PRE + 1024 * slot); };
-  // prologue: NSLOT chunks.  A warm-up step needs only its last four blocks and the block before them (bytes >= 1664 of the step,
+  auto lsw = [&](int chunk) { return (BLKB == 256 && (chunk & 1)) ? lsw1 : lsw0; };
+  // prologue: NSLOT chunks.  A warm-up step needs only its last four blocks and the block before them (bytes >= WB of the step,
   // rounded to a line): the pieces before that are switched off by an out-of-range offset (the instruction still counts).  The
-  // first three chunks (what the first step waits for) go out first, then the requests for the L2-resident tables, then the rest of
+  // first step's chunks (what the first step waits for) go out first, then the requests for the L2-resident tables, then the rest of
   // the ring: the opening burst of all waves' first steps is what every wave's start waits behind.
-  if (from_prev) {
+  if constexpr (ALIGNED) {
+    // the first step (a warm-up step when `warm`; under SDRFM_F_OVERLAP the last step of the PREVIOUS call's row for the stream's first run)
+    const unsigned long long pa = from_prev ? (unsigned long long)(p.iq_prev + (size_t)stream * p.iq_prev_stride) + 2ull * p.N_prev - STEPB : gaddr;
+    const qi4_t rfirst = {(int)(unsigned)pa, (int)(unsigned)(pa >> 32), from_prev ? STEPB : (int)hi, 0x00020000};
+    const int vfirst = from_prev ? 0 : vpos;
+#pragma unroll
+    for (int q = 0; q < CS; ++q) {
+      const int off = 1024 * q + lsw(q);
+      q_raw_buffer_load_lds(rfirst, slot_ptr(q), 16, (warm && off < WB) ? OOBV : vfirst + off, 0, 0, SDRFM_Q_AUX);
+    }
+  } else if (from_prev) {
     // step -1 = the last STEPB bytes of the previous call's row: its bytes >= 1664 come from there (lanes 40.. of chunk 1, lanes ..31
     // of chunk 2), the rest of chunk 2 is the head of this call's row.  Lanes are switched off by EXEC here, not by an out-of-range
     // offset, so that no lane's piece is written twice.
+    static_assert(ALIGNED || WB == 1664, "the lane numbers below");
     const unsigned long long pa = (unsigned long long)(p.iq_prev + (size_t)stream * p.iq_prev_stride) + 2ull * p.N_prev - STEPB;
     const qi4_t rprev = {(int)(unsigned)pa, (int)(unsigned)(pa >> 32), STEPB, 0x00020000};
     q_raw_buffer_load_lds(rsrc, slot_ptr(0), 16, OOBV, 0, 0, SDRFM_Q_AUX);
@@ -213,12 +247,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
   const float hz1 = lane < 2 * QD ? p.hpad[2 * QD - 1 - lane] : 0.0f;
   __builtin_amdgcn_sched_barrier(0);
   asm volatile("" ::: "memory");
+  if constexpr (ALIGNED) {                                      // the second step of the ring (under SDRFM_F_OVERLAP: step 0 of this call's row for the stream's first run)
 #pragma unroll
-  for (int q = 3; q < NSLOT; ++q) q_raw_buffer_load_lds(rsrc, slot_ptr(q & ~3), 16, vpos + 1024 * (q & ~3), 0, 1024 * (q & 3), SDRFM_Q_AUX);
+    for (int q = 0; q < CS; ++q) q_raw_buffer_load_lds(rsrc, slot_ptr(CS + q), 16, vpos + STEPB + 1024 * q + lsw(CS + q), 0, 0, SDRFM_Q_AUX);
+  } else {
+#pragma unroll
+    for (int q = 3; q < NSLOT; ++q) q_raw_buffer_load_lds(rsrc, slot_ptr(q & ~3), 16, vpos + 1024 * (q & ~3), 0, 1024 * (q & 3), SDRFM_Q_AUX);
+  }
   vpos += 1024 * NSLOT;
   if (!warm) {
-    if (lane < HT) *reinterpret_cast<unsigned short*>(smem + PRE - 2 * HT + 2 * lane) = hb0;           // -> end of the pre-halo
-    if (lane + 64 < HT) *reinterpret_cast<unsigned short*>(smem + PRE - 2 * HT + 2 * (lane + 64)) = hb1;
+    // -> end of the pre-halo (the block before the ring: block index -1, swizzle key 7 where the ring is swizzled)
+    constexpr int HSW = ALIGNED ? 0x70 : 0;
+    if (lane < HT) *reinterpret_cast<unsigned short*>(smem + ((PRE - 2 * HT + 2 * lane) ^ HSW)) = hb0;
+    if (lane + 64 < HT) *reinterpret_cast<unsigned short*>(smem + ((PRE - 2 * HT + 2 * (lane + 64)) ^ HSW)) = hb1;
     if (lane < QTA - 1) db[DB0 + sigma - (QTA - 1) + lane] = hd0;
   }
   db[lane] = hz0;
@@ -229,6 +270,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
   int osm = warm ? -1 : 0;                                      // owned steps in the d buffer since the last audio stage
   int mbase = 128 * s0;                                         // output index of d-buffer word DB0 + sigma
   const int baddr = BLKB * n + 16 * g;                          // window of block n starts at PRE + ringoff - BLKB + BLKB n
+  // (ALIGNED) the same pieces through the swizzle: piece c of the window = ring bytes BLKB (n - 1) + 64 c + 16 g, .. + 16 (relative to the
+  // step): block n - 1 + (64 c + 16 g) / BLKB, key = that block's index mod 8 (a step is 16 blocks: the key does not depend on the step)
+  int rdoff[ALIGNED ? 2 * NSC : 1];
+  if constexpr (ALIGNED) {
+#pragma unroll
+    for (int c = 0; c < 2 * NSC; ++c) {
+      const int o = 64 * c + 16 * g, blk = n - 1 + o / BLKB;
+      rdoff[c] = BLKB * blk + ((o % BLKB) ^ ((blk & 7) << 4)) + PRE;
+    }
+  } else {
+    rdoff[0] = 0;
+  }
   const int srcaddr = 4 * (g > 0 ? lane - 16 : ((lane + 47) & 63));   // lane holding y[m-1] of this lane's first output
   const int dlane = 8 * n + 2 * g;
   const int ylast_step = ((int)p.M - 1) >> 7, ylast_lane = ((((int)p.M - 1) & 127) >> 3) + 16 * ((((int)p.M - 1) & 7) >> 1);
@@ -243,26 +296,48 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
 #ifdef SDRFM_Q_STAMPS
     const unsigned long long tw0 = __builtin_readcyclecounter();
 #endif
-    wait_vmcnt<NSLOT - 4>();                                    // this step's bytes have landed: everything but the NSLOT-4 youngest chunks
+    // this step's bytes have landed: everything but the youngest chunk of the 2.5-chunk steps' ring / but the next step's CS chunks
+    wait_vmcnt<(ALIGNED ? CS : NSLOT - 4)>();
     asm volatile("" ::: "memory");
 #ifdef SDRFM_Q_STAMPS
     t_wait += __builtin_readcyclecounter() - tw0;
     if (t_first == 0) t_first = __builtin_amdgcn_s_memrealtime();
 #endif
-    const unsigned char* wb = smem + baddr + ringoff;
+    if constexpr (ALIGNED) {
+      // The block before the step is ALWAYS read from the pre-halo: a step's half of the ring is refilled as soon as its window is in
+      // registers, so its last block — the next step's "block before" — is parked there first, every step (a copy of the block as it
+      // lies: its index, 15 or 31, and -1 share the swizzle key 7).
+      const int ro0 = n == 0 ? 0 : ringoff;
 #pragma unroll
-    for (int c = 2 * C0; c < 2 * NSC; ++c) dst[c - 2 * C0] = *reinterpret_cast<const qi4_t*>(wb + 64 * c);
-    if (ringoff + STEPB == RINGB) {                             // the next step starts the ring over: its pre-halo = the ring's last block
+      for (int c = 2 * C0; c < 2 * NSC; ++c) dst[c - 2 * C0] = *reinterpret_cast<const qi4_t*>(smem + rdoff[c] + (64 * c < BLKB ? ro0 : ringoff));
       if (lane < BLKB / 16) {
-        const qi4_t hcp = *reinterpret_cast<const qi4_t*>(smem + PRE + RINGB - BLKB + 16 * lane);
+        const qi4_t hcp = *reinterpret_cast<const qi4_t*>(smem + PRE + ringoff + STEPB - BLKB + 16 * lane);
         *reinterpret_cast<qi4_t*>(smem + 16 * lane) = hcp;
       }
       __builtin_amdgcn_wave_barrier();
+    } else {
+      const unsigned char* wb = smem + baddr + ringoff;
+#pragma unroll
+      for (int c = 2 * C0; c < 2 * NSC; ++c) dst[c - 2 * C0] = *reinterpret_cast<const qi4_t*>(wb + 64 * c);
+      if (ringoff + STEPB == RINGB) {                           // the next step starts the ring over: its pre-halo = the ring's last block
+        if (lane < BLKB / 16) {
+          const qi4_t hcp = *reinterpret_cast<const qi4_t*>(smem + PRE + RINGB - BLKB + 16 * lane);
+          *reinterpret_cast<qi4_t*>(smem + 16 * lane) = hcp;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
     }
     ringoff = (ringoff + STEPB == RINGB) ? 0 : ringoff + STEPB;
   };
   auto refill_step = [&](int k) {                               // step k's window is in registers: its slots are free, refill them
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (ALIGNED) {                                    // step k + 2 into the half of the ring step k occupied
+#pragma unroll
+      for (int q = 0; q < CS; ++q) q_raw_buffer_load_lds(rsrc, slot_ptr(slot + q), 16, vpos + 1024 * q + lsw(q), 0, 0, SDRFM_Q_AUX);
+      slot = slot ? 0 : CS;
+      vpos += STEPB;
+      return;
+    }
     if (k > 0 && !(k & 1)) {
       q_raw_buffer_load_lds(rsrc, slot_ptr(slot), 16, vpos, 0, 0, SDRFM_Q_AUX);
       vpos += 1024;
@@ -272,6 +347,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
     q_raw_buffer_load_lds(rsrc, slot_ptr(slot), 16, vpos, 0, 1024, SDRFM_Q_AUX);   // chunk numbers = 0 or 2 mod 5); offset:1024 moves both addresses
     slot = (slot + 2 >= NSLOT) ? slot + 2 - NSLOT : slot + 2;
     vpos += 2048;
+  };
+  // Kernel arguments that only rare branches and the epilogue need are read again from the argument segment there (scalar loads through
+  // an opaque pointer), not kept in scalar registers across the step loop: those are all taken, and every one more costs a reload per step.
+  typedef const __attribute__((address_space(4))) SdrfmQParams* KargPtr;
+  auto kargs = [&]() -> KargPtr {
+    KargPtr pp = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(pp));
+    return pp;
   };
   // The audio is not stored stage by stage: a store counts in vmcnt like the ring's fetches, and the next step's wait for "all but the
   // youngest fetches" then also waits for the stores' acknowledgement AND for the fetches issued before them — a full round trip through
@@ -283,7 +366,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
 #if defined(SDRFM_Q_ABLATE) && (SDRFM_Q_ABLATE & 256)   // every wave stores to the same 2 KiB (same instructions, no write traffic to speak of)
     float* out = p.audio;
 #else
-    float* out = p.audio + (size_t)stream * p.audio_stride + jfl;
+    uint32_t st_ = stream;                                      // (derived here, from opaque copies: a pointer kept across the step loop costs registers there)
+    int ln_ = lane;
+    asm volatile("" : "+s"(st_), "+v"(ln_));
+    float* out = kargs()->audio + (size_t)st_ * kargs()->audio_stride + jfl;
 #endif
 #if defined(SDRFM_Q_ABLATE) && (SDRFM_Q_ABLATE & 128)
     const int cnt = (ab[lane] == 1234.5f) ? 2 : 0;
@@ -291,13 +377,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
     const int cnt = (j1 - jfl < 128 * npend) ? j1 - jfl : 128 * npend;
 #endif
     if ((reinterpret_cast<uintptr_t>(out) & 7) == 0) {
-      for (int i = 2 * lane; i < cnt; i += 128) {
+      for (int i = 2 * ln_; i < cnt; i += 128) {
         const qf2_t v = *reinterpret_cast<const qf2_t*>(ab + i);
         if (i + 1 < cnt) *reinterpret_cast<qf2_t*>(out + i) = v;
         else out[i] = v.x;
       }
     } else {
-      for (int i = lane; i < cnt; i += 64) out[i] = ab[i];
+      for (int i = ln_; i < cnt; i += 64) out[i] = ab[i];
     }
     jfl += 128 * npend;
     npend = 0;
@@ -309,14 +395,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
   // buffer (SDRFM_F_OVERLAP) or from the 64 raw samples the previous design-Q call left in hist_q.  The taps are wave-uniform LDS reads
   // (h[k] = 0 for k >= T: fmaf(0, x, acc) = acc bit for bit, acc is never -0).  Then the definition's own
   // discriminator (sdrfm_math.h) — the d's are the bit-exact kernels' d's, a fixed function of the bytes like everything else here.
-  // Kernel arguments that only rare branches and the epilogue need are read again from the argument segment there (scalar loads through
-  // an opaque pointer), not kept in scalar registers across the step loop: those are all taken, and every one more costs a reload per step.
-  typedef const __attribute__((address_space(4))) SdrfmQParams* KargPtr;
-  auto kargs = [&]() -> KargPtr {
-    KargPtr pp = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(pp));
-    return pp;
-  };
   int nflag = 0;
   auto repair_flagged = [&]() {
     // Everything this path needs is derived here, from opaque copies of the lane and stream numbers, so that none of it is hoisted into
@@ -507,7 +585,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
     ++osm;
     // everything the list holds is repaired before the d's are read: at every audio stage, at the run's last step (the d history below), and
     // whenever another step's worth of lanes might not fit
-    if (nflag > 0 && (osm == 5 || kk == nsteps - 1 || nflag > 64)) {
+    if (nflag > 0 && (osm == QDA || kk == nsteps - 1 || nflag > 64)) {
       __builtin_amdgcn_s_setprio(3);                            // a wave in the repair path is behind its SIMD's others: first in line until it is through
       repair_flagged();
       if (prio_at >= 0 && kk >= prio_at) {
@@ -530,8 +608,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
     Q_PHASE(5);                                                 // discriminators, d write
 
     // ---- K4: 128 audio outputs per five owned steps, two consecutive outputs per lane -------------------------------------------
-    if (osm == 5 || (kk == nsteps - 1 && osm > 0)) {
-      const float* w = db + DB0 + sigma + phi + 10 * lane - (QTA - 1);   // oldest d of the stage's output 2 lane: an even word
+    if (osm == QDA || (kk == nsteps - 1 && osm > 0)) {
+      const float* w = db + DB0 + sigma + phi + 2 * QDA * lane - (QTA - 1);   // oldest d of the stage's output 2 lane: an even word
       // The whole 40-word window is read up front (one LDS round trip), then four independent chains: each output's 32 taps as two
       // halves of 16, oldest d first within a half, summed at the end.  (Reading the window eight words at a time in two chains took 340
       // - 470 cycles per step of the wave's time against 280 for this; the kernel's time did not move: the steps wait for their bytes.)
@@ -554,14 +632,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
       a1 += a1b;
       *reinterpret_cast<qf2_t*>(ab + 128 * npend + 2 * lane) = qf2_t{a0, a1};
       ++npend;
-      if (osm == 5) {                                           // the stage's last 32 d's become the next stage's history
+      if (osm == QDA) {                                         // the stage's last 32 d's become the next stage's history
         if (lane < QTA) {
-          const float hv = db[DB0 + sigma + 640 - QTA + lane];
+          const float hv = db[DB0 + sigma + 128 * QDA - QTA + lane];
           db[DB0 + sigma - QTA + lane] = hv;
         }
         __builtin_amdgcn_wave_barrier();
         osm = 0;
-        mbase += 640;
+        mbase += 128 * QDA;
       }
       if (npend == ABS) flush_audio();                          // (long runs only: configs[2]'s runs hold 3.4 stages)
       Q_PHASE(6);                                               // audio stage
@@ -654,30 +732,42 @@ __global__ void __launch_bounds__(64) k_q_read_stream(const uint8_t* base, unsig
 }
 
 typedef void (*QKernel)(SdrfmQParams);
-struct QVariant { uint32_t c0, nslot; QKernel k; const char* name; };
-#define QV(C0_, NS_) { C0_, NS_, k_mfir<C0_, NS_>, "k_mfir<" #C0_ "," #NS_ ">" }
-const QVariant kQVariants[] = {QV(0, 5), QV(0, 10), QV(0, 15), QV(1, 5), QV(1, 10), QV(1, 15)};
+struct QVariant { uint32_t c0, nslot, d, da, lds; QKernel k; const char* name; };
+template <int D, int DA, int NSLOT>
+constexpr uint32_t q_lds() { return (uint32_t)(QGeo<D, DA>::PRE + 1024 * NSLOT + 4 * (QGeo<D, DA>::DBW + ABW + FLW)); }
+#define QV(C0_, NS_) { C0_, NS_, 10, 5, q_lds<10, 5, NS_>(), k_mfir<C0_, NS_, 10, 5>, "k_mfir<" #C0_ "," #NS_ ">" }
+#define QVD(C0_, NS_, D_, DA_) { C0_, NS_, D_, DA_, q_lds<D_, DA_, NS_>(), k_mfir<C0_, NS_, D_, DA_>, "k_mfir<" #C0_ "," #NS_ "," #D_ "," #DA_ ">" }
+// D = 10 / DA = 5: the 2.4 MS/s front end of BASELINE (ring of 5 KiB; 10 and 15 for experiments).  D = 8 / DA = 8: 2.048 MS/s -> 256 kS/s ->
+// 32 kHz (ring of two 2-KiB steps).  D = 16 / DA = 5: 3.2 MS/s -> 200 kS/s -> 40 kHz (ring of two 4-KiB steps).
+const QVariant kQVariants[] = {QV(0, 5), QV(0, 10), QV(0, 15), QV(1, 5), QV(1, 10), QV(1, 15), QVD(0, 4, 8, 8), QVD(1, 4, 8, 8), QVD(0, 8, 16, 5), QVD(1, 8, 16, 5)};
 
-const QVariant* q_find(uint32_t c0, uint32_t nslot) {
+const QVariant* q_find(uint32_t c0, uint32_t nslot, uint32_t d, uint32_t da) {
   if (c0 > 1) c0 = 1;
   for (const QVariant& v : kQVariants)
-    if (v.c0 == c0 && v.nslot == nslot) return &v;
+    if (v.c0 == c0 && v.nslot == nslot && v.d == d && v.da == da) return &v;
   return nullptr;
 }
 
 }  // namespace
 
-uint32_t sdrfm_q_lds_bytes(uint32_t nslot) { return (uint32_t)(PRE + 1024 * (int)nslot + 4 * (DBW + ABW + FLW)); }
+uint32_t sdrfm_q_default_nslot(uint32_t d) { return d == 10 ? 5u : (d == 8 ? 4u : (d == 16 ? 8u : 0u)); }
 
-const char* sdrfm_q_kernel_symbol(uint32_t first_chunk, uint32_t nslot) {
-  const QVariant* v = q_find(first_chunk, nslot);
+bool sdrfm_q_geometry_ok(uint32_t d, uint32_t da) { return q_find(0, sdrfm_q_default_nslot(d), d, da) != nullptr; }
+
+uint32_t sdrfm_q_lds_bytes(uint32_t nslot, uint32_t d, uint32_t da) {
+  const QVariant* v = q_find(0, nslot, d, da);
+  return v ? v->lds : 0u;
+}
+
+const char* sdrfm_q_kernel_symbol(uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da) {
+  const QVariant* v = q_find(first_chunk, nslot, d, da);
   return v ? v->name : "";
 }
 
-int sdrfm_q_blocks_per_cu(uint32_t first_chunk, uint32_t nslot) {
-  const QVariant* v = q_find(first_chunk, nslot);
+int sdrfm_q_blocks_per_cu(uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da) {
+  const QVariant* v = q_find(first_chunk, nslot, d, da);
   int nb = 0;
-  if (!v || hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(v->k), 64, sdrfm_q_lds_bytes(nslot)) != hipSuccess) return 0;
+  if (!v || hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(v->k), 64, v->lds) != hipSuccess) return 0;
   return nb;
 }
 
@@ -686,10 +776,10 @@ hipError_t sdrfm_q_fix_yprev(const uint8_t* hist_q, const float* hpad, float2* y
   return hipGetLastError();
 }
 
-hipError_t sdrfm_q_launch(const SdrfmQParams& p, uint32_t first_chunk, uint32_t nslot, hipStream_t stream) {
-  const QVariant* v = q_find(first_chunk, nslot);
+hipError_t sdrfm_q_launch(const SdrfmQParams& p, uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da, hipStream_t stream) {
+  const QVariant* v = q_find(first_chunk, nslot, d, da);
   if (!v) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(v->k, dim3(p.n_streams * p.runs), dim3(64), sdrfm_q_lds_bytes(nslot), stream, p);
+  hipLaunchKernelGGL(v->k, dim3(p.n_streams * p.runs), dim3(64), v->lds, stream, p);
   return hipGetLastError();
 }
 

@@ -562,3 +562,59 @@ def test_configs3_share_with_overlapped_calls_against_the_oracle(pkg, oracle_mod
         assert scaled_err(got[s], want) <= TOL, s
     for rep in range(1, ns // nd):
         assert np.array_equal(got[nd * rep:nd * rep + nd].view(np.uint32), got[:nd].view(np.uint32)), rep
+
+
+@pytest.mark.parametrize("T,D,Da,fs", [(64, 8, 8, 2.048e6), (16, 8, 8, 2.048e6), (64, 16, 5, 3.2e6), (16, 16, 5, 3.2e6)])
+def test_matrix_pipe_kernel_at_the_other_dongle_rates(pkg, oracle_mod, T, D, Da, fs):
+    """The 2.048 and 3.2 MS/s front ends (rates RTLSDR_set_sample_rate accepts: usbh_rtlsdr.c:676-678) have design-Q instances too: steps of
+    two / four whole KiB chunks, a swizzled ring (blocks of 128 / 256 bytes would put a lane group's window reads on one set of LDS banks).
+    Machine-filling calls of whole audio periods: every distinct row (carriers, noise, constant, counter) against the oracle at the plain
+    tolerance, against the bit-exact kernels on a twin handle, identical rows bit-identical, however the stream is cut bit-identical, and
+    overlapped calls bit-identical to serial ones."""
+    import torch
+    h, g = pkg.default_config(T, fir_decim=D, audio_taps=32, audio_decim=Da)
+    unit = 8 * D * Da
+    ns, calls = 264, [unit * 60, unit * 7, unit * 53, 1000, 2 * unit - 1000, unit * 30]   # (the two odd sizes together: whole audio periods again)
+    total, nd = sum(calls), 12
+    rows = np.concatenate([pkg.make_iq(nd - 5, total, mode="fm", fs=fs, first_id=600), pkg.make_iq(3, total, mode="random", first_id=650),
+                           pkg.make_iq(1, total, mode="const", first_id=660), pkg.make_iq(1, total, mode="counter", first_id=670)])
+    iq = np.tile(rows, (ns // nd, 1))
+    kw = dict(fir_coeffs=h, audio_coeffs=g, fir_decim=D, audio_decim=Da, n_streams=ns, max_bytes_per_call=2 * max(calls))
+    with pkg.FmDemod(pkg.FmConfig(**kw)) as fast, pkg.FmDemod(pkg.FmConfig(bit_exact=True, **kw)) as exact:
+        pos, names, a_fast, a_exact = 0, [], [], []
+        for n in calls:
+            a_fast.append(fast.process_batch(iq[:, 2 * pos:2 * (pos + n)]))
+            names.append(fast.kernel_name)
+            a_exact.append(exact.process_batch(iq[:, 2 * pos:2 * (pos + n)]))
+            assert not exact.kernel_name.startswith("fast-q")
+            pos += n
+        st = fast.q_guard()
+    for n, name in zip(calls, names):
+        assert name.startswith("fast-q") == (n % unit == 0), (n, names)
+        if n % unit == 0:
+            assert "k_mfir<" in name and (",%d,%d>" % (D, Da)) in name, name
+    assert st["lanes"] > 0
+    a_fast, a_exact = np.concatenate(a_fast, axis=1), np.concatenate(a_exact, axis=1)
+    assert np.array_equal(a_fast[:nd].view(np.uint32), a_fast[nd:2 * nd].view(np.uint32))
+    assert scaled_err(a_fast, a_exact) <= 2e-6
+    for s_ in range(nd):
+        assert scaled_err(a_fast[s_], oracle_mod.Oracle(h, g, D, Da).process(rows[s_])) <= TOL, s_
+    # partition invariance and overlapped calls, on device-resident buffers
+    nb = unit * 40
+    dev = torch.from_numpy(np.ascontiguousarray(iq[:, :2 * 3 * nb])).cuda()
+    outs = []
+    for cuts, ovl in (([3 * nb], False), ([nb, nb, nb], False), ([nb, nb, nb], True)):
+        bufs = [torch.zeros((ns, c // (D * Da)), dtype=torch.float32, device="cuda") for c in cuts]
+        torch.cuda.synchronize()
+        with pkg.FmDemod(pkg.FmConfig(**dict(kw, max_bytes_per_call=2 * 3 * nb))) as dm:
+            p0 = 0
+            for c, b in zip(cuts, bufs):
+                dm.process_batch_device(dev[:, 2 * p0:], b, nbytes=2 * c, overlap=ovl)
+                assert dm.kernel_name.startswith("fast-q"), dm.kernel_name
+                p0 += c
+            if ovl:
+                assert "overlapped" in dm.kernel_name
+            dm.synchronize()
+        outs.append(torch.cat(bufs, dim=1).cpu().numpy())
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+    assert np.array_equal(outs[0].view(np.uint32), outs[2].view(np.uint32))

@@ -76,6 +76,22 @@ def test_tables_reproduce_the_fir_through_the_mfma_layout(pkg, oracle_mod, T):
         assert err <= 2e-4, (mode, err)                                    # |y| ~ 100: 2e-6 relative; the audio test is in tools/q_emulate.py
 
 
+@pytest.mark.parametrize("T,D,Da", [(64, 8, 8), (16, 8, 8), (64, 16, 5), (16, 16, 5)])
+def test_tables_of_the_other_front_end_rates(pkg, oracle_mod, T, D, Da):
+    """The 2.048 MS/s (D = 8) and 3.2 MS/s (D = 16) instances of design Q: blocks of 128 / 256 bytes, two / four K-chunks per window."""
+    h, g = pkg.default_config(T, fir_decim=D, audio_taps=32, audio_decim=Da)
+    rc, A, q, cst, c0 = _build(pkg, h, D)
+    assert rc == 0 and A.shape[0] == (D + 3) // 4
+    for mode in ("fm", "random"):
+        iq = pkg.make_iq(1, 16 * D * 100, mode=mode, first_id=3)[0]
+        o = oracle_mod.Oracle(h, g, D, Da)
+        o.process(iq)
+        yo, _ = o.last_stage()
+        ye = _emulate_blocks(A, q, cst, iq, D).reshape(-1, 2)
+        err = np.abs(ye[16:yo.shape[0]].astype(np.float64) - yo[16:]).max()
+        assert err <= 2e-4, (mode, err)
+
+
 def test_digits_are_balanced_and_exact(pkg):
     h, _ = pkg.default_config(64)
     rc, A, q, cst, c0 = _build(pkg, h)

@@ -52,12 +52,12 @@ int main(int argc, char** argv) {
   const int ns = argc > 1 ? atoi(argv[1]) : 256, nsamp = argc > 2 ? atoi(argv[2]) : 240000, T = argc > 3 ? atoi(argv[3]) : 64;
   const int nslot = argc > 4 ? atoi(argv[4]) : 10, runs = argc > 5 ? atoi(argv[5]) : 12, iters = argc > 6 ? atoi(argv[6]) : 40;
   const int mode = (argc > 7 && !strcmp(argv[7], "random")) ? 1 : 0;
-  const int D = 10, Ta = 32, Da = 5, HT = T - 1;
-  if (nsamp % 400) { fprintf(stderr, "nsamp must be a multiple of 400\n"); return 2; }
+  const int D = getenv("QBENCH_D") ? atoi(getenv("QBENCH_D")) : 10, Ta = 32, Da = getenv("QBENCH_DA") ? atoi(getenv("QBENCH_DA")) : 5, HT = T - 1;   // QBENCH_D=8 QBENCH_DA=8 / 16, 5: the other instances (nslot 4 / 8)
+  if (nsamp % (8 * D * Da)) { fprintf(stderr, "nsamp must be a multiple of %d\n", 8 * D * Da); return 2; }
   const int M = nsamp / D, A = M / Da;
   std::vector<float> h, g;
   lowpass(h, T, 100e3 / 2.4e6); lowpass(g, Ta, 15e3 / 240e3);
-  std::vector<int8_t> At(3 * 3 * 64 * 16);
+  std::vector<int8_t> At((size_t)SDRFM_Q_SPARSE_CHUNKS(D) * 3 * 64 * 16);
   float q, cst; uint32_t c0;
   if (sdrfm_q_build(h.data(), T, D, At.data(), &q, &cst, &c0)) { fprintf(stderr, "sdrfm_q_build failed\n"); return 2; }
 
@@ -118,7 +118,7 @@ int main(int argc, char** argv) {
     p.hpad = d_hp; p.hist_q_in = d_hqi; p.hist_q_out = d_hqo; p.yprev_exact = 1; p.n_repaired = d_st;
   }
   hipStream_t st; CK(hipStreamCreate(&st));
-  CK(sdrfm_q_launch(p, c0, nslot, st));
+  CK(sdrfm_q_launch(p, c0, nslot, D, Da, st));
   CK(hipStreamSynchronize(st));
 
   // ---- check against a float64 restatement of the spec -----------------------------------------------------------------------
@@ -169,7 +169,7 @@ int main(int argc, char** argv) {
     b1.iq = d_iq + batch; b1.audio = d_a1; b1.yprev_in = d_ypo; b1.hist_d_in = d_hdo; b1.hist_b_in = d_hbo; b1.yprev_out = d_yp1; b1.hist_d_out = d_hd1; b1.hist_b_out = d_hb2;
     b2.iq = d_iq + batch; b2.audio = d_a2; b2.iq_prev = d_iq; b2.iq_prev_stride = stride; b2.N_prev = nsamp; b2.yprev_in = nullptr; b2.hist_d_in = nullptr; b2.hist_b_in = nullptr;
     b2.yprev_out = d_yp2; b2.hist_d_out = d_hd2; b2.hist_b_out = d_hb2;
-    CK(sdrfm_q_launch(b1, c0, nslot, st)); CK(sdrfm_q_launch(b2, c0, nslot, st)); CK(hipStreamSynchronize(st));
+    CK(sdrfm_q_launch(b1, c0, nslot, D, Da, st)); CK(sdrfm_q_launch(b2, c0, nslot, D, Da, st)); CK(hipStreamSynchronize(st));
     std::vector<uint32_t> a1(astride * ns), a2(astride * ns), s1(ns * 33), s2(ns * 33);
     CK(hipMemcpy(a1.data(), d_a1, a1.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(a2.data(), d_a2, a2.size() * 4, hipMemcpyDeviceToHost));
     CK(hipMemcpy(s1.data(), d_hd1, ns * 31 * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(s2.data(), d_hd2, ns * 31 * 4, hipMemcpyDeviceToHost));
@@ -181,10 +181,10 @@ int main(int argc, char** argv) {
   }
   // ---- timing: back-to-back launches over rotating batches, one pair of events ---------------------------------------------------
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < 5; ++i) { p.iq = d_iq + (size_t)(i % NB) * batch; CK(sdrfm_q_launch(p, c0, nslot, st)); }
+  for (int i = 0; i < 5; ++i) { p.iq = d_iq + (size_t)(i % NB) * batch; CK(sdrfm_q_launch(p, c0, nslot, D, Da, st)); }
   CK(hipStreamSynchronize(st));
   CK(hipEventRecord(e0, st));
-  for (int i = 0; i < iters; ++i) { p.iq = d_iq + (size_t)(i % NB) * batch; CK(sdrfm_q_launch(p, c0, nslot, st)); }
+  for (int i = 0; i < iters; ++i) { p.iq = d_iq + (size_t)(i % NB) * batch; CK(sdrfm_q_launch(p, c0, nslot, D, Da, st)); }
   CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   if (getenv("QBENCH_TWO")) {   // the same launches alternating between TWO streams (no dependency between consecutive launches): what would overlapping calls give?
@@ -204,10 +204,10 @@ int main(int argc, char** argv) {
     } else { CK(hipStreamCreateWithFlags(&s2[0], hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2[1], hipStreamNonBlocking)); }
     hipEvent_t f0, f1, j1; CK(hipEventCreate(&f0)); CK(hipEventCreate(&f1)); CK(hipEventCreate(&j1));
     p.prio_by_age = 0;                                             // (as the library does for overlapped calls)
-    for (int i = 0; i < 6; ++i) { p.iq = d_iq + (size_t)(i % NB) * batch; CK(sdrfm_q_launch(p, c0, nslot, s2[i & 1])); }
+    for (int i = 0; i < 6; ++i) { p.iq = d_iq + (size_t)(i % NB) * batch; CK(sdrfm_q_launch(p, c0, nslot, D, Da, s2[i & 1])); }
     CK(hipStreamSynchronize(s2[0])); CK(hipStreamSynchronize(s2[1]));
     CK(hipEventRecord(f0, s2[0])); CK(hipStreamWaitEvent(s2[1], f0, 0));
-    for (int i = 0; i < iters; ++i) { p.iq = d_iq + (size_t)(i % NB) * batch; CK(sdrfm_q_launch(p, c0, nslot, s2[i & 1])); }
+    for (int i = 0; i < iters; ++i) { p.iq = d_iq + (size_t)(i % NB) * batch; CK(sdrfm_q_launch(p, c0, nslot, D, Da, s2[i & 1])); }
     CK(hipEventRecord(j1, s2[1])); CK(hipStreamWaitEvent(s2[0], j1, 0)); CK(hipEventRecord(f1, s2[0])); CK(hipEventSynchronize(f1));
     float ms2; CK(hipEventElapsedTime(&ms2, f0, f1));
     printf("{\"two_streams_us_per_launch\":%.2f,\"one_stream_us_per_launch\":%.2f}\n", ms2 * 1e3 / iters, ms * 1e3 / iters);
@@ -216,7 +216,7 @@ int main(int argc, char** argv) {
     const size_t nw = (size_t)ns * runs;
     unsigned long long* d_dbg; CK(hipMalloc(&d_dbg, nw * 128)); CK(hipMemset(d_dbg, 0, nw * 128));
     p.dbg = d_dbg; p.iq = d_iq + (size_t)(iters % NB) * batch;
-    CK(sdrfm_q_launch(p, c0, nslot, st)); CK(hipStreamSynchronize(st));
+    CK(sdrfm_q_launch(p, c0, nslot, D, Da, st)); CK(hipStreamSynchronize(st));
     std::vector<unsigned long long> hd16(nw * 16), hd(nw * 8);
     CK(hipMemcpy(hd16.data(), d_dbg, nw * 128, hipMemcpyDeviceToHost));
     for (size_t w = 0; w < nw; ++w) for (int i = 0; i < 8; ++i) hd[8 * w + i] = hd16[16 * w + i];
@@ -256,10 +256,10 @@ int main(int argc, char** argv) {
   unsigned int gst[2] = {0, 0};
   CK(hipMemcpy(gst, d_st, 8, hipMemcpyDeviceToHost));
   printf("{\"guard\":{\"r\":%.4g,\"a\":%.7g,\"lanes_repaired_all_launches\":%u,\"repair_passes_all_launches\":%u}}\n", p.guard_r, p.guard_a, gst[0], gst[1]);
-  printf("{\"blocks_per_cu_api\":%d}\n", sdrfm_q_blocks_per_cu(c0, nslot));
+  printf("{\"blocks_per_cu_api\":%d}\n", sdrfm_q_blocks_per_cu(c0, nslot, D, Da));
   printf("{\"kernel\":\"%s\",\"ns\":%d,\"nsamp\":%d,\"T\":%d,\"nslot\":%d,\"runs\":%d,\"mode\":\"%s\",\"first_chunk\":%u,\"checked_streams\":%zu,"
          "\"max_scaled_err\":%.3g,\"worst_at\":[%d,%d],\"n_over_tol\":%ld,\"nonfinite\":%ld,\"state_err\":%.3g,\"us_per_launch\":%.2f,\"frac_of_8TBs\":%.4f,\"batches\":%d}\n",
-         sdrfm_q_kernel_symbol(c0, nslot), ns, nsamp, T, nslot, runs, mode ? "random" : "fm", c0, chk.size(), worst, worst_s, worst_j, bad, nonfinite,
+         sdrfm_q_kernel_symbol(c0, nslot, D, Da), ns, nsamp, T, nslot, runs, mode ? "random" : "fm", c0, chk.size(), worst, worst_s, worst_j, bad, nonfinite,
          worst_state, us, bytes / (us * 1e-6) / 8e12, NB);
   return (bad || nonfinite || worst_state > 1e-4) ? 1 : 0;
 }
