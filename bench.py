@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--streams-per-gpu", type=int, default=0, help="0 = 256 at one GPU (configs[2]), 512 at several (configs[3] share)")
     ap.add_argument("--seconds", type=float, default=0.1, help="capture length per stream per step")
     ap.add_argument("--fir-taps", type=int, default=64)
+    ap.add_argument("--fir-decim", type=int, default=10, choices=[8, 10, 16], help="fm workload: the front end's rate — 10 = 2.4 MS/s / 10 / 5 (BASELINE, "
+                    "the headline), 8 = 2.048 MS/s / 8 / 8, 16 = 3.2 MS/s / 16 / 5 (the other rates RTLSDR_set_sample_rate accepts); comparison figures")
     ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic streams generated on the host per rank; the other "
                     "rows and the other rotated batches are byte-rotations of them made on the device (0 = generate every row)")
     ap.add_argument("--batches", type=int, default=0, help="input batches the timed loop rotates over (0 = as many as exceed the L3, >= 3)")
@@ -313,13 +315,13 @@ def main():
         return main_wbfm(args, pkg, world, rank, local_rank, use_dist, rccl_world)
     if args.workload == "spectrum":
         return main_spectrum(args, pkg, world, rank, local_rank, use_dist, rccl_world)
-    fs = 2.4e6
+    D, Da = args.fir_decim, (8 if args.fir_decim == 8 else 5)
+    fs = {8: 2.048e6, 10: 2.4e6, 16: 3.2e6}[D]
     ns = args.streams_per_gpu if args.streams_per_gpu > 0 else (256 if world == 1 else 512)
     cfg_name = "configs[2]" if ns == 256 else ("configs[3] share (4096 streams / 8 GPUs)" if ns == 512 else "configs[2]-shaped")
     nsamp = int(round(args.seconds * fs))
     nbytes = 2 * nsamp
-    h, g = pkg.default_config(args.fir_taps, fs=fs)
-    D, Da = 10, 5
+    h, g = pkg.default_config(args.fir_taps, fs=fs, fir_decim=D, audio_taps=32, audio_decim=Da)
 
     dm = pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, fir_decim=D, audio_decim=Da, n_streams=ns, device=local_rank,
                                   dev_library=args.dev_library, bit_exact=args.bit_exact))
@@ -458,10 +460,11 @@ def main():
             "mode": "end-to-end (RCCL scatter of IQ from rank 0 + gather of audio every step)" if args.end_to_end else
                     ("compute-only (IQ resident per GPU); timed calls made with SDRFM_F_OVERLAP: consecutive calls may run concurrently on the device"
                      if overlap else "compute-only (IQ resident per GPU); calls one after the other"),
-            "config": {"workload": "BASELINE %s: %d concurrent 2.4 MS/s uint8 IQ streams per GPU x %.1f s (%d B each), "
-                                   "%d-tap FIR /%d + FM discriminator + %d-tap /%d -> 48 kHz; device-resident, streams sharded "
+            "config": {"workload": ("BASELINE %s: " if D == 10 else "(NOT a BASELINE config: the %s shape at another front-end rate) ") % cfg_name +
+                                   "%d concurrent %.3f MS/s uint8 IQ streams per GPU x %.1f s (%d B each), "
+                                   "%d-tap FIR /%d + FM discriminator + %d-tap /%d; device-resident, streams sharded "
                                    "across GPUs with no collective; timed loop rotates over %d input batches = %.0f MB per GPU (> 256 MiB "
-                                   "L3: cold HBM reads)" % (cfg_name, ns, args.seconds, nbytes, args.fir_taps, D, len(g), Da, nb, nb * ns * nbytes / 1e6),
+                                   "L3: cold HBM reads)" % (ns, fs / 1e6, args.seconds, nbytes, args.fir_taps, D, len(g), Da, nb, nb * ns * nbytes / 1e6),
                        "streams_per_gpu": ns, "bytes_per_stream": nbytes, "fir_taps": args.fir_taps, "kernel": dm.kernel_name,
                        "input_batches_rotated": nb, "input_bytes_rotated_per_gpu": nb * ns * nbytes,
                        "bytes_per_sample_algorithmic": round(alg_bytes / samples_per_launch, 4),
