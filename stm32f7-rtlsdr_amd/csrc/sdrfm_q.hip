@@ -121,7 +121,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 template <int C0, int NSLOT, int D, int DA>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16 ? 3 : 4))) k_mfir(SdrfmQParams p) {
   using G = QGeo<D, DA>;
-  constexpr int QD = D, QDA = DA, NCH = G::NCH, NSC = G::NSC, BLKB = G::BLKB, STEPB = G::STEPB, PRE = G::PRE, DBW = G::DBW, RWIN = G::RWIN;
+  [[maybe_unused]] constexpr int NCH = G::NCH;
+  constexpr int QD = D, QDA = DA, NSC = G::NSC, BLKB = G::BLKB, STEPB = G::STEPB, PRE = G::PRE, DBW = G::DBW, RWIN = G::RWIN;
   constexpr bool ALIGNED = G::ALIGNED;
   constexpr int CS = G::CS, WB = G::WB;
   constexpr int RINGB = NSLOT * 1024;
@@ -258,6 +259,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16
   if (!warm) {
     // -> end of the pre-halo (the block before the ring: block index -1, swizzle key 7 where the ring is swizzled)
     constexpr int HSW = ALIGNED ? 0x70 : 0;
+#ifdef SDRFM_Q_LDSXOR
+    hb0 ^= 0x8080; hb1 ^= 0x8080;                              // (experiment: the ring holds byte - 128 already)
+#endif
     if (lane < HT) *reinterpret_cast<unsigned short*>(smem + ((PRE - 2 * HT + 2 * lane) ^ HSW)) = hb0;
     if (lane + 64 < HT) *reinterpret_cast<unsigned short*>(smem + ((PRE - 2 * HT + 2 * (lane + 64)) ^ HSW)) = hb1;
     if (lane < QTA - 1) db[DB0 + sigma - (QTA - 1) + lane] = hd0;
@@ -299,6 +303,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16
     // this step's bytes have landed: everything but the youngest chunk of the 2.5-chunk steps' ring / but the next step's CS chunks
     wait_vmcnt<(ALIGNED ? CS : NSLOT - 4)>();
     asm volatile("" ::: "memory");
+#ifdef SDRFM_Q_LDSXOR   // experiment (round 3: slower at the full clock; round 4: re-measured in the sustained regime): byte - 128 once per byte, in the LDS
+#pragma unroll
+    for (int i = 0; i < STEPB / 512; ++i)
+      (void)__hip_atomic_fetch_xor(reinterpret_cast<unsigned long long*>(__builtin_assume_aligned(smem + PRE + ringoff + 8 * (lane + 64 * i), 8)), 0x8080808080808080ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#endif
 #ifdef SDRFM_Q_STAMPS
     t_wait += __builtin_readcyclecounter() - tw0;
     if (t_first == 0) t_first = __builtin_amdgcn_s_memrealtime();
@@ -501,9 +510,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16
     qi4_t acc[SDRFM_Q_DIGITS];
 #pragma unroll
     for (int t = 0; t < SDRFM_Q_DIGITS; ++t) acc[t] = qi4_t{0, 0, 0, 0};
-    constexpr int XM = (int)0x80808080;
+    [[maybe_unused]] constexpr int XM = (int)0x80808080;
+#ifndef SDRFM_Q_LDSXOR
 #pragma unroll
     for (int c = 0; c < NB - 1 + (NCH & 1 ? 0 : 1); ++c) B[c] = B[c] ^ qi4_t{XM, XM, XM, XM};   // byte - 128 as i8 (not the piece beyond the window)
+#endif
 #pragma unroll
     for (int c = C0; c < NSC; ++c) {
       // 128 window bytes per issue: the lane's two 16-byte pieces 64 bytes apart
