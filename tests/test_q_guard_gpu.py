@@ -171,3 +171,45 @@ def test_noise_only_streams_move_to_the_bit_exact_kernels_and_back(pkg, oracle_m
         for s in range(8):
             want = oracle_mod.Oracle(h, g).process(rows[s])
             assert scaled_err(np.concatenate([got[k, s] for k in range(ncalls)]), want) <= TOL, (mode, s)
+
+
+@pytest.mark.parametrize("D,Da,fs", [(10, 5, 2.4e6), (8, 8, 2.048e6), (16, 5, 3.2e6)])
+def test_matrix_pipe_kernel_with_repairs_writes_only_its_audio(pkg, D, Da, fs):
+    """Canary (no GPU sanitizer on the pool): the audio of a machine-filling call on rows of noise — the matrix-pipe kernel with its repair path
+    at work — sits in a larger allocation filled with a sentinel; every word outside the documented output region keeps it, at every rate."""
+    import torch
+    SENT = -12345.0
+    h, g = pkg.default_config(64, fs=fs, fir_decim=D, audio_taps=32, audio_decim=Da)
+    unit = 8 * D * Da
+    ns, nsamp = 256, unit * 47
+    A = nsamp // (D * Da)
+    iq = torch.from_numpy(pkg.make_iq(ns, nsamp, mode="random", first_id=77)).cuda()
+    pad, stride = 64, A + 38
+    big = torch.full((pad + ns * stride + pad,), SENT, dtype=torch.float32, device="cuda")
+    audio = big[pad:pad + ns * stride].view(ns, stride)
+    torch.cuda.synchronize()
+    with pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, fir_decim=D, audio_decim=Da, n_streams=ns, max_bytes_per_call=2 * nsamp)) as dm:
+        for rep in range(2):
+            assert dm.process_batch_device(iq, audio) == A
+            dm.synchronize()
+            assert dm.kernel_name.startswith("fast-q"), dm.kernel_name
+        assert dm.q_guard()["lanes"] > 1000
+    host = big.cpu().numpy()
+    assert np.all(host[:pad] == SENT) and np.all(host[-pad:] == SENT)
+    body = host[pad:-pad].reshape(ns, stride)
+    assert np.all(body[:, A:] == SENT)
+    assert np.isfinite(body[:, :A]).all() and not np.any(body[:, :A] == SENT)
+
+
+def test_measured_read_ceiling_hook(pkg):
+    """include/sdrfm_dev.h sdrfm_debug_read_ceiling (what bench.py prints as roofline.peak_measured): a read-only LDS-DMA stream over buffers
+    that together exceed the Infinity Cache lands between the guide's cold-HBM figure and the 8 TB/s specification."""
+    import ctypes as C
+    import torch
+    bufs = [torch.zeros(123 << 20, dtype=torch.uint8, device="cuda") for _ in range(4)]
+    torch.cuda.synchronize()
+    ptrs = (C.c_void_p * len(bufs))(*[b.data_ptr() for b in bufs])
+    out = C.c_double()
+    assert pkg.load_library().sdrfm_debug_read_ceiling(0, ptrs, len(bufs), bufs[0].numel(), 40, C.byref(out)) == 0
+    assert 4000.0 < out.value < 8000.0, out.value
+    assert pkg.load_library().sdrfm_debug_read_ceiling(0, ptrs, 0, bufs[0].numel(), 40, C.byref(out)) == 16        # SDRFM_EINVAL
