@@ -73,3 +73,16 @@ def test_guarded_emulation_on_every_input_class(pkg, T, mode):
         assert frac < 1e-3, frac                               # a carrier never meets the guard (but for the stream's first outputs)
     if mode == "const":
         assert frac == 1.0                                     # |y| = 0.5 |sum h| sqrt 2: everything goes the definition's way
+
+
+@pytest.mark.parametrize("T,D,Da,fs", [(64, 8, 8, 2.048e6), (64, 16, 5, 3.2e6)])
+def test_guarded_emulation_at_the_other_front_end_rates(pkg, T, D, Da, fs):
+    """The same arithmetic at the 2.048 and 3.2 MS/s geometries (the guard's thresholds do not depend on D; the windows do)."""
+    import q_emulate as qe
+    h, g = pkg.default_config(T, fs=fs, fir_decim=D, audio_taps=32, audio_decim=Da)
+    guard = guard_of(pkg, h, g)
+    for mode in ("fm", "random"):
+        iq = pkg.make_iq(1, 8 * D * Da * 150, mode=mode, fs=fs, first_id=47)[0]
+        got, want, _ = qe.design_q_audio(iq, h, g, D=D, Da=Da, guard=guard)
+        e = np.abs(got.astype(np.float64) - want) / np.maximum(np.abs(want), 1.0)
+        assert e.max() <= 1e-6, (mode, e.max())

@@ -17,17 +17,18 @@ t_end, cases, calls_q, fails, worst_exact, worst_oracle = time.time() + budget, 
 calls_ovl = 0; lanes_repaired = 0
 while time.time() < t_end:
     T = int(rng.choice([16, 32, 64, 64, 48, 90, 33]))
-    g = pkg.default_config(64)[1]
+    D, Da, fs = [(10, 5, 2.4e6), (10, 5, 2.4e6), (8, 8, 2.048e6), (16, 5, 3.2e6)][int(rng.integers(4))]      # the three front-end rates design Q has instances for
+    g = pkg.default_config(64, fs=fs, fir_decim=D, audio_taps=32, audio_decim=Da)[1]
     lowpass = True
     if T in (16, 32, 64):
-        h, g = pkg.default_config(T)
+        h, g = pkg.default_config(T, fs=fs, fir_decim=D, audio_taps=32, audio_decim=Da)
     elif rng.random() < 0.7:
         h = pkg.lowpass_taps(T, float(rng.uniform(0.02, 0.06)))            # other lengths / cut-offs: still low-pass, still design Q
     else:
         h = (rng.standard_normal(T) * np.hamming(T)).astype(np.float32); h /= np.abs(h).sum(); lowpass = False   # no pass band
     lowpass = bool(np.abs(h.astype(np.float64)).sum() <= 2.0 * abs(h.astype(np.float64).sum()))   # the library's rule (sdrfm.h: SDRFM_CFG_BIT_EXACT)
     ns = int(rng.choice([1, 2, 7, 64, 256, 300, 1024, 3100]))
-    unit = 400
+    unit = 8 * D * Da
     sizes = []
     for _ in range(int(rng.integers(2, 5))):
         if ns <= 7:
@@ -39,15 +40,15 @@ while time.time() < t_end:
         sizes.append(unit * k if rng.random() < 0.8 else int(rng.integers(1, unit * k)))
     total = sum(sizes)
     nd = min(ns, 6)
-    rows = np.concatenate([pkg.make_iq(max(nd - 2, 1), total, mode="fm", first_id=int(rng.integers(1 << 20))),
+    rows = np.concatenate([pkg.make_iq(max(nd - 2, 1), total, mode="fm", fs=fs, first_id=int(rng.integers(1 << 20))),
                            pkg.make_iq(2, total, mode=str(rng.choice(["random", "const", "counter"])), first_id=int(rng.integers(1 << 20)))])[:nd]
     stride = 2 * total + int(rng.choice([0, 16, 48, 2, 6]))
     dev = torch.zeros((ns, stride), dtype=torch.uint8, device="cuda")
     dev[:, :2 * total] = torch.from_numpy(np.tile(rows, ((ns + nd - 1) // nd, 1))[:ns]).cuda()
     torch.cuda.synchronize()
-    kw = dict(fir_coeffs=h, audio_coeffs=g, n_streams=ns, max_bytes_per_call=2 * max(sizes) + 64)
+    kw = dict(fir_coeffs=h, audio_coeffs=g, fir_decim=D, audio_decim=Da, n_streams=ns, max_bytes_per_call=2 * max(sizes) + 64)
     fast = pkg.FmDemod(pkg.FmConfig(**kw)); exact = pkg.FmDemod(pkg.FmConfig(bit_exact=True, **kw))
-    orcs = [Oracle(h, g) for _ in range(nd)]
+    orcs = [Oracle(h, g, D, Da) for _ in range(nd)]
     pos, log, bad = 0, [], False
     for n in sizes:
         if rng.random() < 0.15:
@@ -82,7 +83,7 @@ while time.time() < t_end:
     fast.close(); exact.close()
     cases += 1
     if bad:
-        fails += 1; print("FAIL", dict(T=T, ns=ns, stride=stride, log=log), flush=True)
+        fails += 1; print("FAIL", dict(T=T, D=D, Da=Da, ns=ns, stride=stride, log=log), flush=True)
         if os.environ.get("FUZZ_DUMP"):                                                                  # the failing case, for tools/dev/replay_q.py
             os.makedirs(os.environ["FUZZ_DUMP"], exist_ok=True)
             np.savez_compressed(os.path.join(os.environ["FUZZ_DUMP"], "case_%d_%d.npz" % (seed, cases)), h=h, g=g, ns=ns, stride=stride, rows=rows,
