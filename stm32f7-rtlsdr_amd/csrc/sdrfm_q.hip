@@ -3,9 +3,14 @@
  *
  * What it fills in the reference: the same empty consumer hook as the rest of the library (RTLSDR_XFER_COMPLETE,
  * Middlewares/ST/STM32_USB_Host_Library/Class/RTLSDR/Src/usbh_rtlsdr.c:1094-1097); byte format usbh_rtlsdr.h:165-173; FIR
- * convention CMSIS/core/arm_math.h:3291-3331.  Arithmetic: qtaps.c / DESIGN.md §4.0 — NOT bit-identical to the fp32 fmaf
+ * convention CMSIS/core/arm_math.h:3291-3331.  Arithmetic: qtaps.c / DESIGN.md §2, §4.Q — NOT bit-identical to the fp32 fmaf
  * chain of the oracle (designs S / B / generic are): K2 is evaluated exactly in integers from taps rounded to 24-bit fixed
- * point, which lands within 7e-7 of the oracle's audio on every input class (tolerance 1e-5; tools/q_emulate.py).
+ * point, which lands within 1e-4 (absolute) of the chain's y: within 1e-6 of the oracle's audio wherever the phase of
+ * y[m] conj(y[m-1]) is well conditioned, and where it is not (a deep fade; a d next to +-pi) the CONDITIONING GUARD lists the
+ * output pair and the repair path recomputes it with the definition's own chain from the raw bytes (repair_flagged below) —
+ * the 1e-5 tolerance holds for any input bytes (tests/test_q_guard_gpu.py, tools/fuzz_q.py at the plain criterion).
+ * Instances: (D, Da) = (10, 5) — 2.4 MS/s, BASELINE —, (8, 8) — 2.048 MS/s — and (16, 5) — 3.2 MS/s; the step sizes below
+ * are the (10, 5) ones (QGeo has the others: steps of 2 / 4 whole KiB chunks, a swizzled ring).
  *
  * Why: designs S / B are VALU-issue-bound at 14.7 vector instructions per sample and lane, 6.4 of them the FIR's FMAs and 3.4
  * the u8 -> f32 conversion (profiles/r02_*).  The i8 matrix pipe takes the raw bytes as they are (one v_xor per 4 bytes) and
