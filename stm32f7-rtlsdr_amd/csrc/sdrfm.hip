@@ -1519,7 +1519,7 @@ struct sdrfm {
 static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nbytes, float* d_audio, size_t audio_stride,
                    uint32_t* n_audio, uint32_t call_flags = 0);
 #define SDRFM_Q_ADAPT_WINDOW 8u      /* design-Q calls between two looks at the sampled repair statistics */
-#define SDRFM_Q_ADAPT_BACKOFF 256u   /* eligible calls served by the bit-exact kernels after a window of noise-like input */
+#define SDRFM_Q_ADAPT_BACKOFF 1024u  /* eligible calls served by the bit-exact kernels after a window of noise-like input */
 static int join_overlap(sdrfm* h);
 
 #define HIP_TRY(expr, code)                                                                          \

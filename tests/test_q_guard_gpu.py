@@ -164,7 +164,7 @@ def test_noise_only_streams_move_to_the_bit_exact_kernels_and_back(pkg, oracle_m
         if expect_switch:
             first = min(k for k, n in enumerate(names) if n != "fast-q")
             assert 8 <= first <= 24, names                            # after the first window(s) of design-Q calls
-            assert all(n in ("fast-s", "fast-b") for n in names[first:]), names   # ... and for the 256 calls that follow
+            assert all(n in ("fast-s", "fast-b") for n in names[first:]), names   # ... and for the 1024 calls that follow
         else:
             assert all(n == "fast-q" for n in names), names
         got = out.cpu().numpy()
