@@ -1498,11 +1498,11 @@ struct sdrfm {
   // passes to a host-mapped word; when more than a quarter of the audio stages of a window of SDRFM_Q_ADAPT_WINDOW design-Q calls needed
   // one, SDRFM_Q_ADAPT_BACKOFF eligible calls go to the bit-exact kernels, after which design Q is tried again.  The choice is a
   // function of the calls made and their bytes, not of timing: windows report into two words in turn, a window is judged when the NEXT
-  // one closes (eight calls later), behind an event recorded after its last call.
-  unsigned int* q_adapt_host; unsigned int* q_adapt_dev;       // two words: window parity
-  hipEvent_t q_win_evt[2][3];                                  // [window parity][internal stream 0, 1, the handle's stream]
-  bool q_win_rec[2][3];
-  uint64_t q_stages_window, q_stages_prev; uint32_t q_window, q_calls_in_window, q_backoff; bool q_prev_window_open;
+  // after that closes (its calls are sixteen calls old by then: the wait below does not block in practice), behind events recorded after its last calls.
+  unsigned int* q_adapt_host; unsigned int* q_adapt_dev;       // three words: window mod 3
+  hipEvent_t q_win_evt[3][3];                                  // [window mod 3][internal stream 0, 1, the handle's stream]
+  bool q_win_rec[3][3];
+  uint64_t q_stages_window, q_stages_of[3]; uint32_t q_window, q_windows_open, q_calls_in_window, q_backoff;
   // SDRFM_F_OVERLAP: two internal streams taken in turn, so that consecutive calls run concurrently on the device (a call's ramp-up
   // under the previous call's tail).  ovl_in orders a call behind what the handle's stream holds when it is made; join_overlap()
   // records ovl_done[k] behind the calls put on internal stream k and makes the handle's stream wait for it.
@@ -1558,7 +1558,7 @@ static void free_handle(sdrfm* h) {
   if (h->d_qA) (void)hipFree(h->d_qA);
   if (h->d_hpad) (void)hipFree(h->d_hpad);
   if (h->q_adapt_host) (void)hipHostFree(h->q_adapt_host);
-  for (int k = 0; k < 6; ++k)
+  for (int k = 0; k < 9; ++k)
     if (h->q_win_evt[k / 3][k % 3]) (void)hipEventDestroy(h->q_win_evt[k / 3][k % 3]);
   if (h->d_qstat) (void)hipFree(h->d_qstat);
   for (int i = 0; i < 2; ++i)
@@ -1845,8 +1845,8 @@ int sdrfm_reset(sdrfm_t* h) {
   }
   h->yprev_exact = true;                                          // y[-1] = 0, as the definition has it
   h->hist_q_valid = false;
-  h->q_backoff = 0; h->q_calls_in_window = 0; h->q_stages_window = 0; h->q_prev_window_open = false;
-  if (h->q_adapt_host) { h->q_adapt_host[0] = 0; h->q_adapt_host[1] = 0; }   // (everything is synchronised above: no writer is left)
+  h->q_backoff = 0; h->q_calls_in_window = 0; h->q_stages_window = 0; h->q_windows_open = 0;
+  if (h->q_adapt_host) { h->q_adapt_host[0] = 0; h->q_adapt_host[1] = 0; h->q_adapt_host[2] = 0; }   // (everything is synchronised above: no writer is left)
   HIP_TRY(hipStreamSynchronize(h->stream), SDRFM_FAIL);
   h->cur = 0;
   h->phase_x = h->phase_d = 0;
@@ -2050,7 +2050,7 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
                                2 * (size_t)(c.fir_taps - 1), c.n_streams, hipMemcpyDeviceToDevice, h->stream), SDRFM_FAIL);
     q.hpad = h->d_hpad; q.hist_q_in = h->d_hist_q[h->cur]; q.hist_q_out = h->d_hist_q[h->cur ^ 1];
     q.guard_r = h->q_guard_r; q.guard_a = h->q_guard_a; q.yprev_exact = h->yprev_exact ? 1u : 0u; q.n_repaired = h->d_qstat;
-    q.n_adapt = h->q_adapt_dev ? h->q_adapt_dev + (h->q_window & 1u) : nullptr;
+    q.n_adapt = h->q_adapt_dev ? h->q_adapt_dev + (h->q_window % 3u) : nullptr;
     // runs (waves) per stream: fill the machine once; every run at least four owned steps (a run that does not start its stream
     // recomputes one step), two when the call is too small to fill the machine otherwise
     uint32_t runs = (h->q_waves_per_cu * h->n_cu) / c.n_streams;
@@ -2067,7 +2067,7 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
     // the stream's content decides too (see the handle): sampled repair passes against sampled audio stages, window by window
     h->q_stages_window += ((uint64_t)c.n_streams * runs * ((q_steps / runs + c.audio_decim - 1) / c.audio_decim) + SDRFM_Q_ADAPT_SAMPLE - 1) / SDRFM_Q_ADAPT_SAMPLE;
     if (h->q_adapt_dev && ++h->q_calls_in_window >= SDRFM_Q_ADAPT_WINDOW) {
-      const uint32_t w = h->q_window & 1u;
+      const uint32_t w = h->q_window % 3u;
       // behind this window's calls, on every stream they may have been put on
       hipStream_t wst[3] = {h->ovl_stream[0], h->ovl_stream[1], h->stream};
       for (int k = 0; k < 3; ++k) {
@@ -2077,24 +2077,27 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
         HIP_TRY(hipEventRecord(h->q_win_evt[w][k], wst[k]), SDRFM_FAIL);
         h->q_win_rec[w][k] = true;
       }
+      h->q_stages_of[w] = h->q_stages_window;
       auto wait_window = [&](uint32_t ww) -> hipError_t {
         for (int k = 0; k < 3; ++k)
           if (h->q_win_rec[ww][k]) { const hipError_t e = hipEventSynchronize(h->q_win_evt[ww][k]); if (e != hipSuccess) return e; }
         return hipSuccess;
       };
-      if (h->q_prev_window_open) {                                                    // judge the window before this one: its calls are eight calls old
-        HIP_TRY(wait_window(w ^ 1u), SDRFM_FAIL);
-        const uint32_t passes = *reinterpret_cast<volatile unsigned int*>(h->q_adapt_host + (w ^ 1u));
-        h->q_adapt_host[w ^ 1u] = 0;                                                  // (the next window reports here again)
-        if ((uint64_t)passes * 4u > h->q_stages_prev) {
-          // ... and this window's calls are in flight still: let them finish before their word is cleared for the windows after the pause
+      if (h->q_windows_open >= 2) {                                                   // judge the window before the last one
+        const uint32_t j = (w + 1u) % 3u;
+        HIP_TRY(wait_window(j), SDRFM_FAIL);
+        const uint32_t passes = *reinterpret_cast<volatile unsigned int*>(h->q_adapt_host + j);
+        h->q_adapt_host[j] = 0;                                                       // (the next window reports here)
+        if ((uint64_t)passes * 4u > h->q_stages_of[j]) {
+          // ... the two windows since are in flight still: let them finish before their words are cleared for the windows after the pause
+          HIP_TRY(wait_window((w + 2u) % 3u), SDRFM_FAIL);
           HIP_TRY(wait_window(w), SDRFM_FAIL);
-          h->q_adapt_host[w] = 0;
+          h->q_adapt_host[0] = 0; h->q_adapt_host[1] = 0; h->q_adapt_host[2] = 0;
           h->q_backoff = SDRFM_Q_ADAPT_BACKOFF;
         }
       }
-      h->q_prev_window_open = h->q_backoff == 0;
-      h->q_stages_prev = h->q_stages_window; h->q_stages_window = 0; h->q_calls_in_window = 0; ++h->q_window;
+      h->q_windows_open = h->q_backoff ? 0u : (h->q_windows_open < 2 ? h->q_windows_open + 1 : 2);
+      h->q_stages_window = 0; h->q_calls_in_window = 0; ++h->q_window;
     }
     snprintf(h->kernel_name, sizeof(h->kernel_name), "%s%s", h->fast_q_name, ovl ? " overlapped" : "");
   } else if (stream_ok) {

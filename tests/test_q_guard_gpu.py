@@ -163,7 +163,7 @@ def test_noise_only_streams_move_to_the_bit_exact_kernels_and_back(pkg, oracle_m
         assert names[0] == "fast-q", names
         if expect_switch:
             first = min(k for k, n in enumerate(names) if n != "fast-q")
-            assert 8 <= first <= 24, names                            # after the first window(s) of design-Q calls
+            assert 8 <= first <= 32, names                            # after the first windows of design-Q calls (a window is judged two windows later)
             assert all(n in ("fast-s", "fast-b") for n in names[first:]), names   # ... and for the 1024 calls that follow
         else:
             assert all(n == "fast-q" for n in names), names
