@@ -753,13 +753,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   float* const aout = w.audio + ((size_t)stream * NB + (lane >> 2)) * w.band_stride;
   auto resample_issue = [&]() {
     const float* const myrow = drow + (lane >> 2) * DROW + HDMAX;      // myrow[c] = column c, c in [-HDMAX, DRING)
+    // (the lane's four samples are consecutive: one division for the first — multiplications by 2^32 / L run at a quarter of the rate —,
+    // then loc grows by M: the quotient by M div L, the phase by M mod L, with a carry)
+    const uint32_t Mq = w.M / (uint32_t)L, Mr = w.M - Mq * (uint32_t)L;      // (wave-uniform: scalar code)
+    const uint32_t loc0 = w.res_r0 + (uint32_t)(p_lo + 4 * (lane & 3)) * w.M;
+    uint32_t qq = __umulhi(loc0, w.inv_L32), phi = loc0 - qq * (uint32_t)L;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int jl = p_lo + 4 * (lane & 3) + i;
-      const uint32_t loc = w.res_r0 + (uint32_t)jl * w.M;
-      const uint32_t qq = __umulhi(loc, w.inv_L32);
+      if (i > 0) {
+        phi += Mr; qq += Mq;
+        if (phi >= (uint32_t)L) { phi -= (uint32_t)L; qq += 1u; }
+      }
       const int nrel = w.res_q0 + (int)qq;                        // call-relative step of the sample's newest d
-      const uint32_t phi = loc - qq * (uint32_t)L;
       rok[i] = jl < p_hi;
       int c = p_dcb + (nrel - p_s0);
       if (c >= DRING) c -= DRING;
