@@ -234,14 +234,27 @@ __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
     }
     __syncthreads();
     // the spec's sum over frames is sequential: add this round's frames in frame order (frame o of the round = frame
-    // o mod FPW of wave o / FPW)
+    // o mod FPW of wave o / FPW).  The adds are a serial chain by the spec; the LDS reads are not: eight frames' rows are fetched at once and
+    // then added in order (one LDS latency per eight frames and bin instead of one per frame).  A thread whose bin index is past N
+    // (N < threads) adds bin k mod N into a sum it never stores.
     const uint32_t nfr = (p.F - f0) < (uint32_t)FPR ? (p.F - f0) : (uint32_t)FPR;
+    const float* const PWr = PW + (FUSEP ? par * (NWF * B) : 0u) + (uint32_t)(tid & (N - 1));
+    auto pw_at = [&](uint32_t o, int q) -> float { return PWr[PWS * (o / FPW) + (o % FPW) * N + (uint32_t)((NT * q) & (N - 1))]; };
+    uint32_t o = 0;
+    for (; o + 8 <= nfr; o += 8) {
+      float t[PPT][8];
 #pragma unroll
-    for (int q = 0; q < PPT; ++q) {
-      const int k = tid + NT * q;
-      if (k < N)
-        for (uint32_t o = 0; o < nfr; ++o) S[q] = S[q] + PW[(FUSEP ? par * (NWF * B) : 0u) + PWS * (o / FPW) + (o % FPW) * N + k];
+      for (int q = 0; q < PPT; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[q][j] = pw_at(o + (uint32_t)j, q);
+#pragma unroll
+      for (int q = 0; q < PPT; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) S[q] = S[q] + t[q][j];
     }
+    for (; o < nfr; ++o)
+#pragma unroll
+      for (int q = 0; q < PPT; ++q) S[q] = S[q] + pw_at(o, q);
     if constexpr (!FUSEP) __syncthreads();                     // the blocks are rewritten by the next round (FUSEP: the next round writes
                                                                // the OTHER power region; the barrier above orders this sum before the round after)
   }
