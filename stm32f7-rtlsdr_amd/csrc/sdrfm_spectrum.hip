@@ -24,7 +24,9 @@
 
 typedef float sf2_t __attribute__((ext_vector_type(2)));
 typedef int si4_t __attribute__((ext_vector_type(4)));
+typedef float sf4_t __attribute__((ext_vector_type(4)));
 __device__ sf2_t spec_typed_load_xy(si4_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.format.v2f32");
+__device__ int spec_raw_load_dword(si4_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.i32");
 // buffer resource word3: dst_sel = (R, G, 0, 1), num_format = USCALED (2), data_format = 8_8 (3)
 #define SDRFM_SPEC_RSRC_U8X2 (4 | (5 << 3) | (0 << 6) | (1 << 9) | (2 << 12) | (3 << 15))
 
@@ -40,9 +42,31 @@ struct SParams {
   const float* win;       // N window values
   uint32_t F;             // frames per stream
   float inv_frames;       // 1.0f / F
+#ifdef SPEC_STAMPS
+  unsigned int* dbg;      // experiment: per-wave cycle sums per phase
+#endif
 };
+#ifdef SPEC_STAMPS
+struct Stamps { unsigned int acc[8]; unsigned int last; };
+__device__ __forceinline__ void stamp(Stamps& st, int i) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const unsigned int now = (unsigned int)__builtin_amdgcn_s_memtime();
+  st.acc[i] += now - st.last;
+  st.last = now;
+}
+#define SPEC_STAMP(i) stamp(*stp, i)
+#define SPEC_STAMP_ARG , Stamps* stp
+#define SPEC_STAMP_PASS , stp
+#else
+#define SPEC_STAMP(i)
+#define SPEC_STAMP_ARG
+#define SPEC_STAMP_PASS
+#endif
 
 __device__ __forceinline__ void butterfly(float2& a, float2& b, float2 w) {   // (A, B) -> (A + W B, A - W B)
+#ifdef SPEC_ABL_BFLY
+  asm volatile("" : "+v"(a.x), "+v"(b.x) : "v"(w.x)); return;   // experiment: LDS traffic without the arithmetic
+#endif
   const float tr = __builtin_fmaf(w.x, b.x, -(w.y * b.y));
   const float ti = __builtin_fmaf(w.x, b.y, w.y * b.x);
   const float2 A = a;
@@ -51,8 +75,13 @@ __device__ __forceinline__ void butterfly(float2& a, float2& b, float2 w) {   //
 }
 
 __device__ __forceinline__ void wave_sync() {                  // LDS written by this wave is visible to all of its lanes
+#ifdef SPEC_NODRAIN
+  asm volatile("" ::: "memory");                               // experiment: program order only (a wave's DS operations execute in order)
+  __builtin_amdgcn_wave_barrier();
+#else
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
+#endif
 }
 // LDS index padding: a DIT pass touches points at power-of-two strides (and the bit-reversed scatter at stride N/64), which
 // without padding put all 64 lanes into 4 of the 16 float2 bank slots; one pad slot per 16 and per 256 elements makes every
@@ -68,54 +97,80 @@ __host__ __device__ constexpr int spad(int i) { return i + (i >> 4) + (i >> 8); 
 // PWO != nullptr (last pass only, kernels with a separate power region): the pass stores |point|^2 at PWO[point index] instead of
 // writing the points back — the power phase's LDS round trip (16 writes + 16 reads of 8 bytes per lane and frame) disappears.
 template <int LOGB, int LOGN, int S, int K>
-__device__ __forceinline__ void fft_pass(float2* X, const float2* TW, const float2 (&W1)[8], float* PWO, int lane) {
+__device__ __forceinline__ void fft_pass(float2* X, const float2* TW, const float2 (&W1)[8], float* PWO, int lane SPEC_STAMP_ARG, float* PO = nullptr) {
   constexpr int H = 1 << (S - 1), G = 1 << K, NG = (1 << LOGB) >> K;
-  constexpr int UNR = LOGB >= 12 ? 1 : 4;                      // (4096 points: 16 points x 4 groups unrolled would not fit in VGPRs)
+  constexpr int UNR = LOGB >= 12 ? 1 : (LOGB == 10 ? 8 : 4);   // (PO: the group loop must unroll completely, LOGB = 10 only)                      // (4096 points: 16 points x 4 groups unrolled would not fit in VGPRs)
 #pragma unroll UNR
   for (int g0 = 0; g0 < NG; g0 += 64) {
     const int g = g0 + lane;
     if (NG >= 64 || g < NG) {
-      const int pos = g & (H - 1), base = ((g >> (S - 1)) << (S - 1 + K)) + pos;   // (pos: position within the stage-S block)
+      // Padded addresses without per-access arithmetic.  pos = position within the stage-S block, base = first point of the group.  With
+      // H >= 64 both are (a constant of g0) + lane; with H < 64 there is one group per lane.  spad() is additive over the pieces used below
+      // (a piece that is a multiple of 16 / 256 does not carry into the >> 4 / >> 8 terms of the other: see the asserts), so a point is at
+      // sb + spad(c H) and a twiddle at tb[t] + spad(constant): one address register per pass and per stage, immediate offsets for the rest.
+      static_assert(H >= 16 || H * G <= 16, "c H must not carry into bit 4 of the padded index");
+      static_assert(H >= 256 || H * G <= 256, "c H must not carry into bit 8 of the padded index");
+      static_assert((S == 1 && K == 4) || LOGN - K >= 4, "twiddle strides below 16 would carry (the first pass takes its twiddles from registers)");
+      const int pos0 = H >= 64 ? lane : (g & (H - 1)), posc = H >= 64 ? (g0 & (H - 1)) : 0;
+      const int pos = pos0 + posc;
+      const int basec = H >= 64 ? ((g0 >> (S - 1)) << (S - 1 + K)) + posc : 0;
+      const int base = H >= 64 ? basec + lane : ((g >> (S - 1)) << (S - 1 + K)) + pos;
+      const int sb = H >= 64 ? spad(lane) + spad(basec) : spad(base);
       float2 v[G];
 #pragma unroll
-      for (int c = 0; c < G; ++c) v[c] = X[spad(base + c * H)];
+      for (int c = 0; c < G; ++c) v[c] = X[sb + spad(c * H)];
+      if constexpr (S == 5) { SPEC_STAMP(2); }
 #pragma unroll
       for (int t = 0; t < K; ++t) {                            // stage S + t: half = H 2^t, partner c ^ 2^t
+        const int tb = spad(pos0 << (LOGN - S - t));
 #pragma unroll
         for (int c = 0; c < G; ++c) {
           if ((c >> t) & 1) continue;
-          const int pos_t = pos + (c & ((1 << t) - 1)) * H;    // position of the pair within its stage-(S+t) block
+          const int jc = posc + (c & ((1 << t) - 1)) * H;      // pos_t = pos0 + jc: position of the pair within its stage-(S+t) block
           if constexpr (S == 1 && K == 4) butterfly(v[c], v[c + (1 << t)], W1[(c & ((1 << t) - 1)) << (3 - t)]);   // first pass: the 8 twiddles W16^k, wave-uniform registers
-          else butterfly(v[c], v[c + (1 << t)], TW[spad(pos_t << (LOGN - S - t))]);
+          else butterfly(v[c], v[c + (1 << t)], TW[tb + spad(jc << (LOGN - S - t))]);
         }
       }
-      if (S + K - 1 == LOGN && PWO) {
+      if (S + K - 1 == LOGN && PO) {                           // the powers stay in registers: PO[G (g0 / 64) + c] = |point base + c H|^2
+#pragma unroll
+        for (int c = 0; c < G; ++c) PO[(g0 >> 6) * G + c] = __builtin_fmaf(v[c].x, v[c].x, v[c].y * v[c].y);
+      } else if (S + K - 1 == LOGN && PWO) {
 #pragma unroll
         for (int c = 0; c < G; ++c) PWO[base + c * H] = __builtin_fmaf(v[c].x, v[c].x, v[c].y * v[c].y);
       } else {
 #pragma unroll
-        for (int c = 0; c < G; ++c) X[spad(base + c * H)] = v[c];
+        for (int c = 0; c < G; ++c) X[sb + spad(c * H)] = v[c];
       }
     }
   }
   wave_sync();
+  SPEC_STAMP(S == 5 ? 3 : 5);
 }
 template <int LOGB, int LOGN, int S>
-__device__ __forceinline__ void fft_passes(float2* X, const float2* TW, const float2 (&W1)[8], float* PWO, int lane) {
+__device__ __forceinline__ void fft_passes(float2* X, const float2* TW, const float2 (&W1)[8], float* PWO, int lane SPEC_STAMP_ARG, float* PO = nullptr) {
   if constexpr (S <= LOGN) {
     // up to 4 stages per pass, but no more than leaves a group (2^K points) for each of the 64 lanes
     constexpr int KMAX = (LOGB - 6) >= 4 ? 4 : ((LOGB - 6) >= 2 ? (LOGB - 6) : 2);
     constexpr int K = (LOGN - S + 1) >= KMAX ? KMAX : (LOGN - S + 1);
-    fft_pass<LOGB, LOGN, S, K>(X, TW, W1, PWO, lane);
-    fft_passes<LOGB, LOGN, S + K>(X, TW, W1, PWO, lane);
+    fft_pass<LOGB, LOGN, S, K>(X, TW, W1, PWO, lane SPEC_STAMP_PASS, PO);
+    fft_passes<LOGB, LOGN, S + K>(X, TW, W1, PWO, lane SPEC_STAMP_PASS, PO);
   }
 }
 
-// First pass (stages 1..4) straight from registers: lane l holds the 16 points at bit-reversed-order positions 16 l .. 16 l + 15 of the
-// wave's 1024-point block (loaded from global memory in exactly that pattern: for a fixed register the 64 lanes read a permutation of
-// 64 consecutive samples, so the loads coalesce as before).  Saves the scatter store and the first pass's reads (16 + 16 LDS accesses
-// of 8 bytes per lane and frame).
-__device__ __forceinline__ void fft_first_pass_from_regs(float2 (&v)[16], float2* X, const float2 (&W1)[8], int lane) {
+// First pass (stages 1..4) straight from registers: a lane holds the 16 points at bit-reversed-order positions 16 g .. 16 g + 15 of the
+// wave's 1024-point block, g = spec_group_of_lane (loaded from global memory in exactly that pattern).  Saves the scatter store and the
+// first pass's reads (16 + 16 LDS accesses of 8 bytes per lane and frame).
+// Which 16-point group a lane takes: group g of a frame needs the samples brev4(c) N/16 + brev(g), c = 0..15, so lane l takes the group whose
+// bit-reversed index is l (within its frame, for blocks of several frames): register c of the 64 lanes is then 64 CONSECUTIVE samples in lane
+// order — one fully coalesced 128-byte request.  (With group = lane the same 64 samples arrive in bit-reversed lane order, and the vector L1
+// works through such a request a few lanes at a time: the loads of a round were still outstanding a whole round later.)
+__host__ __device__ constexpr int spec_brev4(int q) { return ((q & 1) << 3) | ((q & 2) << 1) | ((q & 4) >> 1) | ((q & 8) >> 3); }
+template <int LOGN>
+__device__ __forceinline__ int spec_group_of_lane(int lane) {
+  constexpr int LG = LOGN >= 10 ? 6 : LOGN - 4;                // log2(groups per frame), at most the 64 of a wave
+  return (lane & ~((1 << LG) - 1)) | (int)(__brev((uint32_t)(lane & ((1 << LG) - 1))) >> (32 - LG));
+}
+__device__ __forceinline__ void fft_first_pass_from_regs(float2 (&v)[16], float2* X, const float2 (&W1)[8], int grp16) {
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -124,18 +179,23 @@ __device__ __forceinline__ void fft_first_pass_from_regs(float2 (&v)[16], float2
       butterfly(v[c], v[c + (1 << t)], W1[(c & ((1 << t) - 1)) << (3 - t)]);
     }
 #pragma unroll
-  for (int c = 0; c < 16; ++c) X[spad(16 * lane + c)] = v[c];
+  for (int c = 0; c < 16; ++c) X[spad(16 * grp16 + c)] = v[c];
   wave_sync();
 }
 
 // waves per workgroup, one block of frames each: 8, or 4 for 4096 points (LDS: 160 KiB per CU); the short-frame kernels fit
 // 128 VGPRs without the prefetch registers and run 16 waves, which hide the load latency instead
-constexpr int spec_nwf(int logn) { return logn <= 8 ? 16 : (logn <= 11 ? 8 : 4); }
+#ifndef SPEC_NWF10
+#define SPEC_NWF10 8
+#endif
+constexpr int spec_nwf(int logn) { return logn <= 8 ? 16 : (logn <= 10 ? SPEC_NWF10 : (logn <= 11 ? 8 : 4)); }
+// power regions of the fused kernels: two (written alternately, one barrier per round) when they fit beside the blocks, else one (two barriers)
+constexpr int spec_pregions(int logn) { return spec_nwf(logn) <= 8 ? 2 : 1; }
 // points per wave and round: a frame, or for N < 1024 as many whole frames as make 1024 points (all 64 lanes stay busy)
 constexpr int spec_logb(int logn) { return logn < 10 ? 10 : logn; }
 // kernels whose LDS has room for two separate power regions (NWF blocks of floats each, written alternately) fuse the power into the
 // last FFT pass and need one workgroup barrier per round instead of two
-constexpr bool spec_fusep(int logn) { return logn == 9 || logn == 10; }
+constexpr bool spec_fusep(int logn) { return (logn == 9 || logn == 10) && spec_nwf(logn) <= 12; }
 
 template <int LOGN>
 __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
@@ -159,11 +219,12 @@ __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
   for (int k = 0; k < 8; ++k) W1[k] = N >= 16 ? p.tw[k * (N / 16)] : make_float2(1.f, 0.f);
   // up to 1024 points the lane keeps its window values and the next round's samples in registers; longer frames would
   // need > 256 VGPRs for that, so they read the window through the cache and load their samples when they need them
-  constexpr bool REGS = (LOGB <= 10) && (NWF <= 8);
+  constexpr bool REGS = LOGN == 9 || LOGN == 10;
+  constexpr int PREG = spec_pregions(LOGN);
   static_assert(!REGS || PPL == 16, "the register path holds one 16-point first-pass group per lane");
-  // (REGS) register q of a lane holds the point at bit-reversed-order position u = 16 lane + q of the block = sample regs_sample(q)
+  // (REGS) register q of a lane holds the point at bit-reversed-order position u = 16 group + q of the block = sample regs_sample(q)
   auto regs_sample = [&](int q) -> int {
-    const uint32_t u = (uint32_t)(16 * lane + q);
+    const uint32_t u = (uint32_t)(16 * spec_group_of_lane<LOGN>(lane) + q);
     return (int)((u & ~(uint32_t)(N - 1)) | (__brev(u & (uint32_t)(N - 1)) >> (32 - LOGN)));
   };
   constexpr int PR = REGS ? PPL : 1;
@@ -178,21 +239,49 @@ __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
   const si4_t rsrc = {(int)(unsigned)ga, (int)(unsigned)(ga >> 32), (int)p.iq_span, SDRFM_SPEC_RSRC_U8X2};
   const uint32_t sbase = stream * (uint32_t)p.iq_stride;
   sf2_t cur[PR];
+#ifdef SPEC_RAW
+  int curw[PR];
+  const unsigned long long gaw = ga & ~3ull;
+  const uint32_t adj = (uint32_t)(ga & 3ull);
+  const si4_t rsrcw = {(int)(unsigned)gaw, (int)(unsigned)(gaw >> 32), (int)(p.iq_span + adj), 0x00020000};
+  const uint32_t shw = ((adj + sbase + 2u * (uint32_t)regs_sample(0)) & 2u) << 3;
+#endif
   auto fetch = [&](uint32_t f) {                               // the block starting at frame f -> cur (out-of-range reads return 0)
     if constexpr (REGS) {
 #pragma unroll
-      for (int q = 0; q < PPL; ++q)
+      for (int q = 0; q < PPL; ++q) {
+#ifdef SPEC_RAW
+        curw[q] = spec_raw_load_dword(rsrcw, (int)(((adj + sbase + 2u * (f * (uint32_t)N + (uint32_t)regs_sample(0))) & ~3u) + 2u * (uint32_t)(spec_brev4(q) * (N / 16))), 0, 0);   // (register q = sample brev4(q) N/16 + that of register 0: an immediate offset)
+#else
         cur[q] = spec_typed_load_xy(rsrc, (int)(sbase + 2u * (f * (uint32_t)N + (uint32_t)regs_sample(q))), 0, 0);
+#endif
+      }
     }
   };
   if ((uint32_t)(wv * FPW) < p.F) fetch((uint32_t)(wv * FPW));
   __syncthreads();                                             // TW visible
   uint32_t par = 0;                                            // (FUSEP) which of the two power regions this round writes
-  for (uint32_t f0 = 0; f0 < p.F; f0 += FPR, par ^= 1u) {      // a round: frames f0 .. f0+FPR-1, FPW consecutive ones per wave
+#ifdef SPEC_STAMPS
+  Stamps stv; Stamps* stp = &stv;
+  for (int i = 0; i < 8; ++i) stv.acc[i] = 0;
+  stv.last = (unsigned int)__builtin_amdgcn_s_memtime();
+#endif
+  for (uint32_t f0 = 0; f0 < p.F; f0 += FPR, par ^= (PREG == 2 ? 1u : 0u)) {      // a round: frames f0 .. f0+FPR-1, FPW consecutive ones per wave
     const uint32_t f = f0 + (uint32_t)(wv * FPW);
     if (f < p.F) {                                             // (wave-uniform; frames past F in the block are computed, not summed)
       float2 v1[16];
       if constexpr (REGS) {
+#ifdef SPEC_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SPEC_STAMP(0);
+#endif
+#ifdef SPEC_RAW
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const uint32_t w = (uint32_t)curw[q] >> shw;
+          cur[q].x = (float)(w & 0xffu); cur[q].y = (float)((w >> 8) & 0xffu);
+        }
+#endif
 #pragma unroll
         for (int q = 0; q < 16; ++q) v1[q] = make_float2((cur[q].x - 127.5f) * wv_win[q], (cur[q].y - 127.5f) * wv_win[q]);
       } else {
@@ -205,13 +294,15 @@ __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
         }
       }
       if (f + FPR < p.F) fetch(f + FPR);                       // next round's bytes: in flight during this block's FFTs
+      SPEC_STAMP(4);
       // DIT stages in passes of up to 4 stages, each pass entirely in registers (see fft_pass)
       if constexpr (REGS) {
-        fft_first_pass_from_regs(v1, X, W1, lane);
-        fft_passes<LOGB, LOGN, 5>(X, TW, W1, FUSEP ? PWsep + par * (NWF * B) + wv * B : nullptr, lane);
+        fft_first_pass_from_regs(v1, X, W1, spec_group_of_lane<LOGN>(lane));
+        SPEC_STAMP(1);
+        fft_passes<LOGB, LOGN, 5>(X, TW, W1, FUSEP ? PWsep + par * (NWF * B) + wv * B : nullptr, lane SPEC_STAMP_PASS);
       } else {
         wave_sync();
-        fft_passes<LOGB, LOGN, 1>(X, TW, W1, FUSEP ? PWsep + wv * B : nullptr, lane);
+        fft_passes<LOGB, LOGN, 1>(X, TW, W1, FUSEP ? PWsep + wv * B : nullptr, lane SPEC_STAMP_PASS);
       }
       if constexpr (!FUSEP) {
         // powers of this block, written over the start of its own region (PW[2 NPX wv + i]) in blocks of 16 points per lane:
@@ -233,13 +324,14 @@ __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
       }
     }
     __syncthreads();
+    SPEC_STAMP(6);
     // the spec's sum over frames is sequential: add this round's frames in frame order (frame o of the round = frame
     // o mod FPW of wave o / FPW).  The adds are a serial chain by the spec; the LDS reads are not: eight frames' rows are fetched at once and
     // then added in order (one LDS latency per eight frames and bin instead of one per frame).  A thread whose bin index is past N
     // (N < threads) adds bin k mod N into a sum it never stores.
     const uint32_t nfr = (p.F - f0) < (uint32_t)FPR ? (p.F - f0) : (uint32_t)FPR;
-    const float* const PWr = PW + (FUSEP ? par * (NWF * B) : 0u) + (uint32_t)(tid & (N - 1));
-    auto pw_at = [&](uint32_t o, int q) -> float { return PWr[PWS * (o / FPW) + (o % FPW) * N + (uint32_t)((NT * q) & (N - 1))]; };
+    const float* const PWr = PW + (FUSEP ? par * (NWF * B) : 0u);
+    auto pw_at = [&](uint32_t o, int q) -> float { return PWr[PWS * (o / FPW) + (o % FPW) * N + (uint32_t)((tid + NT * q) & (N - 1))]; };
     uint32_t o = 0;
     for (; o + 8 <= nfr; o += 8) {
       float t[PPT][8];
@@ -255,7 +347,8 @@ __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
     for (; o < nfr; ++o)
 #pragma unroll
       for (int q = 0; q < PPT; ++q) S[q] = S[q] + pw_at(o, q);
-    if constexpr (!FUSEP) __syncthreads();                     // the blocks are rewritten by the next round (FUSEP: the next round writes
+    SPEC_STAMP(7);
+    if constexpr (!FUSEP || PREG == 1) __syncthreads();        // the blocks are rewritten by the next round (FUSEP: the next round writes
                                                                // the OTHER power region; the barrier above orders this sum before the round after)
   }
 #pragma unroll
@@ -263,6 +356,187 @@ __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
     const int k = tid + NT * q;
     if (k < N) p.power[(size_t)stream * p.power_stride + (size_t)((k + N / 2) & (N - 1))] = S[q] * p.inv_frames;
   }
+#ifdef SPEC_STAMPS
+  if (p.dbg && lane == 0) for (int i = 0; i < 8; ++i) p.dbg[(stream * NWF + wv) * 8 + i] = stv.acc[i];
+#endif
+}
+
+// LDS written before the barrier is visible after it; unlike __syncthreads() this does not wait for the global loads in flight (the next
+// round's samples stay in flight across it)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// The 512- and 1024-point kernel: ONE WAVE PER BLOCK OF 1024 POINTS, NO WORKGROUP BARRIER IN THE FRAME LOOP.
+// k_spectrum's waves meet at a barrier every round to add their power rows, so they move in lock step — all of them load, all of them
+// transform, all of them wait for LDS at the same time — and every round ends with a tail in which the SIMDs drain.  Here the running sum
+// travels instead: wave w takes blocks w, w + NWF, ...; the last pass leaves the block's powers in registers (lane l: the bins
+// l + 64 i + 256 c of its frame(s)); the wave waits for the running sum after the previous block (written to one of two LDS slots by the wave
+// before it, announced by a sequence word), adds its frames to it IN FRAME ORDER — S = S + P, the spec's sequential sum, the same lane holds
+// the same bins in every wave — and hands it on (the wave with the last block scales and stores it).  The hand-over is a chain through
+// the waves (~350 cycles per block), so in the steady state each wave runs that far behind its predecessor: the waves are spread over the
+// phases of a frame by construction, no barrier tail, no all-to-all of power rows.  Two slots suffice: block b + 2's sum is written after
+// its wave read slot (b + 1) & 1, which was written after block b + 1's wave had read slot b & 1 completely.
+// Samples arrive as raw dwords (lane pairs share one: `buffer_load_dword`, 16 per block and lane, immediate offsets) and are split with
+// v_cvt_f32_ubyte: the typed 2-byte loads of k_spectrum cost ~3x the issue time.  Needs iq and iq_stride even (else k_spectrum).
+template <int LOGN, int NWF, int R>
+__global__ void __launch_bounds__(64 * NWF) k_spectrum_chain(SParams p) {
+  static_assert(LOGN == 9 || LOGN == 10, "the register-fed kernels");
+  constexpr int N = 1 << LOGN, NT = 64 * NWF, LOGB = 10, B = 1 << LOGB, FPW = B / N, SV = 16 / FPW;   // SV: bins per lane
+  extern __shared__ __attribute__((aligned(16))) unsigned char spec_smem[];
+  constexpr int NPT = spad(N / 2 - 1) + 1, NPX = spad(B - 1) + 1;
+  float2* TW = reinterpret_cast<float2*>(spec_smem);
+  const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  float2* X = reinterpret_cast<float2*>(spec_smem) + NPT + wv * NPX;
+  float4* const SL = reinterpret_cast<float4*>(reinterpret_cast<float2*>(spec_smem) + NPT + NWF * NPX);   // slot s: SL[(s SV/4 + j) 64 + lane]
+  uint32_t* const TAG = reinterpret_cast<uint32_t*>(SL + 2 * (SV / 4) * 64);   // TAG[64 s + lane] = 1 + the block whose sum slot s holds (one word per lane)
+  const uint32_t stream = blockIdx.x;
+  for (int i = tid; i < N / 2; i += NT) TW[spad(i)] = p.tw[i];
+  if (tid < 128) TAG[tid] = 0u;
+  float2 W1[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) W1[k] = p.tw[k * (N / 16)];
+  const int grp = spec_group_of_lane<LOGN>(lane);
+  auto regs_sample = [&](int q) -> int {
+    const uint32_t u = (uint32_t)(16 * grp + q);
+    return (int)((u & ~(uint32_t)(N - 1)) | (__brev(u & (uint32_t)(N - 1)) >> (32 - LOGN)));
+  };
+  // the 16 window values of a lane's samples: the same in every wave (and block), kept in LDS as WL[j 64 + lane] (4 x ds_read_b128 per block)
+  float4* const WL = reinterpret_cast<float4*>(TAG + 128);
+  if (wv == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      WL[j * 64 + lane] = make_float4(p.win[regs_sample(4 * j) & (N - 1)], p.win[regs_sample(4 * j + 1) & (N - 1)],
+                                      p.win[regs_sample(4 * j + 2) & (N - 1)], p.win[regs_sample(4 * j + 3) & (N - 1)]);
+  }
+  const unsigned long long ga = (unsigned long long)p.iq, gaw = ga & ~3ull;
+  const uint32_t adj = (uint32_t)(ga & 3ull);                  // 0 or 2
+  const si4_t rsrcw = {(int)(unsigned)gaw, (int)(unsigned)(gaw >> 32), (int)(p.iq_span + adj), 0x00020000};
+  const uint32_t sbase = stream * (uint32_t)p.iq_stride;
+  const uint32_t shw = ((adj + sbase + 2u * (uint32_t)regs_sample(0)) & 2u) << 3;   // which half of its dword a lane's samples are
+  int curw[16];
+  auto fetch = [&](uint32_t b) {                               // block b -> curw (past the batch's span: zeros, never used)
+    const uint32_t v0 = (adj + sbase + 2u * (b * (uint32_t)B + (uint32_t)regs_sample(0))) & ~3u;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) curw[q] = spec_raw_load_dword(rsrcw, (int)(v0 + 2u * (uint32_t)(spec_brev4(q) * (N / 16))), 0, 0);
+  };
+  const uint32_t NB = (p.F + (uint32_t)FPW - 1u) / (uint32_t)FPW;   // blocks (the last one may hold a frame past F: computed, not summed)
+  const uint32_t NR = (NB + (uint32_t)R - 1u) / (uint32_t)R;        // runs of R consecutive blocks: one hand-over of the running sum per run
+  fetch((uint32_t)(wv * R));
+  __syncthreads();                                             // TW, TAG and WL visible; the only workgroup barrier
+#ifdef SPEC_STAMPS
+  Stamps stv; Stamps* stp = &stv;
+  for (int i = 0; i < 8; ++i) stv.acc[i] = 0;
+  stv.last = (unsigned int)__builtin_amdgcn_s_memtime();
+#endif
+  for (uint32_t r = (uint32_t)wv; r < NR; r += (uint32_t)NWF) {
+    float PO[R][16];
+#pragma unroll
+    for (int jr = 0; jr < R; ++jr) {
+      const uint32_t b = r * (uint32_t)R + (uint32_t)jr;
+      if (b < NB) {                                            // (wave-uniform)
+        float2 v1[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 wn4 = WL[j * 64 + lane];
+          const float wn[4] = {wn4.x, wn4.y, wn4.z, wn4.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint32_t w = (uint32_t)curw[4 * j + q] >> shw;
+            v1[4 * j + q] = make_float2(((float)(w & 0xffu) - 127.5f) * wn[q], ((float)((w >> 8) & 0xffu) - 127.5f) * wn[q]);
+          }
+        }
+#ifndef SPEC_ABL_NOFETCH
+        fetch(jr + 1 < R ? b + 1u : (r + (uint32_t)NWF) * (uint32_t)R);   // this wave's next block: in flight during this one's passes
+#else
+#pragma unroll
+        for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(curw[q]));   // experiment: no loads after the first block
+#endif
+        SPEC_STAMP(4);
+        fft_first_pass_from_regs(v1, X, W1, grp);
+        SPEC_STAMP(1);
+        fft_passes<LOGB, LOGN, 5>(X, TW, W1, nullptr, lane SPEC_STAMP_PASS, PO[jr]);
+      }
+    }
+    // the running sum after run r - 1: ONE batch of LDS reads, the slot's tag first — DS operations of a wave execute in order and the
+    // writer stores the tag last, so a batch that sees the tag sees the sum (a batch that does not is repeated).  While the predecessor
+    // itself is still waiting (tag < r - 1) only the tag is watched, one cheap read per 64 cycles.
+    float S[SV];
+    __builtin_amdgcn_s_setprio(3);                             // the hand-over is the one serial chain through the workgroup
+    if (r > 0u) {
+      const uint32_t sl = (r - 1u) & 1u;
+      const uint32_t a_tag = (uint32_t)(uintptr_t)(TAG + sl * 64 + lane), a_dat = (uint32_t)(uintptr_t)(SL + sl * (SV / 4) * 64 + lane);
+      const uint32_t a_tagp = (uint32_t)(uintptr_t)(TAG + (sl ^ 1u) * 64 + lane);
+      uint32_t tag;
+      sf4_t t[SV / 4];
+      auto batch = [&]() {
+        if constexpr (SV == 16)
+          asm volatile("ds_read_b32 %0, %5\n\tds_read_b128 %1, %6\n\tds_read_b128 %2, %6 offset:1024\n\tds_read_b128 %3, %6 offset:2048\n\t"
+                       "ds_read_b128 %4, %6 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(tag), "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[SV / 4 - 2]), "=&v"(t[SV / 4 - 1]) : "v"(a_tag), "v"(a_dat) : "memory");
+        else
+          asm volatile("ds_read_b32 %0, %3\n\tds_read_b128 %1, %4\n\tds_read_b128 %2, %4 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(tag), "=&v"(t[0]), "=&v"(t[1]) : "v"(a_tag), "v"(a_dat) : "memory");
+      };
+      batch();
+      if ((uint32_t)__builtin_amdgcn_readfirstlane((int)tag) != r) {
+        if (r > 1u) {                                          // far from the head of the chain: wait until the predecessor has its input
+          uint32_t tp;
+          for (;;) {
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(tp) : "v"(a_tagp) : "memory");
+            if ((uint32_t)__builtin_amdgcn_readfirstlane((int)tp) >= r - 1u) break;
+            __builtin_amdgcn_s_sleep(2);
+          }
+        }
+        do batch(); while ((uint32_t)__builtin_amdgcn_readfirstlane((int)tag) != r);   // next in line: whole batches, one round trip after the tag lands
+      }
+#pragma unroll
+      for (int j = 0; j < SV / 4; ++j) { S[4 * j] = t[j].x; S[4 * j + 1] = t[j].y; S[4 * j + 2] = t[j].z; S[4 * j + 3] = t[j].w; }
+      SPEC_STAMP(6);
+    } else {
+#pragma unroll
+      for (int j = 0; j < SV; ++j) S[j] = 0.0f;
+    }
+    // N = 1024: PO[.][4 i + c] = bin lane + 64 i + 256 c.  N = 512: PO[.][2 i + c], i < 4: first frame's bin lane + 64 i + 256 c; i >= 4: second frame's
+#pragma unroll
+    for (int jr = 0; jr < R; ++jr) {
+      const uint32_t b = r * (uint32_t)R + (uint32_t)jr;
+      if (b < NB) {
+#pragma unroll
+        for (int j = 0; j < SV; ++j) S[j] = S[j] + PO[jr][j];
+        if constexpr (FPW == 2) {
+          if (b * 2u + 1u < p.F) {
+#pragma unroll
+            for (int j = 0; j < SV; ++j) S[j] = S[j] + PO[jr][SV + j];
+          }
+        }
+      }
+    }
+    if (r + 1u < NR) {
+      const uint32_t sl = r & 1u;
+      const uint32_t a_tag = (uint32_t)(uintptr_t)(TAG + sl * 64 + lane), a_dat = (uint32_t)(uintptr_t)(SL + sl * (SV / 4) * 64 + lane);
+      sf4_t t[SV / 4];
+#pragma unroll
+      for (int j = 0; j < SV / 4; ++j) { t[j].x = S[4 * j]; t[j].y = S[4 * j + 1]; t[j].z = S[4 * j + 2]; t[j].w = S[4 * j + 3]; }
+      const uint32_t tag = r + 1u;
+      if constexpr (SV == 16)
+        asm volatile("ds_write_b128 %1, %2\n\tds_write_b128 %1, %3 offset:1024\n\tds_write_b128 %1, %4 offset:2048\n\tds_write_b128 %1, %5 offset:3072\n\t"
+                     "ds_write_b32 %0, %6" :: "v"(a_tag), "v"(a_dat), "v"(t[0]), "v"(t[1]), "v"(t[SV / 4 - 2]), "v"(t[SV / 4 - 1]), "v"(tag) : "memory");
+      else
+        asm volatile("ds_write_b128 %1, %2\n\tds_write_b128 %1, %3 offset:1024\n\tds_write_b32 %0, %4"
+                     :: "v"(a_tag), "v"(a_dat), "v"(t[0]), "v"(t[1]), "v"(tag) : "memory");
+      __builtin_amdgcn_s_setprio(0);
+      SPEC_STAMP(7);
+    } else {
+      constexpr int GP = FPW == 1 ? 4 : 2;                     // points per group of the last pass
+#pragma unroll
+      for (int j = 0; j < SV; ++j) {
+        const int k = lane + 64 * (j / GP) + 256 * (j % GP);
+        p.power[(size_t)stream * p.power_stride + (size_t)((k + N / 2) & (N - 1))] = S[j] * p.inv_frames;
+      }
+    }
+  }
+#ifdef SPEC_STAMPS
+  if (p.dbg && lane == 0) for (int i = 0; i < 8; ++i) p.dbg[(stream * NWF + wv) * 8 + i] = stv.acc[i];
+#endif
 }
 
 typedef void (*spec_kernel_t)(SParams);
@@ -292,6 +566,10 @@ struct sdrfm_spectrum {
   float* d_power;
   spec_kernel_t kernel;
   size_t lds_bytes;
+  int chain_nwf;           // waves per workgroup of k_spectrum_chain (0: k_spectrum)
+#ifdef SPEC_STAMPS
+  unsigned int* d_dbg;
+#endif
 };
 
 #define STRY(expr, code)                                                                                     \
@@ -306,6 +584,21 @@ struct sdrfm_spectrum {
 static void sfree(sdrfm_spectrum* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
+#ifdef SPEC_STAMPS
+  if (h->d_dbg) {
+    (void)hipDeviceSynchronize();
+    const uint32_t nw = h->cfg.n_streams * (h->chain_nwf ? h->chain_nwf : spec_nwf((int)h->logn));
+    unsigned int* hb = (unsigned int*)malloc((size_t)nw * 8 * sizeof(unsigned int));
+    (void)hipMemcpy(hb, h->d_dbg, (size_t)nw * 8 * sizeof(unsigned int), hipMemcpyDeviceToHost);
+    double sum[8] = {0};
+    for (uint32_t w = 0; w < nw; ++w) for (int i = 0; i < 8; ++i) sum[i] += hb[w * 8 + i];
+    fprintf(stderr, "[spec stamps] mean cycles per wave over the last launch (100 MHz memtime ticks?):");
+    for (int i = 0; i < 8; ++i) fprintf(stderr, " [%d] %.0f", i, sum[i] / nw);
+    fprintf(stderr, "\n");
+    free(hb);
+    (void)hipFree(h->d_dbg);
+  }
+#endif
   void* ptrs[] = {h->d_tw, h->d_win, h->d_iq, h->d_power};
   for (void* q : ptrs) if (q) (void)hipFree(q);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -332,8 +625,25 @@ int sdrfm_spectrum_create(const sdrfm_spectrum_config* cfg, sdrfm_spectrum_t** o
   h->device = cfg->device; h->logn = logn;
   h->max_bytes = cfg->max_bytes_per_call ? cfg->max_bytes_per_call : (1u << 20);
   h->kernel = pick_kernel(logn);
-  h->lds_bytes = ((size_t)(spad((int)cfg->nfft / 2 - 1) + 1) + (size_t)spec_nwf((int)logn) * (size_t)(spad((1 << spec_logb((int)logn)) - 1) + 1)) * sizeof(float2) +
-                 (spec_fusep((int)logn) ? 2 * (size_t)spec_nwf((int)logn) * ((size_t)1 << spec_logb((int)logn)) * sizeof(float) : 0);   // two power regions
+  const char* var_ = getenv("SDRFM_SPEC_VARIANT");
+  const int variant = var_ ? atoi(var_) : 122;                 // waves per workgroup x 10 + blocks per run (0: k_spectrum)
+  const bool phased = (logn == 9 || logn == 10) && variant != 0;
+  h->chain_nwf = 0;
+  if (phased) {
+    const int nwf = variant / 10, rr = variant % 10;
+    h->chain_nwf = nwf;
+#define CK(NW, RR) if (nwf == NW && rr == RR) h->kernel = logn == 9 ? k_spectrum_chain<9, NW, RR> : k_spectrum_chain<10, NW, RR>;
+    h->kernel = nullptr;
+    CK(8, 1) CK(8, 2) CK(12, 1) CK(12, 2) CK(12, 3) CK(16, 1) CK(8, 3)
+#undef CK
+    if (!h->kernel) { delete h; return SDRFM_EINVAL; }
+  }
+  const size_t npt = (size_t)(spad((int)cfg->nfft / 2 - 1) + 1), npx = (size_t)(spad((1 << spec_logb((int)logn)) - 1) + 1);
+  if (h->chain_nwf)
+    h->lds_bytes = (npt + (size_t)h->chain_nwf * npx) * sizeof(float2) + 2 * 4096 + 512 + 4096;   // twiddles, blocks, two sum slots, their tags, the lanes' window values
+  else
+    h->lds_bytes = (npt + (size_t)spec_nwf((int)logn) * npx) * sizeof(float2) +
+                   (spec_fusep((int)logn) ? spec_pregions((int)logn) * (size_t)spec_nwf((int)logn) * ((size_t)1 << spec_logb((int)logn)) * sizeof(float) : 0);   // power region(s)
 #define CR(expr) do { if ((expr) != hipSuccess) { sfree(h); return SDRFM_ENOMEM; } } while (0)
   CR(hipSetDevice(h->device));
   if (h->lds_bytes > 64 * 1024 &&
@@ -388,7 +698,11 @@ static int senqueue(sdrfm_spectrum* h, const uint8_t* d_iq, size_t iq_stride, ui
   SParams p;
   p.iq = d_iq; p.iq_stride = iq_stride; p.iq_span = (uint32_t)span; p.power = d_power; p.power_stride = power_stride;
   p.tw = h->d_tw; p.win = h->d_win; p.F = F; p.inv_frames = 1.0f / (float)F;
-  hipLaunchKernelGGL(h->kernel, dim3(ns), dim3(64 * spec_nwf((int)h->logn)), h->lds_bytes, h->stream, p);
+#ifdef SPEC_STAMPS
+  if (!h->d_dbg) (void)hipMalloc(&h->d_dbg, (size_t)ns * 16 * 8 * sizeof(unsigned int));
+  p.dbg = h->d_dbg;
+#endif
+  hipLaunchKernelGGL(h->kernel, dim3(ns), dim3(64 * (h->chain_nwf ? h->chain_nwf : spec_nwf((int)h->logn))), h->lds_bytes, h->stream, p);
   STRY(hipGetLastError(), SDRFM_FAIL);
   return SDRFM_OK;
 }
