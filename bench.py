@@ -596,7 +596,7 @@ def main_spectrum(args, pkg, world, rank, local_rank, use_dist, rccl_world):
     frames = last["n"]
     if rank == 0:
         alg = ns * frames * nfft * 2.0 + ns * nfft * 4.0
-        kname = "k_spectrum<%d>" % int(np.log2(nfft))
+        kname = sv.kernel_name
         res = {"metric": "IQ MSamples/s through the windowed-FFT spectrum view", "value": round(world * ns * frames * nfft * args.steps / elapsed / 1e6, 1),
                "unit": "MSamples/s", "n_gpus": world, "rccl_world": rccl_world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -42,11 +42,13 @@ struct SParams {
   const float* win;       // N window values
   uint32_t F;             // frames per stream
   float inv_frames;       // 1.0f / F
-#ifdef SPEC_STAMPS
-  unsigned int* dbg;      // experiment: per-wave cycle sums per phase
+#ifdef SDRFM_DEV
+  unsigned int* dbg;      // development library: per-wave cycle sums per phase of k_spectrum_chain (or null)
 #endif
 };
-#ifdef SPEC_STAMPS
+#ifdef SDRFM_DEV
+// phase stamps (development library only): s_memtime at the phase boundaries of k_spectrum_chain, summed per wave.  A stamp waits for the
+// wave's outstanding LDS operations, so a phase's figure includes the drain of what it issued.
 struct Stamps { unsigned int acc[8]; unsigned int last; };
 __device__ __forceinline__ void stamp(Stamps& st, int i) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -64,9 +66,6 @@ __device__ __forceinline__ void stamp(Stamps& st, int i) {
 #endif
 
 __device__ __forceinline__ void butterfly(float2& a, float2& b, float2 w) {   // (A, B) -> (A + W B, A - W B)
-#ifdef SPEC_ABL_BFLY
-  asm volatile("" : "+v"(a.x), "+v"(b.x) : "v"(w.x)); return;   // experiment: LDS traffic without the arithmetic
-#endif
   const float tr = __builtin_fmaf(w.x, b.x, -(w.y * b.y));
   const float ti = __builtin_fmaf(w.x, b.y, w.y * b.x);
   const float2 A = a;
@@ -75,13 +74,8 @@ __device__ __forceinline__ void butterfly(float2& a, float2& b, float2 w) {   //
 }
 
 __device__ __forceinline__ void wave_sync() {                  // LDS written by this wave is visible to all of its lanes
-#ifdef SPEC_NODRAIN
-  asm volatile("" ::: "memory");                               // experiment: program order only (a wave's DS operations execute in order)
-  __builtin_amdgcn_wave_barrier();
-#else
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
-#endif
 }
 // LDS index padding: a DIT pass touches points at power-of-two strides (and the bit-reversed scatter at stride N/64), which
 // without padding put all 64 lanes into 4 of the 16 float2 bank slots; one pad slot per 16 and per 256 elements makes every
@@ -96,10 +90,13 @@ __host__ __device__ constexpr int spad(int i) { return i + (i >> 4) + (i >> 8); 
 // different frames, so the same pass transforms all of them at once (index arithmetic over the block, twiddles of N).
 // PWO != nullptr (last pass only, kernels with a separate power region): the pass stores |point|^2 at PWO[point index] instead of
 // writing the points back — the power phase's LDS round trip (16 writes + 16 reads of 8 bytes per lane and frame) disappears.
+// PO != nullptr (last pass only): the powers stay in registers.  TR != nullptr: the pass's twiddles come from registers (filled once per
+// kernel in the order TR[(G - 1) group + 2^t - 1 + j]) instead of the LDS table.
 template <int LOGB, int LOGN, int S, int K>
-__device__ __forceinline__ void fft_pass(float2* X, const float2* TW, const float2 (&W1)[8], float* PWO, int lane SPEC_STAMP_ARG, float* PO = nullptr) {
+__device__ __forceinline__ void fft_pass(float2* X, const float2* TW, const float2 (&W1)[8], float* PWO, int lane SPEC_STAMP_ARG, float* PO = nullptr, const float2* TR = nullptr) {
   constexpr int H = 1 << (S - 1), G = 1 << K, NG = (1 << LOGB) >> K;
-  constexpr int UNR = LOGB >= 12 ? 1 : (LOGB == 10 ? 8 : 4);   // (PO: the group loop must unroll completely, LOGB = 10 only)                      // (4096 points: 16 points x 4 groups unrolled would not fit in VGPRs)
+  // (4096 points: 16 points x 4 groups unrolled would not fit in VGPRs; PO / TR, LOGB = 10 only: the group loop must unroll completely)
+  constexpr int UNR = LOGB >= 12 ? 1 : (LOGB == 10 ? 8 : 4);
 #pragma unroll UNR
   for (int g0 = 0; g0 < NG; g0 += 64) {
     const int g = g0 + lane;
@@ -128,6 +125,7 @@ __device__ __forceinline__ void fft_pass(float2* X, const float2* TW, const floa
           if ((c >> t) & 1) continue;
           const int jc = posc + (c & ((1 << t) - 1)) * H;      // pos_t = pos0 + jc: position of the pair within its stage-(S+t) block
           if constexpr (S == 1 && K == 4) butterfly(v[c], v[c + (1 << t)], W1[(c & ((1 << t) - 1)) << (3 - t)]);   // first pass: the 8 twiddles W16^k, wave-uniform registers
+          else if (TR) butterfly(v[c], v[c + (1 << t)], TR[(g0 >> 6) * (G - 1) + (1 << t) - 1 + (c & ((1 << t) - 1))]);   // twiddles kept in registers
           else butterfly(v[c], v[c + (1 << t)], TW[tb + spad(jc << (LOGN - S - t))]);
         }
       }
@@ -185,17 +183,12 @@ __device__ __forceinline__ void fft_first_pass_from_regs(float2 (&v)[16], float2
 
 // waves per workgroup, one block of frames each: 8, or 4 for 4096 points (LDS: 160 KiB per CU); the short-frame kernels fit
 // 128 VGPRs without the prefetch registers and run 16 waves, which hide the load latency instead
-#ifndef SPEC_NWF10
-#define SPEC_NWF10 8
-#endif
-constexpr int spec_nwf(int logn) { return logn <= 8 ? 16 : (logn <= 10 ? SPEC_NWF10 : (logn <= 11 ? 8 : 4)); }
-// power regions of the fused kernels: two (written alternately, one barrier per round) when they fit beside the blocks, else one (two barriers)
-constexpr int spec_pregions(int logn) { return spec_nwf(logn) <= 8 ? 2 : 1; }
+constexpr int spec_nwf(int logn) { return logn <= 8 ? 16 : (logn <= 11 ? 8 : 4); }
 // points per wave and round: a frame, or for N < 1024 as many whole frames as make 1024 points (all 64 lanes stay busy)
 constexpr int spec_logb(int logn) { return logn < 10 ? 10 : logn; }
 // kernels whose LDS has room for two separate power regions (NWF blocks of floats each, written alternately) fuse the power into the
 // last FFT pass and need one workgroup barrier per round instead of two
-constexpr bool spec_fusep(int logn) { return (logn == 9 || logn == 10) && spec_nwf(logn) <= 12; }
+constexpr bool spec_fusep(int logn) { return logn == 9 || logn == 10; }
 
 template <int LOGN>
 __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
@@ -220,7 +213,6 @@ __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
   // up to 1024 points the lane keeps its window values and the next round's samples in registers; longer frames would
   // need > 256 VGPRs for that, so they read the window through the cache and load their samples when they need them
   constexpr bool REGS = LOGN == 9 || LOGN == 10;
-  constexpr int PREG = spec_pregions(LOGN);
   static_assert(!REGS || PPL == 16, "the register path holds one 16-point first-pass group per lane");
   // (REGS) register q of a lane holds the point at bit-reversed-order position u = 16 group + q of the block = sample regs_sample(q)
   auto regs_sample = [&](int q) -> int {
@@ -239,49 +231,26 @@ __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
   const si4_t rsrc = {(int)(unsigned)ga, (int)(unsigned)(ga >> 32), (int)p.iq_span, SDRFM_SPEC_RSRC_U8X2};
   const uint32_t sbase = stream * (uint32_t)p.iq_stride;
   sf2_t cur[PR];
-#ifdef SPEC_RAW
-  int curw[PR];
-  const unsigned long long gaw = ga & ~3ull;
-  const uint32_t adj = (uint32_t)(ga & 3ull);
-  const si4_t rsrcw = {(int)(unsigned)gaw, (int)(unsigned)(gaw >> 32), (int)(p.iq_span + adj), 0x00020000};
-  const uint32_t shw = ((adj + sbase + 2u * (uint32_t)regs_sample(0)) & 2u) << 3;
-#endif
   auto fetch = [&](uint32_t f) {                               // the block starting at frame f -> cur (out-of-range reads return 0)
     if constexpr (REGS) {
 #pragma unroll
-      for (int q = 0; q < PPL; ++q) {
-#ifdef SPEC_RAW
-        curw[q] = spec_raw_load_dword(rsrcw, (int)(((adj + sbase + 2u * (f * (uint32_t)N + (uint32_t)regs_sample(0))) & ~3u) + 2u * (uint32_t)(spec_brev4(q) * (N / 16))), 0, 0);   // (register q = sample brev4(q) N/16 + that of register 0: an immediate offset)
-#else
+      for (int q = 0; q < PPL; ++q)
         cur[q] = spec_typed_load_xy(rsrc, (int)(sbase + 2u * (f * (uint32_t)N + (uint32_t)regs_sample(q))), 0, 0);
-#endif
-      }
     }
   };
   if ((uint32_t)(wv * FPW) < p.F) fetch((uint32_t)(wv * FPW));
   __syncthreads();                                             // TW visible
   uint32_t par = 0;                                            // (FUSEP) which of the two power regions this round writes
-#ifdef SPEC_STAMPS
-  Stamps stv; Stamps* stp = &stv;
+#ifdef SDRFM_DEV
+  Stamps stv; Stamps* stp = &stv;                              // (the stamps of the shared passes go nowhere in this kernel)
   for (int i = 0; i < 8; ++i) stv.acc[i] = 0;
-  stv.last = (unsigned int)__builtin_amdgcn_s_memtime();
+  stv.last = 0;
 #endif
-  for (uint32_t f0 = 0; f0 < p.F; f0 += FPR, par ^= (PREG == 2 ? 1u : 0u)) {      // a round: frames f0 .. f0+FPR-1, FPW consecutive ones per wave
+  for (uint32_t f0 = 0; f0 < p.F; f0 += FPR, par ^= 1u) {      // a round: frames f0 .. f0+FPR-1, FPW consecutive ones per wave
     const uint32_t f = f0 + (uint32_t)(wv * FPW);
     if (f < p.F) {                                             // (wave-uniform; frames past F in the block are computed, not summed)
       float2 v1[16];
       if constexpr (REGS) {
-#ifdef SPEC_STAMPS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        SPEC_STAMP(0);
-#endif
-#ifdef SPEC_RAW
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const uint32_t w = (uint32_t)curw[q] >> shw;
-          cur[q].x = (float)(w & 0xffu); cur[q].y = (float)((w >> 8) & 0xffu);
-        }
-#endif
 #pragma unroll
         for (int q = 0; q < 16; ++q) v1[q] = make_float2((cur[q].x - 127.5f) * wv_win[q], (cur[q].y - 127.5f) * wv_win[q]);
       } else {
@@ -294,11 +263,9 @@ __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
         }
       }
       if (f + FPR < p.F) fetch(f + FPR);                       // next round's bytes: in flight during this block's FFTs
-      SPEC_STAMP(4);
       // DIT stages in passes of up to 4 stages, each pass entirely in registers (see fft_pass)
       if constexpr (REGS) {
         fft_first_pass_from_regs(v1, X, W1, spec_group_of_lane<LOGN>(lane));
-        SPEC_STAMP(1);
         fft_passes<LOGB, LOGN, 5>(X, TW, W1, FUSEP ? PWsep + par * (NWF * B) + wv * B : nullptr, lane SPEC_STAMP_PASS);
       } else {
         wave_sync();
@@ -324,7 +291,6 @@ __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
       }
     }
     __syncthreads();
-    SPEC_STAMP(6);
     // the spec's sum over frames is sequential: add this round's frames in frame order (frame o of the round = frame
     // o mod FPW of wave o / FPW).  The adds are a serial chain by the spec; the LDS reads are not: eight frames' rows are fetched at once and
     // then added in order (one LDS latency per eight frames and bin instead of one per frame).  A thread whose bin index is past N
@@ -347,8 +313,7 @@ __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
     for (; o < nfr; ++o)
 #pragma unroll
       for (int q = 0; q < PPT; ++q) S[q] = S[q] + pw_at(o, q);
-    SPEC_STAMP(7);
-    if constexpr (!FUSEP || PREG == 1) __syncthreads();        // the blocks are rewritten by the next round (FUSEP: the next round writes
+    if constexpr (!FUSEP) __syncthreads();        // the blocks are rewritten by the next round (FUSEP: the next round writes
                                                                // the OTHER power region; the barrier above orders this sum before the round after)
   }
 #pragma unroll
@@ -356,27 +321,23 @@ __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
     const int k = tid + NT * q;
     if (k < N) p.power[(size_t)stream * p.power_stride + (size_t)((k + N / 2) & (N - 1))] = S[q] * p.inv_frames;
   }
-#ifdef SPEC_STAMPS
-  if (p.dbg && lane == 0) for (int i = 0; i < 8; ++i) p.dbg[(stream * NWF + wv) * 8 + i] = stv.acc[i];
-#endif
 }
 
-// LDS written before the barrier is visible after it; unlike __syncthreads() this does not wait for the global loads in flight (the next
-// round's samples stay in flight across it)
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// The 512- and 1024-point kernel: ONE WAVE PER BLOCK OF 1024 POINTS, NO WORKGROUP BARRIER IN THE FRAME LOOP.
+// The 512- and 1024-point kernel: THE RUNNING SUM TRAVELS, NO WORKGROUP BARRIER IN THE FRAME LOOP.
 // k_spectrum's waves meet at a barrier every round to add their power rows, so they move in lock step — all of them load, all of them
-// transform, all of them wait for LDS at the same time — and every round ends with a tail in which the SIMDs drain.  Here the running sum
-// travels instead: wave w takes blocks w, w + NWF, ...; the last pass leaves the block's powers in registers (lane l: the bins
-// l + 64 i + 256 c of its frame(s)); the wave waits for the running sum after the previous block (written to one of two LDS slots by the wave
-// before it, announced by a sequence word), adds its frames to it IN FRAME ORDER — S = S + P, the spec's sequential sum, the same lane holds
-// the same bins in every wave — and hands it on (the wave with the last block scales and stores it).  The hand-over is a chain through
-// the waves (~350 cycles per block), so in the steady state each wave runs that far behind its predecessor: the waves are spread over the
-// phases of a frame by construction, no barrier tail, no all-to-all of power rows.  Two slots suffice: block b + 2's sum is written after
-// its wave read slot (b + 1) & 1, which was written after block b + 1's wave had read slot b & 1 completely.
-// Samples arrive as raw dwords (lane pairs share one: `buffer_load_dword`, 16 per block and lane, immediate offsets) and are split with
-// v_cvt_f32_ubyte: the typed 2-byte loads of k_spectrum cost ~3x the issue time.  Needs iq and iq_stride even (else k_spectrum).
+// transform, all of them wait for LDS at the same time (measured: ~3300 of 7300 cycles per round spent issuing the sample loads, 1350 at the
+// barrier) — and every round ends with a tail in which the SIMDs drain.  Here a wave takes RUNS of R consecutive blocks of 1024 points
+// (a frame, or two 512-point frames side by side): run r = w, w + NWF, ...  The last pass leaves a block's powers in registers (lane l: the
+// bins l + 64 i + 256 c of its frame(s)); after its run the wave fetches the running sum after run r - 1 from one of two LDS slots (written
+// by the wave before it, a per-lane tag written last), adds its frames to it IN FRAME ORDER — S = S + P, the spec's sequential sum; the
+// same lane holds the same bins in every wave — and hands it on; the wave with the last run scales and stores it.  The hand-over is one
+// serial chain through the workgroup (~1100-1400 cycles per hop under load: two LDS round trips and the adds), so the waves spread over
+// the phases of a frame by construction: no barrier tail, no all-to-all of power rows.  R = 1 is bound by that chain (234 hops: 110 us),
+// R = 2 is not (89 us); R = 3 gains nothing more and costs 16 registers.  Two slots suffice: the sum after run r + 2 is written by a wave
+// that has read slot (r + 1) & 1, which was written after run r + 1's wave had read slot r & 1 completely.
+// Samples arrive as raw dwords (lane pairs share one: `buffer_load_dword`, 16 per block and lane at immediate offsets from one address)
+// and are split with v_cvt_f32_ubyte: a typed 2-byte load costs ~3x the issue time.  Needs iq and iq_stride even (else k_spectrum).
+// The window values of a lane's 16 samples and the last pass's twiddles are the same for every block: LDS (4 x ds_read_b128) / registers.
 template <int LOGN, int NWF, int R>
 __global__ void __launch_bounds__(64 * NWF) k_spectrum_chain(SParams p) {
   static_assert(LOGN == 9 || LOGN == 10, "the register-fed kernels");
@@ -409,7 +370,8 @@ __global__ void __launch_bounds__(64 * NWF) k_spectrum_chain(SParams p) {
   }
   const unsigned long long ga = (unsigned long long)p.iq, gaw = ga & ~3ull;
   const uint32_t adj = (uint32_t)(ga & 3ull);                  // 0 or 2
-  const si4_t rsrcw = {(int)(unsigned)gaw, (int)(unsigned)(gaw >> 32), (int)(p.iq_span + adj), 0x00020000};
+  // (the range covers whole dwords: with iq = 2 mod 4 the first and the last sample of the batch share theirs with two bytes outside it)
+  const si4_t rsrcw = {(int)(unsigned)gaw, (int)(unsigned)(gaw >> 32), (int)((p.iq_span + adj + 3u) & ~3u), 0x00020000};
   const uint32_t sbase = stream * (uint32_t)p.iq_stride;
   const uint32_t shw = ((adj + sbase + 2u * (uint32_t)regs_sample(0)) & 2u) << 3;   // which half of its dword a lane's samples are
   int curw[16];
@@ -422,11 +384,22 @@ __global__ void __launch_bounds__(64 * NWF) k_spectrum_chain(SParams p) {
   const uint32_t NR = (NB + (uint32_t)R - 1u) / (uint32_t)R;        // runs of R consecutive blocks: one hand-over of the running sum per run
   fetch((uint32_t)(wv * R));
   __syncthreads();                                             // TW, TAG and WL visible; the only workgroup barrier
-#ifdef SPEC_STAMPS
+#ifdef SDRFM_DEV
   Stamps stv; Stamps* stp = &stv;
   for (int i = 0; i < 8; ++i) stv.acc[i] = 0;
   stv.last = (unsigned int)__builtin_amdgcn_s_memtime();
 #endif
+  constexpr int K3 = LOGN - 8, G3 = 1 << K3, NI3 = (B >> K3) / 64;   // the last pass: stages 9 .. LOGN, NI3 groups per lane
+  float2 TR3[NI3 * (G3 - 1)];                                  // its twiddles: the same for every block, kept in registers
+#pragma unroll
+  for (int i = 0; i < NI3; ++i)
+#pragma unroll
+    for (int t = 0; t < K3; ++t)
+#pragma unroll
+      for (int j = 0; j < (1 << t); ++j) {
+        const int posc = (64 * i) & 255, jc = posc + j * 256, sh = LOGN - 9 - t;
+        TR3[i * (G3 - 1) + (1 << t) - 1 + j] = TW[spad(lane << sh) + spad(jc << sh)];
+      }
   for (uint32_t r = (uint32_t)wv; r < NR; r += (uint32_t)NWF) {
     float PO[R][16];
 #pragma unroll
@@ -444,16 +417,12 @@ __global__ void __launch_bounds__(64 * NWF) k_spectrum_chain(SParams p) {
             v1[4 * j + q] = make_float2(((float)(w & 0xffu) - 127.5f) * wn[q], ((float)((w >> 8) & 0xffu) - 127.5f) * wn[q]);
           }
         }
-#ifndef SPEC_ABL_NOFETCH
         fetch(jr + 1 < R ? b + 1u : (r + (uint32_t)NWF) * (uint32_t)R);   // this wave's next block: in flight during this one's passes
-#else
-#pragma unroll
-        for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(curw[q]));   // experiment: no loads after the first block
-#endif
         SPEC_STAMP(4);
         fft_first_pass_from_regs(v1, X, W1, grp);
         SPEC_STAMP(1);
-        fft_passes<LOGB, LOGN, 5>(X, TW, W1, nullptr, lane SPEC_STAMP_PASS, PO[jr]);
+        fft_pass<LOGB, LOGN, 5, 4>(X, TW, W1, nullptr, lane SPEC_STAMP_PASS);
+        fft_pass<LOGB, LOGN, 9, K3>(X, TW, W1, nullptr, lane SPEC_STAMP_PASS, PO[jr], TR3);
       }
     }
     // the running sum after run r - 1: ONE batch of LDS reads, the slot's tag first — DS operations of a wave execute in order and the
@@ -534,7 +503,7 @@ __global__ void __launch_bounds__(64 * NWF) k_spectrum_chain(SParams p) {
       }
     }
   }
-#ifdef SPEC_STAMPS
+#ifdef SDRFM_DEV
   if (p.dbg && lane == 0) for (int i = 0; i < 8; ++i) p.dbg[(stream * NWF + wv) * 8 + i] = stv.acc[i];
 #endif
 }
@@ -564,11 +533,16 @@ struct sdrfm_spectrum {
   float* d_win;
   uint8_t* d_iq; size_t d_iq_stride;
   float* d_power;
-  spec_kernel_t kernel;
+  spec_kernel_t kernel;     // k_spectrum<log2 N>: every N; for N = 512 / 1024 only when iq or iq_stride is odd
   size_t lds_bytes;
-  int chain_nwf;           // waves per workgroup of k_spectrum_chain (0: k_spectrum)
-#ifdef SPEC_STAMPS
-  unsigned int* d_dbg;
+  spec_kernel_t chain;      // k_spectrum_chain (N = 512 / 1024, iq and iq_stride even) or null
+  size_t chain_lds_bytes;
+  int chain_nwf;            // its waves per workgroup
+  char name[2][48];         // kernel names as the profiler prints them: [0] k_spectrum<..>, [1] k_spectrum_chain<..>
+  int last;                 // which of the two the last call launched
+#ifdef SDRFM_DEV
+  unsigned int* d_dbg;      // phase stamps (SDRFM_SPEC_STAMPS=1)
+  int stamps;
 #endif
 };
 
@@ -584,15 +558,17 @@ struct sdrfm_spectrum {
 static void sfree(sdrfm_spectrum* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
-#ifdef SPEC_STAMPS
+#ifdef SDRFM_DEV
   if (h->d_dbg) {
     (void)hipDeviceSynchronize();
-    const uint32_t nw = h->cfg.n_streams * (h->chain_nwf ? h->chain_nwf : spec_nwf((int)h->logn));
+    const uint32_t nw = h->cfg.n_streams * (uint32_t)h->chain_nwf;
     unsigned int* hb = (unsigned int*)malloc((size_t)nw * 8 * sizeof(unsigned int));
     (void)hipMemcpy(hb, h->d_dbg, (size_t)nw * 8 * sizeof(unsigned int), hipMemcpyDeviceToHost);
     double sum[8] = {0};
     for (uint32_t w = 0; w < nw; ++w) for (int i = 0; i < 8; ++i) sum[i] += hb[w * 8 + i];
-    fprintf(stderr, "[spec stamps] mean cycles per wave over the last launch (100 MHz memtime ticks?):");
+    // [4] samples -> points, next block's loads issued  [1] first pass  [2] second pass: points read  [3] its butterflies and write-back
+    // [5] last pass  [6] waiting for / fetching the running sum  [7] adds and hand-over   (shader cycles, summed over the wave's blocks)
+    fprintf(stderr, "[spec stamps] k_spectrum_chain, %d waves per workgroup: mean shader cycles per wave in the last launch:", h->chain_nwf);
     for (int i = 0; i < 8; ++i) fprintf(stderr, " [%d] %.0f", i, sum[i] / nw);
     fprintf(stderr, "\n");
     free(hb);
@@ -625,29 +601,36 @@ int sdrfm_spectrum_create(const sdrfm_spectrum_config* cfg, sdrfm_spectrum_t** o
   h->device = cfg->device; h->logn = logn;
   h->max_bytes = cfg->max_bytes_per_call ? cfg->max_bytes_per_call : (1u << 20);
   h->kernel = pick_kernel(logn);
-  const char* var_ = getenv("SDRFM_SPEC_VARIANT");
-  const int variant = var_ ? atoi(var_) : 122;                 // waves per workgroup x 10 + blocks per run (0: k_spectrum)
-  const bool phased = (logn == 9 || logn == 10) && variant != 0;
-  h->chain_nwf = 0;
-  if (phased) {
-    const int nwf = variant / 10, rr = variant % 10;
-    h->chain_nwf = nwf;
-#define CK(NW, RR) if (nwf == NW && rr == RR) h->kernel = logn == 9 ? k_spectrum_chain<9, NW, RR> : k_spectrum_chain<10, NW, RR>;
-    h->kernel = nullptr;
-    CK(8, 1) CK(8, 2) CK(12, 1) CK(12, 2) CK(12, 3) CK(16, 1) CK(8, 3)
-#undef CK
-    if (!h->kernel) { delete h; return SDRFM_EINVAL; }
-  }
   const size_t npt = (size_t)(spad((int)cfg->nfft / 2 - 1) + 1), npx = (size_t)(spad((1 << spec_logb((int)logn)) - 1) + 1);
-  if (h->chain_nwf)
-    h->lds_bytes = (npt + (size_t)h->chain_nwf * npx) * sizeof(float2) + 2 * 4096 + 512 + 4096;   // twiddles, blocks, two sum slots, their tags, the lanes' window values
-  else
-    h->lds_bytes = (npt + (size_t)spec_nwf((int)logn) * npx) * sizeof(float2) +
-                   (spec_fusep((int)logn) ? spec_pregions((int)logn) * (size_t)spec_nwf((int)logn) * ((size_t)1 << spec_logb((int)logn)) * sizeof(float) : 0);   // power region(s)
+  h->lds_bytes = (npt + (size_t)spec_nwf((int)logn) * npx) * sizeof(float2) +
+                 (spec_fusep((int)logn) ? 2 * (size_t)spec_nwf((int)logn) * ((size_t)1 << spec_logb((int)logn)) * sizeof(float) : 0);   // two power regions
+  snprintf(h->name[0], sizeof(h->name[0]), "k_spectrum<%u>", logn);
+  if (logn == 9 || logn == 10) {                               // 12 waves per workgroup, runs of 2 blocks (see k_spectrum_chain)
+    h->chain_nwf = 12;
+    h->chain = logn == 9 ? k_spectrum_chain<9, 12, 2> : k_spectrum_chain<10, 12, 2>;
+#ifdef SDRFM_DEV
+    // development library: SDRFM_SPEC_VARIANT = waves per workgroup x 10 + blocks per run (0: k_spectrum), SDRFM_SPEC_STAMPS=1: phase stamps
+    const char* var_ = getenv("SDRFM_SPEC_VARIANT");
+    const int variant = var_ ? atoi(var_) : 122, nwf = variant / 10, rr = variant % 10;
+    h->stamps = getenv("SDRFM_SPEC_STAMPS") != nullptr;
+    if (variant == 0) h->chain = nullptr;
+#define CK(NW, RR) if (nwf == NW && rr == RR) { h->chain = logn == 9 ? k_spectrum_chain<9, NW, RR> : k_spectrum_chain<10, NW, RR>; h->chain_nwf = NW; }
+    CK(8, 1) CK(8, 2) CK(8, 3) CK(12, 1) CK(12, 3) CK(16, 1)
+#undef CK
+#endif
+    int rr_ = 2;
+#ifdef SDRFM_DEV
+    if (h->chain && var_ && variant) rr_ = rr;
+#endif
+    snprintf(h->name[1], sizeof(h->name[1]), "k_spectrum_chain<%u, %d, %d>", logn, h->chain_nwf, rr_);
+    h->chain_lds_bytes = (npt + (size_t)h->chain_nwf * npx) * sizeof(float2) + 2 * 4096 + 512 + 4096;   // twiddles, blocks, two sum slots, their tags, the lanes' window values
+  }
 #define CR(expr) do { if ((expr) != hipSuccess) { sfree(h); return SDRFM_ENOMEM; } } while (0)
   CR(hipSetDevice(h->device));
-  if (h->lds_bytes > 64 * 1024 &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(h->kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) {
+  if ((h->lds_bytes > 64 * 1024 &&
+       hipFuncSetAttribute(reinterpret_cast<const void*>(h->kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) ||
+      (h->chain && h->chain_lds_bytes > 64 * 1024 &&
+       hipFuncSetAttribute(reinterpret_cast<const void*>(h->chain), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->chain_lds_bytes) != hipSuccess)) {
     sfree(h);
     return SDRFM_NOT_SUPPORTED;
   }
@@ -666,11 +649,14 @@ int sdrfm_spectrum_create(const sdrfm_spectrum_config* cfg, sdrfm_spectrum_t** o
   free(tw); free(win);
   CR(e);
 #undef CR
+  h->last = h->chain ? 1 : 0;
   *out = h;
   return SDRFM_OK;
 }
 
 void sdrfm_spectrum_destroy(sdrfm_spectrum_t* h) { sfree(h); }
+
+const char* sdrfm_spectrum_kernel_name(const sdrfm_spectrum_t* h) { return h ? h->name[h->last] : ""; }
 
 int sdrfm_spectrum_set_stream(sdrfm_spectrum_t* h, void* hip_stream) {
   if (!h) return SDRFM_EINVAL;
@@ -693,16 +679,20 @@ static int senqueue(sdrfm_spectrum* h, const uint8_t* d_iq, size_t iq_stride, ui
     return SDRFM_OK;
   }
   const uint64_t span = (uint64_t)(ns - 1) * iq_stride + 2ull * F * N;
-  if (span >= (1ull << 32)) return SDRFM_ECAPACITY;           // one buffer descriptor spans the batch
+  if (span >= (1ull << 32) - 8) return SDRFM_ECAPACITY;       // one buffer descriptor spans the batch (rounded out to whole dwords)
   (void)nbytes;
   SParams p;
   p.iq = d_iq; p.iq_stride = iq_stride; p.iq_span = (uint32_t)span; p.power = d_power; p.power_stride = power_stride;
   p.tw = h->d_tw; p.win = h->d_win; p.F = F; p.inv_frames = 1.0f / (float)F;
-#ifdef SPEC_STAMPS
-  if (!h->d_dbg) (void)hipMalloc(&h->d_dbg, (size_t)ns * 16 * 8 * sizeof(unsigned int));
-  p.dbg = h->d_dbg;
+  // the raw-dword kernel needs every sample pair inside one aligned dword: iq and iq_stride even
+  const bool use_chain = h->chain && !(((uintptr_t)d_iq | (uintptr_t)iq_stride) & 1u);
+#ifdef SDRFM_DEV
+  if (h->stamps && use_chain && !h->d_dbg && hipMalloc(&h->d_dbg, (size_t)ns * 16 * 8 * sizeof(unsigned int)) != hipSuccess) h->d_dbg = nullptr;
+  p.dbg = use_chain ? h->d_dbg : nullptr;
 #endif
-  hipLaunchKernelGGL(h->kernel, dim3(ns), dim3(64 * (h->chain_nwf ? h->chain_nwf : spec_nwf((int)h->logn))), h->lds_bytes, h->stream, p);
+  h->last = use_chain ? 1 : 0;
+  if (use_chain) hipLaunchKernelGGL(h->chain, dim3(ns), dim3(64 * h->chain_nwf), h->chain_lds_bytes, h->stream, p);
+  else hipLaunchKernelGGL(h->kernel, dim3(ns), dim3(64 * spec_nwf((int)h->logn)), h->lds_bytes, h->stream, p);
   STRY(hipGetLastError(), SDRFM_FAIL);
   return SDRFM_OK;
 }

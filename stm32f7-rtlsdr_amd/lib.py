@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "sdrfm_wbfm_set_stream", "sdrfm_wbfm_synchronize", "sdrfm_wbfm_kernel_name", "sdrfm_rtl_pack_fir", "sdrfm_rtl_resampler", "sdrfm_e4k_pll_params",
     "sdrfm_shard_range",
     "sdrfm_spectrum_create", "sdrfm_spectrum_destroy", "sdrfm_spectrum_process_batch", "sdrfm_spectrum_set_stream",
-    "sdrfm_spectrum_synchronize",
+    "sdrfm_spectrum_synchronize", "sdrfm_spectrum_kernel_name",
     "sdrfm_pcm_deemph_s16", "sdrfm_pcm_alpha",
     "sdrfm_pcm_sink_create", "sdrfm_pcm_sink_destroy", "sdrfm_pcm_sink_reset", "sdrfm_pcm_sink_process_batch",
     "sdrfm_pcm_sink_set_stream", "sdrfm_pcm_sink_synchronize", "sdrfm_pcm_sink_get_state",
@@ -161,6 +161,8 @@ def load_library(dev=False):
     lib.sdrfm_spectrum_set_stream.restype = C.c_int
     lib.sdrfm_spectrum_synchronize.argtypes = [vp]
     lib.sdrfm_spectrum_synchronize.restype = C.c_int
+    lib.sdrfm_spectrum_kernel_name.argtypes = [vp]
+    lib.sdrfm_spectrum_kernel_name.restype = C.c_char_p
     lib.sdrfm_rtl_pack_fir.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_uint8)]
     lib.sdrfm_rtl_pack_fir.restype = C.c_int
     lib.sdrfm_rtl_resampler.argtypes = [u32, u32, u32p, u32p, C.POINTER(C.c_double)]

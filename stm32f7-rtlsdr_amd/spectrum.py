@@ -16,11 +16,12 @@ class SpectrumConfig:
     n_streams: int = 1
     max_bytes_per_call: int = 1 << 20
     device: int = 0
+    dev_library: bool = False         # tools only: csrc/libsdrfm_dev.so (phase stamps, SDRFM_SPEC_VARIANT)
 
 
 class SpectrumView:
     def __init__(self, cfg: SpectrumConfig):
-        self._lib = _l.load_library()
+        self._lib = _l.load_library(dev=cfg.dev_library)
         self.cfg = cfg
         c = _l.SpectrumConfig()
         c.struct_size = C.sizeof(_l.SpectrumConfig)
@@ -56,6 +57,11 @@ class SpectrumView:
 
     def synchronize(self):
         self._ck(self._lib.sdrfm_spectrum_synchronize(self._h), "sdrfm_spectrum_synchronize")
+
+    @property
+    def kernel_name(self):
+        """the kernel the last call launched (sdrfm_spectrum_kernel_name)"""
+        return self._lib.sdrfm_spectrum_kernel_name(self._h).decode()
 
     def process_batch(self, iq: np.ndarray):
         """host memory: iq [n_streams, nbytes] uint8 -> (power [n_streams, nfft] float32, frames averaged)"""

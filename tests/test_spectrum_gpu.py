@@ -69,3 +69,71 @@ def test_edges_and_errors(pkg):
         with pytest.raises(pkg.SdrfmError) as e:
             pkg.SpectrumView(pkg.SpectrumConfig(nfft=bad))
         assert e.value.status == 16
+
+
+@pytest.mark.parametrize("nfft", [512, 1024])
+def test_frame_counts_around_the_runs_of_the_chained_kernel(pkg, oracle_mod, nfft):
+    """N = 512 / 1024 run k_spectrum_chain: 12 waves per stream take runs of two 1024-point blocks and hand the running sum on.  Frame counts
+    below, at and above one block, one run and one cycle of the twelve waves (24 blocks), odd counts (512 points: a last block with one
+    frame), three streams with different data: bit for bit against the oracle."""
+    fpb = 1024 // nfft                                           # frames per block
+    counts = sorted(set([1, 2, 3, 4, 5, 2 * fpb + 1, 23 * fpb, 24 * fpb - 1, 24 * fpb, 24 * fpb + 1, 25 * fpb, 47 * fpb + 1, 48 * fpb, 49 * fpb, 100]))
+    ns = 3
+    sv = pkg.SpectrumView(pkg.SpectrumConfig(nfft=nfft, n_streams=ns, max_bytes_per_call=2 * nfft * 101))
+    for F in counts:
+        iq = pkg.make_iq(ns, F * nfft + 7, mode="fm" if F % 2 else "random", first_id=300 + F)
+        got, frames = sv.process_batch(iq)
+        assert frames == F
+        for s in range(ns):
+            want, _ = oracle_mod.SpectrumOracle(nfft).process(iq[s])
+            assert np.array_equal(got[s].view(np.uint32), want.view(np.uint32)), (nfft, F, s)
+    sv.close()
+
+
+@pytest.mark.parametrize("nfft", [256, 512, 1024])
+@pytest.mark.parametrize("offset,stride_extra", [(1, 0), (0, 1), (1, 3), (2, 2), (0, 0), (2, 0), (0, 2)])
+def test_device_buffers_at_odd_addresses_and_strides(pkg, oracle_mod, nfft, offset, stride_extra):
+    """The raw-dword kernel wants iq and iq_stride even; anything else is served by the typed-load kernel.  Same results either way."""
+    import torch
+    ns, F = 4, 27
+    nbytes = 2 * nfft * F
+    iq = pkg.make_iq(ns, nfft * F, mode="fm", first_id=900 + nfft)
+    stride = nbytes + 6 + stride_extra
+    buf = torch.zeros(offset + ns * stride, dtype=torch.uint8, device="cuda")
+    view = buf[offset:offset + ns * stride].view(ns, stride)[:, :nbytes]
+    view.copy_(torch.from_numpy(iq))
+    assert view.data_ptr() % 2 == offset % 2 and view.stride(0) == stride
+    power = torch.zeros((ns, nfft), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    sv = pkg.SpectrumView(pkg.SpectrumConfig(nfft=nfft, n_streams=ns, max_bytes_per_call=nbytes))
+    assert sv.process_batch_device(view, power) == F
+    sv.synchronize()
+    for s in range(ns):
+        want, _ = oracle_mod.SpectrumOracle(nfft).process(iq[s])
+        assert np.array_equal(power[s].cpu().numpy().view(np.uint32), want.view(np.uint32)), (nfft, offset, stride_extra, s)
+    sv.close()
+
+
+def test_bench_shape_streams_agree_with_the_oracle_and_with_each_other(pkg, oracle_mod):
+    """256 streams x 234 frames x 1024 points (bench.py's spectrum workload): streams 0, 100, 255 against the oracle, and the launch repeated on
+    the same buffers gives the same bits (no dependence on wave timing in the hand-over chain)."""
+    import torch
+    ns, nfft, F = 256, 1024, 234
+    rows = pkg.make_iq(8, nfft * F, mode="fm", first_id=700)
+    iq = np.tile(rows, (ns // 8, 1))
+    d_iq = torch.from_numpy(iq).cuda()
+    power = [torch.zeros((ns, nfft), dtype=torch.float32, device="cuda") for _ in range(3)]
+    torch.cuda.synchronize()
+    sv = pkg.SpectrumView(pkg.SpectrumConfig(nfft=nfft, n_streams=ns, max_bytes_per_call=2 * nfft * F))
+    for pw in power:
+        assert sv.process_batch_device(d_iq, pw) == F
+    sv.synchronize()
+    got = power[0].cpu().numpy()
+    for s in (0, 100, 255):
+        want, _ = oracle_mod.SpectrumOracle(nfft).process(iq[s])
+        assert np.array_equal(got[s].view(np.uint32), want.view(np.uint32)), s
+    for rep in range(1, ns // 8):
+        assert np.array_equal(got[8 * rep:8 * rep + 8].view(np.uint32), got[:8].view(np.uint32)), rep
+    for pw in power[1:]:
+        assert torch.equal(pw, power[0])
+    sv.close()
