@@ -604,7 +604,7 @@ def main_spectrum(args, pkg, world, rank, local_rank, use_dist, rccl_world):
                "config": {"workload": "spectrum view (SURVEY 8f-3) of BASELINE configs[2] buffers: %d x 2.4 MS/s uint8 IQ streams per GPU x %.1f s, "
                                       "%d-point Hann FFT, %d frames averaged per stream; %d input batches rotated (cold HBM reads)" % (ns, args.seconds, nfft, frames, nb),
                           "streams_per_gpu": ns, "bytes_per_stream": 2 * nsamp, "kernel": kname, "input_batches_rotated": nb},
-               "roofline": bound_block("lds", kname, ms, alg, (latest_traffic(kname, alg) or {}).get("hbm_bytes_per_launch"))}
+               "roofline": bound_block("valu" if "chain" in kname else "lds", kname, ms, alg, (latest_traffic(kname, alg) or {}).get("hbm_bytes_per_launch"))}
         print(json.dumps(res), flush=True)
     sv.set_stream(None)
     sv.close()

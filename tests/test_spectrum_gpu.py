@@ -137,3 +137,24 @@ def test_bench_shape_streams_agree_with_the_oracle_and_with_each_other(pkg, orac
     for pw in power[1:]:
         assert torch.equal(pw, power[0])
     sv.close()
+
+
+def test_kernel_names(pkg):
+    """sdrfm_spectrum_kernel_name: 512 / 1024 points run the chained kernel (the typed-load kernel when iq or iq_stride is odd: the test
+    above), the other lengths k_spectrum<log2 N>."""
+    import torch
+    nfft = 1024
+    sv = pkg.SpectrumView(pkg.SpectrumConfig(nfft=nfft, n_streams=2, max_bytes_per_call=2 * nfft * 5))
+    assert sv.kernel_name.startswith("k_spectrum_chain<10")
+    buf = torch.zeros(2 * (2 * nfft * 5 + 1), dtype=torch.uint8, device="cuda")
+    power = torch.zeros((2, nfft), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    assert sv.process_batch_device(buf.view(2, -1)[:, :2 * nfft * 5], power) == 5     # odd stride
+    assert sv.kernel_name == "k_spectrum<10>"
+    assert sv.process_batch_device(buf[:2 * 2 * nfft * 5].view(2, -1), power) == 5
+    assert sv.kernel_name.startswith("k_spectrum_chain<10")
+    sv.synchronize()
+    sv.close()
+    sv = pkg.SpectrumView(pkg.SpectrumConfig(nfft=256))
+    assert sv.kernel_name == "k_spectrum<8>"
+    sv.close()
