@@ -91,9 +91,11 @@ __host__ __device__ constexpr int spad(int i) { return i + (i >> 4) + (i >> 8); 
 // PWO != nullptr (last pass only, kernels with a separate power region): the pass stores |point|^2 at PWO[point index] instead of
 // writing the points back — the power phase's LDS round trip (16 writes + 16 reads of 8 bytes per lane and frame) disappears.
 // PO != nullptr (last pass only): the powers stay in registers.  TR != nullptr: the pass's twiddles come from registers (filled once per
-// kernel in the order TR[(G - 1) group + 2^t - 1 + j]) instead of the LDS table.
+// kernel in the order TR[(G - 1) group + 2^t - 1 + j]) instead of the LDS table.  TC != nullptr (one group per lane, H < 64): they come from a
+// table of this pass alone, TC[(2^t - 1 + j) H] for the lane's pos (TC points at its column): consecutive lanes read consecutive entries
+// whatever N is (the N/2-entry table is read at strides of N / 2^(S+t); measured for N = 512: 117.5 -> 107 us with the compact table).
 template <int LOGB, int LOGN, int S, int K>
-__device__ __forceinline__ void fft_pass(float2* X, const float2* TW, const float2 (&W1)[8], float* PWO, int lane SPEC_STAMP_ARG, float* PO = nullptr, const float2* TR = nullptr) {
+__device__ __forceinline__ void fft_pass(float2* X, const float2* TW, const float2 (&W1)[8], float* PWO, int lane SPEC_STAMP_ARG, float* PO = nullptr, const float2* TR = nullptr, const float2* TC = nullptr) {
   constexpr int H = 1 << (S - 1), G = 1 << K, NG = (1 << LOGB) >> K;
   // (4096 points: 16 points x 4 groups unrolled would not fit in VGPRs; PO / TR, LOGB = 10 only: the group loop must unroll completely)
   constexpr int UNR = LOGB >= 12 ? 1 : (LOGB == 10 ? 8 : 4);
@@ -126,6 +128,7 @@ __device__ __forceinline__ void fft_pass(float2* X, const float2* TW, const floa
           const int jc = posc + (c & ((1 << t) - 1)) * H;      // pos_t = pos0 + jc: position of the pair within its stage-(S+t) block
           if constexpr (S == 1 && K == 4) butterfly(v[c], v[c + (1 << t)], W1[(c & ((1 << t) - 1)) << (3 - t)]);   // first pass: the 8 twiddles W16^k, wave-uniform registers
           else if (TR) butterfly(v[c], v[c + (1 << t)], TR[(g0 >> 6) * (G - 1) + (1 << t) - 1 + (c & ((1 << t) - 1))]);   // twiddles kept in registers
+          else if (TC) butterfly(v[c], v[c + (1 << t)], TC[((1 << t) - 1 + (c & ((1 << t) - 1))) * H]);   // compact table of this pass: TC[(2^t - 1 + j) H + pos]
           else butterfly(v[c], v[c + (1 << t)], TW[tb + spad(jc << (LOGN - S - t))]);
         }
       }
@@ -362,6 +365,13 @@ __global__ void __launch_bounds__(64 * NWF) k_spectrum_chain(SParams p) {
   };
   // the 16 window values of a lane's samples: the same in every wave (and block), kept in LDS as WL[j 64 + lane] (4 x ds_read_b128 per block)
   float4* const WL = reinterpret_cast<float4*>(TAG + 128);
+  float2* const T2 = reinterpret_cast<float2*>(WL + 4 * 64);   // (512 points) the second pass's twiddles: T2[(2^t - 1 + j) 16 + pos] = tw[(pos + 16 j) N / 2^(5+t)]
+  if constexpr (LOGN == 9) {                                   // (1024 points: no gain, and the extra address register spills)
+    for (int i = tid; i < 15 * 16; i += NT) {
+      const int e = i >> 4, pos = i & 15, t = 31 - __builtin_clz((unsigned)(e + 1)), j = e + 1 - (1 << t);
+      T2[i] = p.tw[(pos + 16 * j) << (LOGN - 5 - t)];
+    }
+  }
   if (wv == 0) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -421,7 +431,7 @@ __global__ void __launch_bounds__(64 * NWF) k_spectrum_chain(SParams p) {
         SPEC_STAMP(4);
         fft_first_pass_from_regs(v1, X, W1, grp);
         SPEC_STAMP(1);
-        fft_pass<LOGB, LOGN, 5, 4>(X, TW, W1, nullptr, lane SPEC_STAMP_PASS);
+        fft_pass<LOGB, LOGN, 5, 4>(X, TW, W1, nullptr, lane SPEC_STAMP_PASS, nullptr, nullptr, LOGN == 9 ? T2 + (lane & 15) : nullptr);
         fft_pass<LOGB, LOGN, 9, K3>(X, TW, W1, nullptr, lane SPEC_STAMP_PASS, PO[jr], TR3);
       }
     }
@@ -623,7 +633,7 @@ int sdrfm_spectrum_create(const sdrfm_spectrum_config* cfg, sdrfm_spectrum_t** o
     if (h->chain && var_ && variant) rr_ = rr;
 #endif
     snprintf(h->name[1], sizeof(h->name[1]), "k_spectrum_chain<%u, %d, %d>", logn, h->chain_nwf, rr_);
-    h->chain_lds_bytes = (npt + (size_t)h->chain_nwf * npx) * sizeof(float2) + 2 * 4096 + 512 + 4096;   // twiddles, blocks, two sum slots, their tags, the lanes' window values
+    h->chain_lds_bytes = (npt + (size_t)h->chain_nwf * npx) * sizeof(float2) + 2 * 4096 + 512 + 4096 + 1920;   // twiddles, blocks, two sum slots, their tags, the lanes' window values, the second pass's twiddles
   }
 #define CR(expr) do { if ((expr) != hipSuccess) { sfree(h); return SDRFM_ENOMEM; } } while (0)
   CR(hipSetDevice(h->device));
