@@ -73,6 +73,10 @@ __device__ __forceinline__ void butterfly(float2& a, float2& b, float2 w) {   //
   b = make_float2(A.x - tr, A.y - ti);
 }
 
+// byte address within the workgroup's LDS of a pointer into it (what a ds_* instruction written in inline asm takes)
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
 __device__ __forceinline__ void wave_sync() {                  // LDS written by this wave is visible to all of its lanes
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
@@ -442,8 +446,8 @@ __global__ void __launch_bounds__(64 * NWF) k_spectrum_chain(SParams p) {
     __builtin_amdgcn_s_setprio(3);                             // the hand-over is the one serial chain through the workgroup
     if (r > 0u) {
       const uint32_t sl = (r - 1u) & 1u;
-      const uint32_t a_tag = (uint32_t)(uintptr_t)(TAG + sl * 64 + lane), a_dat = (uint32_t)(uintptr_t)(SL + sl * (SV / 4) * 64 + lane);
-      const uint32_t a_tagp = (uint32_t)(uintptr_t)(TAG + (sl ^ 1u) * 64 + lane);
+      const uint32_t a_tag = lds_addr(TAG + sl * 64 + lane), a_dat = lds_addr(SL + sl * (SV / 4) * 64 + lane);
+      const uint32_t a_tagp = lds_addr(TAG + (sl ^ 1u) * 64 + lane);
       uint32_t tag;
       sf4_t t[SV / 4];
       auto batch = [&]() {
@@ -491,7 +495,7 @@ __global__ void __launch_bounds__(64 * NWF) k_spectrum_chain(SParams p) {
     }
     if (r + 1u < NR) {
       const uint32_t sl = r & 1u;
-      const uint32_t a_tag = (uint32_t)(uintptr_t)(TAG + sl * 64 + lane), a_dat = (uint32_t)(uintptr_t)(SL + sl * (SV / 4) * 64 + lane);
+      const uint32_t a_tag = lds_addr(TAG + sl * 64 + lane), a_dat = lds_addr(SL + sl * (SV / 4) * 64 + lane);
       sf4_t t[SV / 4];
 #pragma unroll
       for (int j = 0; j < SV / 4; ++j) { t[j].x = S[4 * j]; t[j].y = S[4 * j + 1]; t[j].z = S[4 * j + 2]; t[j].w = S[4 * j + 3]; }
