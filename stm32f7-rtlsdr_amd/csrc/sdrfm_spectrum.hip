@@ -354,7 +354,9 @@ __global__ void __launch_bounds__(64 * NWF) k_spectrum_chain(SParams p) {
   float2* TW = reinterpret_cast<float2*>(spec_smem);
   const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
   float2* X = reinterpret_cast<float2*>(spec_smem) + NPT + wv * NPX;
-  float4* const SL = reinterpret_cast<float4*>(reinterpret_cast<float2*>(spec_smem) + NPT + NWF * NPX);   // slot s: SL[(s SV/4 + j) 64 + lane]
+  // (16-byte aligned — NPT is odd for 512 points: a ds_read_b128 / ds_write_b128 at an address that is only 8-byte aligned is legal and costs
+  //  several times its cycles: 107 -> 82 us for the 512-point launch when the slots, the window values and the tags moved up by 8 bytes)
+  float4* const SL = reinterpret_cast<float4*>(reinterpret_cast<float2*>(spec_smem) + ((NPT + NWF * NPX + 1) & ~1));   // slot s: SL[(s SV/4 + j) 64 + lane]
   uint32_t* const TAG = reinterpret_cast<uint32_t*>(SL + 2 * (SV / 4) * 64);   // TAG[64 s + lane] = 1 + the block whose sum slot s holds (one word per lane)
   const uint32_t stream = blockIdx.x;
   for (int i = tid; i < N / 2; i += NT) TW[spad(i)] = p.tw[i];
@@ -637,7 +639,7 @@ int sdrfm_spectrum_create(const sdrfm_spectrum_config* cfg, sdrfm_spectrum_t** o
     if (h->chain && var_ && variant) rr_ = rr;
 #endif
     snprintf(h->name[1], sizeof(h->name[1]), "k_spectrum_chain<%u, %d, %d>", logn, h->chain_nwf, rr_);
-    h->chain_lds_bytes = (npt + (size_t)h->chain_nwf * npx) * sizeof(float2) + 2 * 4096 + 512 + 4096 + 1920;   // twiddles, blocks, two sum slots, their tags, the lanes' window values, the second pass's twiddles
+    h->chain_lds_bytes = (((npt + (size_t)h->chain_nwf * npx + 1) & ~(size_t)1)) * sizeof(float2) + 2 * 4096 + 512 + 4096 + 1920;   // twiddles, blocks, two sum slots, their tags, the lanes' window values, the second pass's twiddles
   }
 #define CR(expr) do { if ((expr) != hipSuccess) { sfree(h); return SDRFM_ENOMEM; } } while (0)
   CR(hipSetDevice(h->device));
