@@ -40,7 +40,12 @@ def test_newest_round_traffic_feeds_the_headline_kernel():
     assert 1.0 <= t["hbm_bytes_per_launch"] / head["algorithmic_bytes_per_launch"] < 1.06       # warm-up re-reads: ~2 % of the bytes
     # the pipe figures of the kernels that are not bound by the HBM come from the same round's passes
     d = b.latest_pmc_derived("wbfm-fused (k_wbfm_steps<8,10>)")
-    assert d is not None and d["file"].startswith("r04_") and 0.5 < d["valu_issue_busy_fraction"] < 0.9
+    assert d is not None and d["file"].startswith(("r04_", "r04b_")) and 0.5 < d["valu_issue_busy_fraction"] < 0.9
+    # (round 4, second pass: the spectrum view's 1024-point kernel was rebuilt; its line names the new kernel and finds that kernel's passes)
+    d = b.latest_pmc_derived("k_spectrum_chain<10, 12, 2>")
+    assert d is not None and d["file"] == "r04b_spectrum_pmc.json" and 0.5 < d["valu_issue_busy_fraction"] < 0.9
+    t = b.latest_traffic("k_spectrum_chain<10, 12, 2>", 256 * 234 * 1024 * 2.0 + 256 * 1024 * 4.0)
+    assert t is not None and 1.0 <= t["hbm_bytes_per_launch"] / t["algorithmic_bytes_per_launch"] < 1.1
 
 
 def test_traffic_never_below_algorithmic_bytes():
