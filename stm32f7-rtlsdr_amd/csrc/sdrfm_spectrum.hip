@@ -12,6 +12,8 @@
 // couple, so each pass reads and writes a point once).  After a round the frames' powers are added to the running sums
 // (registers, N/threads bins per thread) in frame order — the spec's sum over frames is sequential — which costs two
 // workgroup barriers per round instead of ~7 per frame.
+// 512 and 1024 points have a second kernel, k_spectrum_chain (below): no barrier in the frame loop at all — the running sum is handed from
+// wave to wave —, raw dword loads, the first pass fed from registers; k_spectrum serves them only when iq or iq_stride is odd.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
