@@ -60,7 +60,7 @@ def parse():
                     help="fm = BASELINE configs[2]/[3] (default, the headline); wbfm = configs[4] channelizer path, 128 streams/GPU; "
                          "spectrum = FFT view (SURVEY 8f-3) of the configs[2] buffers")
     ap.add_argument("--nfft", type=int, default=1024, help="spectrum workload: FFT length")
-    ap.add_argument("--dev-library", action="store_true", help="fm workload: load csrc/libsdrfm_dev.so (honours the SDRFM_* development "
+    ap.add_argument("--dev-library", action="store_true", help="fm / spectrum workloads: load csrc/libsdrfm_dev.so (honours the SDRFM_* development "
                     "knobs, e.g. SDRFM_NO_STREAM=1 for design B); the reported line then says so and is not a product figure")
     ap.add_argument("--bit-exact", action="store_true", help="fm workload: SDRFM_CFG_BIT_EXACT handle — the fmaf-chain kernels only (design S "
                     "instead of the matrix-pipe design Q); a comparison figure, labelled as such")
@@ -577,7 +577,7 @@ def main_spectrum(args, pkg, world, rank, local_rank, use_dist, rccl_world):
     import torch.distributed as dist
     fs, ns, nfft = 2.4e6, (args.streams_per_gpu if args.streams_per_gpu > 0 else 256), args.nfft
     nsamp = int(round(args.seconds * fs))
-    sv = pkg.SpectrumView(pkg.SpectrumConfig(nfft=nfft, n_streams=ns, device=local_rank, max_bytes_per_call=2 * nsamp))
+    sv = pkg.SpectrumView(pkg.SpectrumConfig(nfft=nfft, n_streams=ns, device=local_rank, max_bytes_per_call=2 * nsamp, dev_library=args.dev_library))
     stream = torch.cuda.Stream()
     sv.set_stream(stream.cuda_stream)
     nb = pick_batches(args, ns * 2 * nsamp)

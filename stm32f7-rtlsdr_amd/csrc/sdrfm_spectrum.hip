@@ -349,8 +349,13 @@ __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
 // The window values of a lane's 16 samples and the last pass's twiddles are the same for every block: LDS (4 x ds_read_b128) / registers.
 template <int LOGN, int NWF, int R>
 __global__ void __launch_bounds__(64 * NWF) k_spectrum_chain(SParams p) {
-  static_assert(LOGN == 9 || LOGN == 10, "the register-fed kernels");
-  constexpr int N = 1 << LOGN, NT = 64 * NWF, LOGB = 10, B = 1 << LOGB, FPW = B / N, SV = 16 / FPW;   // SV: bins per lane
+  static_assert(LOGN >= 6 && LOGN <= 10, "blocks of 1024 points");
+  // SMALL (64 .. 256 points, 4 .. 16 frames per block): the last pass leaves a frame's bins spread over a quarter of the lanes, so the block's
+  // powers go through the wave's own (by then free) LDS block once — rows [frame][bin] — and come back as the N/64 consecutive bins a lane sums
+  constexpr bool SMALL = LOGN <= 8;
+  constexpr int N = 1 << LOGN, NT = 64 * NWF, LOGB = 10, B = 1 << LOGB, FPW = B / N, SV = SMALL ? 4 : 16 / FPW;   // SV: floats per lane of a hand-over slot
+  constexpr int NBL = SMALL ? N / 64 : SV;                     // bins a lane sums
+  static_assert(!SMALL || R * B * 4 <= (spad(B - 1) + 1) * 8, "(SMALL) the run's power rows must fit the wave's own block");
   extern __shared__ __attribute__((aligned(16))) unsigned char spec_smem[];
   constexpr int NPT = spad(N / 2 - 1) + 1, NPX = spad(B - 1) + 1;
   float2* TW = reinterpret_cast<float2*>(spec_smem);
@@ -407,17 +412,19 @@ __global__ void __launch_bounds__(64 * NWF) k_spectrum_chain(SParams p) {
   for (int i = 0; i < 8; ++i) stv.acc[i] = 0;
   stv.last = (unsigned int)__builtin_amdgcn_s_memtime();
 #endif
-  constexpr int K3 = LOGN - 8, G3 = 1 << K3, NI3 = (B >> K3) / 64;   // the last pass: stages 9 .. LOGN, NI3 groups per lane
+  constexpr int K3 = SMALL ? 1 : LOGN - 8, G3 = 1 << K3, NI3 = (B >> K3) / 64;   // (512 / 1024 points) the last pass: stages 9 .. LOGN, NI3 groups per lane
   float2 TR3[NI3 * (G3 - 1)];                                  // its twiddles: the same for every block, kept in registers
+  if constexpr (!SMALL) {
 #pragma unroll
-  for (int i = 0; i < NI3; ++i)
+    for (int i = 0; i < NI3; ++i)
 #pragma unroll
-    for (int t = 0; t < K3; ++t)
+      for (int t = 0; t < K3; ++t)
 #pragma unroll
-      for (int j = 0; j < (1 << t); ++j) {
-        const int posc = (64 * i) & 255, jc = posc + j * 256, sh = LOGN - 9 - t;
-        TR3[i * (G3 - 1) + (1 << t) - 1 + j] = TW[spad(lane << sh) + spad(jc << sh)];
-      }
+        for (int j = 0; j < (1 << t); ++j) {
+          const int posc = (64 * i) & 255, jc = posc + j * 256, sh = LOGN - 9 - t;
+          TR3[i * (G3 - 1) + (1 << t) - 1 + j] = TW[spad(lane << sh) + spad(jc << sh)];
+        }
+  }
   for (uint32_t r = (uint32_t)wv; r < NR; r += (uint32_t)NWF) {
     float PO[R][16];
 #pragma unroll
@@ -439,14 +446,38 @@ __global__ void __launch_bounds__(64 * NWF) k_spectrum_chain(SParams p) {
         SPEC_STAMP(4);
         fft_first_pass_from_regs(v1, X, W1, grp);
         SPEC_STAMP(1);
-        fft_pass<LOGB, LOGN, 5, 4>(X, TW, W1, nullptr, lane SPEC_STAMP_PASS, nullptr, nullptr, LOGN == 9 ? T2 + (lane & 15) : nullptr);
-        fft_pass<LOGB, LOGN, 9, K3>(X, TW, W1, nullptr, lane SPEC_STAMP_PASS, PO[jr], TR3);
+        if constexpr (SMALL) {
+          fft_pass<LOGB, LOGN, 5, LOGN - 4>(X, TW, W1, nullptr, lane SPEC_STAMP_PASS, PO[jr]);   // stages 5 .. LOGN: the last pass
+        } else {
+          fft_pass<LOGB, LOGN, 5, 4>(X, TW, W1, nullptr, lane SPEC_STAMP_PASS, nullptr, nullptr, LOGN == 9 ? T2 + (lane & 15) : nullptr);
+          fft_pass<LOGB, LOGN, 9, K3>(X, TW, W1, nullptr, lane SPEC_STAMP_PASS, PO[jr], TR3);
+        }
       }
     }
     // the running sum after run r - 1: ONE batch of LDS reads, the slot's tag first — DS operations of a wave execute in order and the
     // writer stores the tag last, so a batch that sees the tag sees the sum (a batch that does not is repeated).  While the predecessor
     // itself is still waiting (tag < r - 1) only the tag is watched, one cheap read per 64 cycles.
     float S[SV];
+    float PV[SMALL ? R * FPW : 1][NBL];                        // (SMALL) the run's powers of this lane's bins, frame by frame
+    if constexpr (SMALL) {
+      // PO[jr][G i + c] = frame (lane >> 4) + 4 i of block jr, bin (lane & 15) + 16 c  ->  row-major rows in the wave's block (free now)  ->  PV
+      constexpr int K = LOGN - 4, G = 1 << K, NI = (B >> K) / 64;
+      float* const PR = reinterpret_cast<float*>(X);
+#pragma unroll
+      for (int jr = 0; jr < R; ++jr)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int c = 0; c < G; ++c) PR[jr * B + (((lane >> 4) + 4 * i) << LOGN) + (lane & 15) + 16 * c] = PO[jr][G * i + c];
+      wave_sync();
+#pragma unroll
+      for (int jr = 0; jr < R; ++jr)
+#pragma unroll
+        for (int f = 0; f < FPW; ++f)
+#pragma unroll
+          for (int j = 0; j < NBL; ++j) PV[jr * FPW + f][j] = PR[jr * B + (f << LOGN) + NBL * lane + j];
+      wave_sync();                                             // (the next run's first pass writes the block)
+    }
     __builtin_amdgcn_s_setprio(3);                             // the hand-over is the one serial chain through the workgroup
     if (r > 0u) {
       const uint32_t sl = (r - 1u) & 1u;
@@ -455,7 +486,9 @@ __global__ void __launch_bounds__(64 * NWF) k_spectrum_chain(SParams p) {
       uint32_t tag;
       sf4_t t[SV / 4];
       auto batch = [&]() {
-        if constexpr (SV == 16)
+        if constexpr (SV == 4)
+          asm volatile("ds_read_b32 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(tag), "=&v"(t[0]) : "v"(a_tag), "v"(a_dat) : "memory");
+        else if constexpr (SV == 16)
           asm volatile("ds_read_b32 %0, %5\n\tds_read_b128 %1, %6\n\tds_read_b128 %2, %6 offset:1024\n\tds_read_b128 %3, %6 offset:2048\n\t"
                        "ds_read_b128 %4, %6 offset:3072\n\ts_waitcnt lgkmcnt(0)"
                        : "=&v"(tag), "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[SV / 4 - 2]), "=&v"(t[SV / 4 - 1]) : "v"(a_tag), "v"(a_dat) : "memory");
@@ -465,15 +498,23 @@ __global__ void __launch_bounds__(64 * NWF) k_spectrum_chain(SParams p) {
       };
       batch();
       if ((uint32_t)__builtin_amdgcn_readfirstlane((int)tag) != r) {
+        // (a wave never waits longer than one turn of the chain, ~100 us whatever F is: 2^20 polls — tens of milliseconds — mean the hand-over
+        //  is broken, and the kernel traps rather than hang the device)
+        uint32_t polls = 0;
         if (r > 1u) {                                          // far from the head of the chain: wait until the predecessor has its input
           uint32_t tp;
           for (;;) {
             asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(tp) : "v"(a_tagp) : "memory");
             if ((uint32_t)__builtin_amdgcn_readfirstlane((int)tp) >= r - 1u) break;
+            if (++polls > (1u << 20)) __builtin_trap();
             __builtin_amdgcn_s_sleep(2);
           }
         }
-        do batch(); while ((uint32_t)__builtin_amdgcn_readfirstlane((int)tag) != r);   // next in line: whole batches, one round trip after the tag lands
+        polls = 0;
+        do {                                                   // next in line: whole batches, one round trip after the tag lands
+          batch();
+          if (++polls > (1u << 20)) __builtin_trap();
+        } while ((uint32_t)__builtin_amdgcn_readfirstlane((int)tag) != r);
       }
 #pragma unroll
       for (int j = 0; j < SV / 4; ++j) { S[4 * j] = t[j].x; S[4 * j + 1] = t[j].y; S[4 * j + 2] = t[j].z; S[4 * j + 3] = t[j].w; }
@@ -483,6 +524,17 @@ __global__ void __launch_bounds__(64 * NWF) k_spectrum_chain(SParams p) {
       for (int j = 0; j < SV; ++j) S[j] = 0.0f;
     }
     // N = 1024: PO[.][4 i + c] = bin lane + 64 i + 256 c.  N = 512: PO[.][2 i + c], i < 4: first frame's bin lane + 64 i + 256 c; i >= 4: second frame's
+    if constexpr (SMALL) {
+#pragma unroll
+      for (int jr = 0; jr < R; ++jr)
+#pragma unroll
+        for (int f = 0; f < FPW; ++f) {
+          if ((r * (uint32_t)R + (uint32_t)jr) * (uint32_t)FPW + (uint32_t)f < p.F) {   // (wave-uniform; frames past F: computed, not summed)
+#pragma unroll
+            for (int j = 0; j < NBL; ++j) S[j] = S[j] + PV[jr * FPW + f][j];
+          }
+        }
+    } else
 #pragma unroll
     for (int jr = 0; jr < R; ++jr) {
       const uint32_t b = r * (uint32_t)R + (uint32_t)jr;
@@ -504,7 +556,9 @@ __global__ void __launch_bounds__(64 * NWF) k_spectrum_chain(SParams p) {
 #pragma unroll
       for (int j = 0; j < SV / 4; ++j) { t[j].x = S[4 * j]; t[j].y = S[4 * j + 1]; t[j].z = S[4 * j + 2]; t[j].w = S[4 * j + 3]; }
       const uint32_t tag = r + 1u;
-      if constexpr (SV == 16)
+      if constexpr (SV == 4)
+        asm volatile("ds_write_b128 %1, %2\n\tds_write_b32 %0, %3" :: "v"(a_tag), "v"(a_dat), "v"(t[0]), "v"(tag) : "memory");
+      else if constexpr (SV == 16)
         asm volatile("ds_write_b128 %1, %2\n\tds_write_b128 %1, %3 offset:1024\n\tds_write_b128 %1, %4 offset:2048\n\tds_write_b128 %1, %5 offset:3072\n\t"
                      "ds_write_b32 %0, %6" :: "v"(a_tag), "v"(a_dat), "v"(t[0]), "v"(t[1]), "v"(t[SV / 4 - 2]), "v"(t[SV / 4 - 1]), "v"(tag) : "memory");
       else
@@ -515,8 +569,8 @@ __global__ void __launch_bounds__(64 * NWF) k_spectrum_chain(SParams p) {
     } else {
       constexpr int GP = FPW == 1 ? 4 : 2;                     // points per group of the last pass
 #pragma unroll
-      for (int j = 0; j < SV; ++j) {
-        const int k = lane + 64 * (j / GP) + 256 * (j % GP);
+      for (int j = 0; j < NBL; ++j) {
+        const int k = SMALL ? NBL * lane + j : lane + 64 * (j / GP) + 256 * (j % GP);
         p.power[(size_t)stream * p.power_stride + (size_t)((k + N / 2) & (N - 1))] = S[j] * p.inv_frames;
       }
     }
@@ -623,16 +677,19 @@ int sdrfm_spectrum_create(const sdrfm_spectrum_config* cfg, sdrfm_spectrum_t** o
   h->lds_bytes = (npt + (size_t)spec_nwf((int)logn) * npx) * sizeof(float2) +
                  (spec_fusep((int)logn) ? 2 * (size_t)spec_nwf((int)logn) * ((size_t)1 << spec_logb((int)logn)) * sizeof(float) : 0);   // two power regions
   snprintf(h->name[0], sizeof(h->name[0]), "k_spectrum<%u>", logn);
-  if (logn == 9 || logn == 10) {                               // 12 waves per workgroup, runs of 2 blocks (see k_spectrum_chain)
+  if (logn <= 10) {                                            // 12 waves per workgroup, runs of 2 blocks (see k_spectrum_chain)
     h->chain_nwf = 12;
-    h->chain = logn == 9 ? k_spectrum_chain<9, 12, 2> : k_spectrum_chain<10, 12, 2>;
+    h->chain = logn == 6 ? k_spectrum_chain<6, 12, 2> : logn == 7 ? k_spectrum_chain<7, 12, 2> : logn == 8 ? k_spectrum_chain<8, 12, 2>
+             : logn == 9 ? k_spectrum_chain<9, 12, 2> : k_spectrum_chain<10, 12, 2>;
 #ifdef SDRFM_DEV
     // development library: SDRFM_SPEC_VARIANT = waves per workgroup x 10 + blocks per run (0: k_spectrum), SDRFM_SPEC_STAMPS=1: phase stamps
     const char* var_ = getenv("SDRFM_SPEC_VARIANT");
     const int variant = var_ ? atoi(var_) : 122, nwf = variant / 10, rr = variant % 10;
     h->stamps = getenv("SDRFM_SPEC_STAMPS") != nullptr;
     if (variant == 0) h->chain = nullptr;
-#define CK(NW, RR) if (nwf == NW && rr == RR) { h->chain = logn == 9 ? k_spectrum_chain<9, NW, RR> : k_spectrum_chain<10, NW, RR>; h->chain_nwf = NW; }
+#define CK(NW, RR) if (nwf == NW && rr == RR && logn >= 9) { h->chain = logn == 9 ? k_spectrum_chain<9, NW, RR> : k_spectrum_chain<10, NW, RR>; h->chain_nwf = NW; }
+    if (logn <= 8 && nwf == 16 && rr == 2) { h->chain = logn == 6 ? k_spectrum_chain<6, 16, 2> : logn == 7 ? k_spectrum_chain<7, 16, 2> : k_spectrum_chain<8, 16, 2>; h->chain_nwf = 16; }
+    if (logn <= 8 && nwf == 16 && rr == 1) { h->chain = logn == 6 ? k_spectrum_chain<6, 16, 1> : logn == 7 ? k_spectrum_chain<7, 16, 1> : k_spectrum_chain<8, 16, 1>; h->chain_nwf = 16; }
     CK(8, 1) CK(8, 2) CK(8, 3) CK(12, 1) CK(12, 3) CK(16, 1)
 #undef CK
 #endif

@@ -71,15 +71,15 @@ def test_edges_and_errors(pkg):
         assert e.value.status == 16
 
 
-@pytest.mark.parametrize("nfft", [512, 1024])
+@pytest.mark.parametrize("nfft", [64, 128, 256, 512, 1024])
 def test_frame_counts_around_the_runs_of_the_chained_kernel(pkg, oracle_mod, nfft):
-    """N = 512 / 1024 run k_spectrum_chain: 12 waves per stream take runs of two 1024-point blocks and hand the running sum on.  Frame counts
-    below, at and above one block, one run and one cycle of the twelve waves (24 blocks), odd counts (512 points: a last block with one
-    frame), three streams with different data: bit for bit against the oracle."""
+    """N <= 1024 run k_spectrum_chain: 12 waves per stream take runs of two 1024-point blocks and hand the running sum on.  Frame counts
+    below, at and above one block, one run and one cycle of the twelve waves (24 blocks), counts that leave a last block partly filled
+    (N < 1024: several frames per block), three streams with different data: bit for bit against the oracle."""
     fpb = 1024 // nfft                                           # frames per block
-    counts = sorted(set([1, 2, 3, 4, 5, 2 * fpb + 1, 23 * fpb, 24 * fpb - 1, 24 * fpb, 24 * fpb + 1, 25 * fpb, 47 * fpb + 1, 48 * fpb, 49 * fpb, 100]))
+    counts = sorted(set([1, 2, 3, 4, 5, fpb - 1, fpb, fpb + 1, 2 * fpb + 1, 23 * fpb, 24 * fpb - 1, 24 * fpb, 24 * fpb + 1, 25 * fpb, 47 * fpb + 1, 48 * fpb, 49 * fpb, 50 * fpb + fpb // 2, 100]) - {0})
     ns = 3
-    sv = pkg.SpectrumView(pkg.SpectrumConfig(nfft=nfft, n_streams=ns, max_bytes_per_call=2 * nfft * 101))
+    sv = pkg.SpectrumView(pkg.SpectrumConfig(nfft=nfft, n_streams=ns, max_bytes_per_call=2 * nfft * (max(counts) + 1)))
     for F in counts:
         iq = pkg.make_iq(ns, F * nfft + 7, mode="fm" if F % 2 else "random", first_id=300 + F)
         got, frames = sv.process_batch(iq)
@@ -140,8 +140,8 @@ def test_bench_shape_streams_agree_with_the_oracle_and_with_each_other(pkg, orac
 
 
 def test_kernel_names(pkg):
-    """sdrfm_spectrum_kernel_name: 512 / 1024 points run the chained kernel (the typed-load kernel when iq or iq_stride is odd: the test
-    above), the other lengths k_spectrum<log2 N>."""
+    """sdrfm_spectrum_kernel_name: up to 1024 points run the chained kernel (the typed-load kernel when iq or iq_stride is odd: the test
+    above), 2048 and 4096 points k_spectrum<log2 N>."""
     import torch
     nfft = 1024
     sv = pkg.SpectrumView(pkg.SpectrumConfig(nfft=nfft, n_streams=2, max_bytes_per_call=2 * nfft * 5))
@@ -156,5 +156,8 @@ def test_kernel_names(pkg):
     sv.synchronize()
     sv.close()
     sv = pkg.SpectrumView(pkg.SpectrumConfig(nfft=256))
-    assert sv.kernel_name == "k_spectrum<8>"
+    assert sv.kernel_name.startswith("k_spectrum_chain<8")
+    sv.close()
+    sv = pkg.SpectrumView(pkg.SpectrumConfig(nfft=2048))
+    assert sv.kernel_name == "k_spectrum<11>"
     sv.close()

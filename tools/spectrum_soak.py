@@ -13,7 +13,7 @@ pkg = importlib.import_module("stm32f7-rtlsdr_amd")
 from oracle import oracle as om
 n_launch = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
 bad = 0
-for ns, nfft, F in ((256, 1024, 234), (256, 512, 468), (256, 1024, 25), (64, 512, 49), (1024, 1024, 7)):
+for ns, nfft, F in ((256, 1024, 234), (256, 512, 468), (256, 1024, 25), (64, 512, 49), (1024, 1024, 7), (256, 256, 937), (256, 64, 3750), (64, 128, 51)):
     rows = pkg.make_iq(8, nfft * F, mode="random" if F == 25 else "fm", first_id=1234 + F)
     iq_h = np.tile(rows, (ns // 8, 1))
     iq = torch.from_numpy(iq_h).cuda()
