@@ -237,8 +237,8 @@ int  sdrfm_spectrum_process_batch(sdrfm_spectrum_t* h, const uint8_t* iq, size_t
 int  sdrfm_spectrum_set_stream(sdrfm_spectrum_t* h, void* hip_stream);
 int  sdrfm_spectrum_synchronize(sdrfm_spectrum_t* h);
 /* The kernel the last call launched, as a profiler prints it (before the first call: the one a device buffer with even iq and iq_stride
- * gets).  512 and 1024 points have a kernel that reads the samples as aligned dwords; a call whose iq or iq_stride is odd is served by the
- * typed-load kernel of the other lengths.  Same results either way. */
+ * gets).  Up to 1024 points a kernel that reads the samples as halves of aligned dwords serves the call; one whose iq or iq_stride is odd is
+ * served by the typed-load kernel of the longer lengths.  Same results either way. */
 const char* sdrfm_spectrum_kernel_name(const sdrfm_spectrum_t* h);
 
 /* ------------------------------------------------------------------------------------------------------------------
