@@ -12,8 +12,8 @@
 // couple, so each pass reads and writes a point once).  After a round the frames' powers are added to the running sums
 // (registers, N/threads bins per thread) in frame order — the spec's sum over frames is sequential — which costs two
 // workgroup barriers per round instead of ~7 per frame.
-// 512 and 1024 points have a second kernel, k_spectrum_chain (below): no barrier in the frame loop at all — the running sum is handed from
-// wave to wave —, raw dword loads, the first pass fed from registers; k_spectrum serves them only when iq or iq_stride is odd.
+// Up to 1024 points a second kernel serves the call, k_spectrum_chain (below): no barrier in the frame loop at all — the running sum is handed
+// from wave to wave —, raw dword loads, the first pass fed from registers; k_spectrum serves those lengths only when iq or iq_stride is odd.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
   }
 }
 
-// The 512- and 1024-point kernel: THE RUNNING SUM TRAVELS, NO WORKGROUP BARRIER IN THE FRAME LOOP.
+// The kernel of 64 .. 1024 points: THE RUNNING SUM TRAVELS, NO WORKGROUP BARRIER IN THE FRAME LOOP.
 // k_spectrum's waves meet at a barrier every round to add their power rows, so they move in lock step — all of them load, all of them
 // transform, all of them wait for LDS at the same time (measured: ~3300 of 7300 cycles per round spent issuing the sample loads, 1350 at the
 // barrier) — and every round ends with a tail in which the SIMDs drain.  Here a wave takes RUNS of R consecutive blocks of 1024 points
@@ -347,6 +347,8 @@ __global__ void __launch_bounds__(64 * spec_nwf(LOGN)) k_spectrum(SParams p) {
 // Samples arrive as raw dwords (lane pairs share one: `buffer_load_dword`, 16 per block and lane at immediate offsets from one address)
 // and are split with v_cvt_f32_ubyte: a typed 2-byte load costs ~3x the issue time.  Needs iq and iq_stride even (else k_spectrum).
 // The window values of a lane's 16 samples and the last pass's twiddles are the same for every block: LDS (4 x ds_read_b128) / registers.
+// 64 .. 256 points (SMALL, 4 .. 16 frames per block): a frame's bins end up spread over a quarter of the lanes, so a run's powers go through the
+// wave's own block once (it is free after the last pass) and come back as the N/64 consecutive bins a lane sums — before the wave waits for the sum.
 template <int LOGN, int NWF, int R>
 __global__ void __launch_bounds__(64 * NWF) k_spectrum_chain(SParams p) {
   static_assert(LOGN >= 6 && LOGN <= 10, "blocks of 1024 points");
