@@ -33,10 +33,10 @@ def test_newest_round_traffic_feeds_the_headline_kernel():
     """The default bench line (design Q, configs[2]) takes `roofline.traffic` from the newest committed counter passes of the same kernel and size
     (round 4: taken at the final kernel commit, with the conditioning guard in)."""
     b = _bench()
-    head = json.load(open(os.path.join(ROOT, "profiles", "traffic_r04.json")))
+    head = json.load(open(os.path.join(ROOT, "profiles", "traffic_r04b.json")))      # (re-taken at the round's last kernel commit)
     assert head["kernel_name"].startswith("fast-q") and "k_mfir" in head["rocprof_kernel"]
     t = b.latest_traffic(head["kernel_name"], head["algorithmic_bytes_per_launch"])
-    assert t is not None and t["file"].startswith(("traffic_r04", "r04_")) and t["hbm_bytes_per_launch"] == head["hbm_bytes_per_launch"]
+    assert t is not None and t["file"].startswith(("traffic_r04b", "r04b_")) and t["hbm_bytes_per_launch"] == head["hbm_bytes_per_launch"]
     assert 1.0 <= t["hbm_bytes_per_launch"] / head["algorithmic_bytes_per_launch"] < 1.06       # warm-up re-reads: ~2 % of the bytes
     # the pipe figures of the kernels that are not bound by the HBM come from the same round's passes
     d = b.latest_pmc_derived("wbfm-fused (k_wbfm_steps<8,10>)")
