@@ -149,6 +149,7 @@ __device__ __forceinline__ void fft_pass(float2* X, const float2* TW, const floa
         for (int c = 0; c < G; ++c) X[sb + spad(c * H)] = v[c];
       }
     }
+    if constexpr (LOGB == 11) __builtin_amdgcn_sched_barrier(0);   // (2048 points: one group's loads and butterflies at a time: 160 -> 143 - 154 us)
   }
   wave_sync();
   SPEC_STAMP(S == 5 ? 3 : 5);
