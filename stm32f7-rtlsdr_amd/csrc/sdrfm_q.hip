@@ -379,6 +379,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16
     __builtin_amdgcn_wave_barrier();
 #if defined(SDRFM_Q_ABLATE) && (SDRFM_Q_ABLATE & 256)   // every wave stores to the same 2 KiB (same instructions, no write traffic to speak of)
     float* out = p.audio;
+    const int ln_ = lane;
 #else
     uint32_t st_ = stream;                                      // (derived here, from opaque copies: a pointer kept across the step loop costs registers there)
     int ln_ = lane;

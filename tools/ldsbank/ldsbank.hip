@@ -2,7 +2,7 @@
 // and an operation), every wave repeats the one instruction ITERS times; under `rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS` the ratio of
 // the two counters per dispatch is the LDS-array cycles that instruction takes (conflict-free ds_read_b64: 2 ...).  Patterns come from a text
 // file written by tools/ldsbank/patterns.py: one line per pattern, `op a0 a1 ... a63` (op 0 = ds_read_b64, 1 = ds_write_b64,
-// 2 = ds_read_b128, 3 = ds_write_b128, 4 = ds_read_b32, 5 = ds_write_b32; addresses in bytes).
+// 2 = ds_read_b128, 3 = ds_write_b128, 4 = ds_read_b32, 5 = ds_write_b32, 6 = ds_read2_b64 offset1:1, 7 = ds_write2_b32 offset1:1; addresses in bytes).
 //   hipcc --offload-arch=gfx950 -O2 -o tools/ldsbank/ldsbank tools/ldsbank/ldsbank.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -29,6 +29,8 @@ __global__ void __launch_bounds__(64) k_pat(const int* __restrict__ addr, int it
       if (OP == 3) asm volatile("ds_write_b128 %0, %1" :: "v"(a), "v"(v4) : "memory");
       if (OP == 4) { float r; asm volatile("ds_read_b32 %0, %1" : "=v"(r) : "v"(a)); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); acc += 0.f * r; }
       if (OP == 5) asm volatile("ds_write_b32 %0, %1" :: "v"(a), "v"(v2.x) : "memory");
+      if (OP == 6) { f4 r; asm volatile("ds_read2_b64 %0, %1 offset1:1" : "=v"(r) : "v"(a)); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); acc += 0.f * r.x; }
+      if (OP == 7) asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" :: "v"(a), "v"(v2.x), "v"(v2.y) : "memory");
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
@@ -50,8 +52,8 @@ int main(int argc, char** argv) {
   int* d_addr; float* d_sink;
   (void)hipMalloc(&d_addr, addrs.size() * sizeof(int)); (void)hipMalloc(&d_sink, 256);
   (void)hipMemcpy(d_addr, addrs.data(), addrs.size() * sizeof(int), hipMemcpyHostToDevice);
-  void (*ks[6])(const int*, int, float*) = {k_pat<0>, k_pat<1>, k_pat<2>, k_pat<3>, k_pat<4>, k_pat<5>};
-  for (int k = 0; k < 6; ++k) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ks[k]), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  void (*ks[8])(const int*, int, float*) = {k_pat<0>, k_pat<1>, k_pat<2>, k_pat<3>, k_pat<4>, k_pat<5>, k_pat<6>, k_pat<7>};
+  for (int k = 0; k < 8; ++k) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ks[k]), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
   for (size_t p = 0; p < ops.size(); ++p) {
     hipLaunchKernelGGL(ks[ops[p]], dim3(wgs), dim3(64), 40960, 0, d_addr + 64 * p, iters, d_sink);   // 40 KB: 4 workgroups (one per SIMD) per CU
   }

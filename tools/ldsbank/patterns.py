@@ -2,7 +2,7 @@
 """Pattern sets for tools/ldsbank/ldsbank: `python patterns.py <set> > patterns.txt` also writes patterns.labels (one label per line).
 sets: calib (strides, broadcasts: what the bank model is), chain <pad...> (the access patterns of k_spectrum_chain<10> under a padding)."""
 import sys
-OPS = {"r64": 0, "w64": 1, "r128": 2, "w128": 3, "r32": 4, "w32": 5}
+OPS = {"r64": 0, "w64": 1, "r128": 2, "w128": 3, "r32": 4, "w32": 5, "r2x64": 6, "w2x32": 7}
 out, labels = [], []
 def add(label, op, addrs):
     assert len(addrs) == 64 and max(addrs) < 40960 - 16, (label, max(addrs))
@@ -44,10 +44,34 @@ def chain(pad, gmap=None, n=1024, full=False):
         for j in range(2):
             add("P3 twiddle stage 10 i=%d j=%d" % (i, j), "r64", [8 * pad(l + 64 * i + 256 * j) for l in range(64)])
 
+def mfir():
+    """the LDS accesses of k_mfir<0, 5, 10, 5> (csrc/sdrfm_q.hip), lane (n, g) = (l & 15, l >> 4): PRE = 160, ring 5120, d buffer behind it"""
+    PRE, RING, DB0 = 160, 5120, 128
+    db = PRE + RING
+    for ringoff in (0, 2560):
+        for c in (0, 5):
+            add("window read piece c=%d, ring offset %d (ds_read_b128)" % (c, ringoff), "r128", [ringoff + 160 * (l & 15) + 16 * (l >> 4) + 64 * c for l in range(64)])
+    for sigma in (0, 1):
+        add("d write, lane (n, g) -> words 8 n + 2 g, + 1 (ds_write2_b32), sigma=%d" % sigma, "w2x32", [db + 4 * (DB0 + sigma + 8 * (l & 15) + 2 * (l >> 4)) for l in range(64)])
+    add("d write as ds_write_b64", "w64", [db + 4 * (DB0 + 8 * (l & 15) + 2 * (l >> 4)) for l in range(64)])
+    add("d write, padded layout: word m + 2 (m >> 5) (what a conflict-free layout would cost: not built)", "w2x32",
+        [db + 4 * (DB0 + (8 * (l & 15) + 2 * (l >> 4)) + 2 * ((8 * (l & 15)) >> 5)) for l in range(64)])
+    for phi in (0, 3):
+        for i in (0, 9):
+            add("K4 window read pair i=%d, phi=%d: word phi + 10 lane - 31 + 4 i (ds_read2_b64)" % (i, phi), "r2x64",
+                [db + 4 * (DB0 + ((phi + 1) & 1) + phi + 10 * l - 31 + 4 * i - ((phi + 10 * l - 31) & 1) * 0) & ~7 for l in range(64)])
+    add("parked audio write: 8 bytes per lane (ds_write_b64)", "w64", [db + 4 * (DB0 + 656) + 8 * l for l in range(64)])
+    add("parked audio read at the flush (ds_read_b64)", "r64", [db + 4 * (DB0 + 656) + 8 * l for l in range(64)])
+    add("history copy read (ds_read_b32, lanes 0-31)", "r32", [db + 4 * (DB0 + 640 - 32 + (l & 31)) for l in range(64)])
+    add("history copy write (ds_write_b32, lanes 0-31)", "w32", [db + 4 * (DB0 - 32 + (l & 31)) for l in range(64)])
+    add("repair list entry write (ds_write_b16 ~ ds_write_b32 at 2 l)", "w32", [db + 4 * (DB0 + 656 + 512) + 4 * (l // 2) for l in range(64)])
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "calib"
     if which == "calib":
         calib()
+    elif which == "mfir":
+        mfir()
     elif which in ("chain", "chainperm", "chainall", "chainpermall"):
         co = [int(x) for x in sys.argv[2:]] or [4, 1, 8, 1]          # pairs (shift, coefficient)
         # chainperm: first-pass group of a lane = bits (4, 0, 1, 2, 5, 3) of the lane number (group bit k = lane bit perm[k])

@@ -32,6 +32,7 @@ static void lowpass(std::vector<float>& h, int T, double fc) {
 
 static void fill_row(uint8_t* row, int nsamp, int mode, unsigned id) {
   if (mode == 1) { for (int i = 0; i < 2 * nsamp; ++i) row[i] = (uint8_t)(rnd() >> 40); return; }
+  if (mode == 2) { for (int i = 0; i < 2 * nsamp; ++i) row[i] = (i & 1) ? 60 : 200; return; }   // constant bytes (a DC carrier): no data toggling — what the clock does then
   double ph = 0.1 * id, fcar = ((int)(id % 41) - 20) * 1000.0;
   for (int n = 0; n < nsamp; ++n) {
     const double tt = n / 2.4e6, a = 0.5 * sin(2 * M_PI * 1000 * tt) + 0.3 * sin(2 * M_PI * 3100 * tt) + 0.2 * sin(2 * M_PI * 7300 * tt);
@@ -51,7 +52,7 @@ static int gst_passes_hint(const unsigned long long* hd16, size_t nw) {   // any
 int main(int argc, char** argv) {
   const int ns = argc > 1 ? atoi(argv[1]) : 256, nsamp = argc > 2 ? atoi(argv[2]) : 240000, T = argc > 3 ? atoi(argv[3]) : 64;
   const int nslot = argc > 4 ? atoi(argv[4]) : 10, runs = argc > 5 ? atoi(argv[5]) : 12, iters = argc > 6 ? atoi(argv[6]) : 40;
-  const int mode = (argc > 7 && !strcmp(argv[7], "random")) ? 1 : 0;
+  const int mode = (argc > 7 && !strcmp(argv[7], "random")) ? 1 : ((argc > 7 && !strcmp(argv[7], "const")) ? 2 : 0);
   const int D = getenv("QBENCH_D") ? atoi(getenv("QBENCH_D")) : 10, Ta = 32, Da = getenv("QBENCH_DA") ? atoi(getenv("QBENCH_DA")) : 5, HT = T - 1;   // QBENCH_D=8 QBENCH_DA=8 / 16, 5: the other instances (nslot 4 / 8)
   if (nsamp % (8 * D * Da)) { fprintf(stderr, "nsamp must be a multiple of %d\n", 8 * D * Da); return 2; }
   const int M = nsamp / D, A = M / Da;
@@ -259,7 +260,7 @@ int main(int argc, char** argv) {
   printf("{\"blocks_per_cu_api\":%d}\n", sdrfm_q_blocks_per_cu(c0, nslot, D, Da));
   printf("{\"kernel\":\"%s\",\"ns\":%d,\"nsamp\":%d,\"T\":%d,\"nslot\":%d,\"runs\":%d,\"mode\":\"%s\",\"first_chunk\":%u,\"checked_streams\":%zu,"
          "\"max_scaled_err\":%.3g,\"worst_at\":[%d,%d],\"n_over_tol\":%ld,\"nonfinite\":%ld,\"state_err\":%.3g,\"us_per_launch\":%.2f,\"frac_of_8TBs\":%.4f,\"batches\":%d}\n",
-         sdrfm_q_kernel_symbol(c0, nslot, D, Da), ns, nsamp, T, nslot, runs, mode ? "random" : "fm", c0, chk.size(), worst, worst_s, worst_j, bad, nonfinite,
+         sdrfm_q_kernel_symbol(c0, nslot, D, Da), ns, nsamp, T, nslot, runs, mode == 1 ? "random" : (mode == 2 ? "const" : "fm"), c0, chk.size(), worst, worst_s, worst_j, bad, nonfinite,
          worst_state, us, bytes / (us * 1e-6) / 8e12, NB);
   return (bad || nonfinite || worst_state > 1e-4) ? 1 : 0;
 }
