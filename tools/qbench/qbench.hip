@@ -30,11 +30,12 @@ static void lowpass(std::vector<float>& h, int T, double fc) {
   for (int k = 0; k < T; ++k) h[k] = (float)(t[k] / s);
 }
 
-static void fill_row(uint8_t* row, int nsamp, int mode, unsigned id) {
-  if (mode == 1) { for (int i = 0; i < 2 * nsamp; ++i) row[i] = (uint8_t)(rnd() >> 40); return; }
-  if (mode == 2) { for (int i = 0; i < 2 * nsamp; ++i) row[i] = (i & 1) ? 60 : 200; return; }   // constant bytes (a DC carrier): no data toggling — what the clock does then
+// row[-2 * nhist .. 2 * nsamp): `nhist` samples of history before the call and the call's samples, one continuous signal
+static void fill_row(uint8_t* row, int nsamp, int mode, unsigned id, int nhist) {
+  if (mode == 1) { for (int i = -2 * nhist; i < 2 * nsamp; ++i) row[i] = (uint8_t)(rnd() >> 40); return; }
+  if (mode == 2) { for (int i = -2 * nhist; i < 2 * nsamp; ++i) row[i] = (i & 1) ? 60 : 200; return; }   // constant bytes (a DC carrier): no data toggling — what the clock does then
   double ph = 0.1 * id, fcar = ((int)(id % 41) - 20) * 1000.0;
-  for (int n = 0; n < nsamp; ++n) {
+  for (int n = -nhist; n < nsamp; ++n) {
     const double tt = n / 2.4e6, a = 0.5 * sin(2 * M_PI * 1000 * tt) + 0.3 * sin(2 * M_PI * 3100 * tt) + 0.2 * sin(2 * M_PI * 7300 * tt);
     ph += 2 * M_PI * (fcar + 75e3 * a) / 2.4e6;
     const double ni = ((double)(rnd() >> 40) / 16777216.0 - 0.5) * 8, nq = ((double)(rnd() >> 40) / 16777216.0 - 0.5) * 8;
@@ -70,15 +71,22 @@ int main(int argc, char** argv) {
   if (getenv("QBENCH_NB")) NB = atoi(getenv("QBENCH_NB"));   // 1 = resident input (Infinity Cache), for compute-bound estimates
   std::vector<uint8_t> hiq(batch);
   const int ncheck = ns < 6 ? ns : 6;
+  // the history before the call continues the same signal (a running capture: random history bytes in front of a carrier would send the
+  // streams' first outputs to the repair path — 18 repair calls per launch that a running capture does not have)
+  std::vector<uint8_t> hhb((size_t)ns * HT * 2), tmp(2 * (size_t)(nsamp + HT));
   for (int s = 0; s < ns; ++s) {
-    if (s < ncheck || s == ns - 1) fill_row(hiq.data() + s * stride, nsamp, mode, s);
-    else memcpy(hiq.data() + s * stride, hiq.data() + (s % ncheck) * stride, stride);
+    if (s < ncheck || s == ns - 1) {
+      fill_row(tmp.data() + 2 * HT, nsamp, mode, s, HT);
+      memcpy(hiq.data() + s * stride, tmp.data() + 2 * HT, stride);
+      memcpy(hhb.data() + (size_t)s * HT * 2, tmp.data(), 2 * HT);
+    } else {
+      memcpy(hiq.data() + s * stride, hiq.data() + (s % ncheck) * stride, stride);
+      memcpy(hhb.data() + (size_t)s * HT * 2, hhb.data() + (size_t)(s % ncheck) * HT * 2, 2 * HT);
+    }
   }
-  std::vector<uint8_t> hhb((size_t)ns * HT * 2);
   std::vector<float> hhd((size_t)ns * 31), hyp((size_t)ns * 2);
-  for (auto& v : hhb) v = (uint8_t)(rnd() >> 40);
   for (auto& v : hhd) v = (float)((double)(rnd() >> 40) / 16777216.0 - 0.5);
-  for (auto& v : hyp) v = (float)(((double)(rnd() >> 40) / 16777216.0 - 0.5) * 100);
+  for (auto& v : hyp) { const double u = (double)(rnd() >> 40) / 16777216.0 - 0.5; v = (float)((u < 0 ? -1.0 : 1.0) * (40.0 + 120.0 * fabs(u))); }   // a carrier's magnitude
 
   uint8_t* d_iq; float* d_audio; float2 *d_ypi, *d_ypo, *d_hxo; float *d_hdi, *d_hdo, *d_g; uint8_t *d_hbi, *d_hbo; int8_t* d_A;
   const size_t astride = (A + 63) & ~63;
@@ -168,6 +176,8 @@ int main(int argc, char** argv) {
     CK(hipMemset(d_a1, 0xff, astride * ns * 4)); CK(hipMemset(d_a2, 0xee, astride * ns * 4));
     SdrfmQParams b1 = p, b2 = p;
     b1.iq = d_iq + batch; b1.audio = d_a1; b1.yprev_in = d_ypo; b1.hist_d_in = d_hdo; b1.hist_b_in = d_hbo; b1.yprev_out = d_yp1; b1.hist_d_out = d_hd1; b1.hist_b_out = d_hb2;
+    b1.hist_q_in = p.hist_q_out; b1.hist_q_out = const_cast<uint8_t*>(p.hist_q_in); b1.yprev_exact = 0;   // (the state the first call handed over: its own y[-1], the raw samples it left)
+    b2.hist_q_out = const_cast<uint8_t*>(p.hist_q_in); b2.yprev_exact = 0;
     b2.iq = d_iq + batch; b2.audio = d_a2; b2.iq_prev = d_iq; b2.iq_prev_stride = stride; b2.N_prev = nsamp; b2.yprev_in = nullptr; b2.hist_d_in = nullptr; b2.hist_b_in = nullptr;
     b2.yprev_out = d_yp2; b2.hist_d_out = d_hd2; b2.hist_b_out = d_hb2;
     CK(sdrfm_q_launch(b1, c0, nslot, D, Da, st)); CK(sdrfm_q_launch(b2, c0, nslot, D, Da, st)); CK(hipStreamSynchronize(st));

@@ -59,11 +59,6 @@ constexpr int DB0 = 128;                        // d buffer: word DB0 + sigma = 
 constexpr int ABS = 4;                          // audio stages (128 outputs each) parked in LDS before they are stored
 constexpr int ABW = 128 * ABS;                  // words, after the d buffer
 constexpr int FLW = 64 + 2;                     // words, after the parked audio: up to 128 two-byte entries of lanes waiting for the repair path, two counters
-#ifndef SDRFM_Q_GTAB
-#define SDRFM_Q_GTAB 1   // 1: the audio taps are read from a table in LDS (one address for the whole wave: broadcasts) into VGPRs at every audio stage — a v_fma_f32
-#endif                   // with a tap from an SGPR issues at half rate (tools/ubench, profiles/ubench_r01), and 32 taps kept in SGPRs crowd the loop's scalars out; 0: rounds 3 - 4 (taps in SGPRs)
-constexpr int GTW = SDRFM_Q_GTAB ? 2 + (int)SDRFM_Q_TA : 0;    // words, after the list (16-byte aligned: FLW + 2 is a multiple of 4 words)
-typedef float qf4_t __attribute__((ext_vector_type(4)));
 constexpr int QTP = (int)SDRFM_Q_TP;            // the repair path's chain length (taps padded with zeros)
 // geometry of an instance: FIR decimation D (even), audio decimation DA
 template <int D, int DA>
@@ -82,18 +77,15 @@ struct QGeo {
   // chunks, blocks of 160 bytes: conflict-free as they are (the layout of rounds 3 - 4, untouched).
   static constexpr bool ALIGNED = (STEPB % 1024) == 0;
   static constexpr int CS = STEPB / 1024;       // (ALIGNED) chunks per step
+  static constexpr int WB = (STEPB - 5 * BLKB) & ~127;   // a warm-up step needs its bytes from here on (its last four blocks and the one before them, whole lines)
   static_assert(QTP % 4 == 0 && (2 * D) % 4 == 0, "the repair path loads whole groups of four samples, none of which straddles the call's first sample");
-  static_assert(QTP + 2 * D <= 96, "the tap table of the repair path sits below the d history");
+  static_assert(QTP + 2 * D <= 96, "the tap table of the repair path sits below the d's a warm-up step keeps");
   static_assert(D % 2 == 0 && D <= 16 && (ALIGNED || D == 10), "geometries the ring logic is written for");
 };
 #ifndef SDRFM_Q_AUX
 #define SDRFM_Q_AUX 2   // cache policy of the ring's fetches: 2 = nt (streamed once; measured 0.4-1 us per launch better than the default policy)
 #endif
-#ifndef SDRFM_Q_WQB
-#define SDRFM_Q_WQB 4   // blocks of a warm-up = the unit runs are cut in (>= 4: QTA - 1 d's and the y before them)
-#endif
-constexpr int WQB = SDRFM_Q_WQB;
-static_assert(WQB >= 4 && WQB <= 16 && 8 * WQB >= (int)SDRFM_Q_TA, "a warm-up holds the d history of a run's first audio output");
+constexpr int OOBV = (int)0x80000000;           // a voffset that is out of range for every row (num_records < 2^31)
 
 // K3 for design Q: the spec's conjugate product (sdrfm_math.h: one fused, two rounded products) and this kernel's own atan2 — the
 // same range reduction as sdrfm_atan2f with a shorter minimax polynomial (6 coefficients in s = v^2, |error| <= 3.9e-7 rad
@@ -137,7 +129,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16
   [[maybe_unused]] constexpr int NCH = G::NCH;
   constexpr int QD = D, QDA = DA, NSC = G::NSC, BLKB = G::BLKB, STEPB = G::STEPB, PRE = G::PRE, DBW = G::DBW, RWIN = G::RWIN;
   constexpr bool ALIGNED = G::ALIGNED;
-  constexpr int CS = G::CS;
+  constexpr int CS = G::CS, WB = G::WB;
   constexpr int RINGB = NSLOT * 1024;
   static_assert(RINGB % (2 * STEPB) == 0 && (ALIGNED ? NSLOT == 2 * CS : (NSLOT >= 5 && NSLOT - 4 < 16)), "ring: whole pairs of steps");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -146,16 +138,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16
   unsigned short* const fl16 = reinterpret_cast<unsigned short*>(ab + ABW);   // lanes waiting for the repair path: (step slot + 1) << 6 | lane
   const int lane = (int)threadIdx.x, n = lane & 15, g = lane >> 4;
   const uint32_t stream = blockIdx.x / p.runs, run = blockIdx.x - stream * p.runs;
-  // Runs are cut in QUADS of four blocks (32 outputs = the warm-up a run needs: QTA - 1 d's and the y before them; 4 BLKB bytes = whole
-  // 128-byte lines).  Every wave but the stream's first one (when that takes the carried state) walks one warm-up quad before what it
-  // owns; a wave's STEP GRID starts at its warm-up quad (not at a multiple of 16 blocks of the stream), so the warm-up costs a quarter
-  // of a step and the Gq = Qt + (warm-up quads) grid quads of a stream are dealt out evenly: the waves' walks differ by one quad at most
-  // (configs[2]: 63 or 64 quads = 16 steps for every wave; rounds 3 - 4 cut at whole steps and recomputed a whole step: 16 or 17).
-  const uint32_t Bt = (p.M + 7u) >> 3, Qt = (Bt + WQB - 1u) / WQB, vs = p.iq_prev ? 1u : 0u;
-  const uint32_t Gq = Qt + p.runs - 1u + vs;
-  const uint32_t e0 = (uint32_t)(((uint64_t)run * Gq) / p.runs), e1 = (uint32_t)(((uint64_t)(run + 1) * Gq) / p.runs);
-  const int q0 = run == 0 ? 0 : (int)e0 - (int)(run - 1u + vs), q1 = (int)e1 - (int)(run + vs);
-  if (q0 >= q1) return;
+  // (with iq_prev the stream's first run warms up like every other run: the cuts are made over steps_total + 1 steps and moved down by
+  // one, so that every wave still walks the same number of steps)
+  const uint32_t vshift = p.iq_prev ? 1u : 0u, vsteps = p.steps_total + vshift;
+  const int s0 = run == 0 ? 0 : (int)(((uint64_t)run * vsteps) / p.runs - vshift), s1 = (int)(((uint64_t)(run + 1) * vsteps) / p.runs - vshift);
+  if (s0 >= s1) return;
   if (lane == 0) *reinterpret_cast<uint2*>(fl16 + 128) = make_uint2(0u, 0u);   // repair statistics of this wave (before any LDS-DMA is in flight: no wait)
 #ifdef SDRFM_Q_STAMPS   // development harness (tools/qbench): per-wave time stamps, 8 words per wave
   unsigned long long* const tsp = p.dbg ? p.dbg + 16 * (size_t)blockIdx.x : nullptr;
@@ -166,30 +153,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16
 #ifdef SDRFM_Q_PHASES
   unsigned long long t_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = 0;
 #endif
-  // A run warms up unless it starts the stream's chunk AND takes the carried state; with iq_prev (the previous call's buffer:
-  // SDRFM_F_OVERLAP) the stream's first run warms up too, from that buffer's last bytes, and the call depends on nothing the previous
-  // call computes.
-  const bool from_prev = run == 0 && p.iq_prev != nullptr;
-  const bool warm = run > 0 || from_prev;
-  const int b0 = WQB * q0;                                      // owned blocks [b0, b1)
-  int b1 = WQB * q1;
-  if (b1 > (int)Bt) b1 = (int)Bt;
-  const bool last_run = b1 == (int)Bt;
-  const int bs = warm ? b0 - WQB : b0;                          // the wave's grid starts at this block (-4 for the stream's first run under SDRFM_F_OVERLAP)
-  const int nsteps = (b1 - bs + 15) >> 4;
-  const int nlast = b1 - bs - 16 * (nsteps - 1);                // blocks of the last step that exist (the lanes beyond hold whatever the ring held)
-  const int o0 = 8 * bs;                                        // first output of the grid = output index of d-buffer word DB0 + sigma
-  const int jg0 = (o0 + 64 * QDA) / QDA - 64;                   // floor(o0 / QDA): first audio output whose newest d lies in the grid
-  const int jlo = warm ? (o0 + 8 * WQB) / QDA : 0;                  // first audio output whose newest d lies in an OWNED block (the ones before it are the previous run's)
-  int j1 = (8 * b1) / QDA;
+  // A run recomputes the step before it unless it starts the stream's chunk AND takes the carried state; with iq_prev (the previous
+  // call's buffer: SDRFM_F_OVERLAP) the stream's first run warms up too, from that buffer's last bytes, and the call depends on
+  // nothing the previous call computes.
+  const bool from_prev = s0 == 0 && p.iq_prev != nullptr;
+  const bool warm = s0 > 0 || from_prev, last_run = (uint32_t)s1 == p.steps_total;
+  const int ks = warm ? s0 - 1 : s0, nsteps = s1 - ks;
+  const int j0 = (128 * s0) / QDA;                              // first audio output whose newest d lies in an owned step
+  int j1 = (128 * s1) / QDA;
   if (j1 > (int)p.A_out) j1 = (int)p.A_out;
-  const int phi = QDA * jg0 + QDA - 1 - o0;                     // newest d of output jg0, relative to the grid's first output (0..QDA-1)
+  const int phi = QDA * j0 + QDA - 1 - 128 * s0;                // its newest d, relative to the first owned output (0..4)
   const int sigma = (phi + 1) & 1;                              // shifts the d buffer so that every lane's window starts on an even word
 
   // ---- carried state (the stream's first run): the loads are issued here and land in LDS after the ring's prologue has left ------
-  // y[m-1] of the step's first output (lane 0).  A warm-up has none: the grid's first d is never read (a run's first audio output reaches
-  // QTA - 1 = 31 d's back, the warm-up quad holds 32), and a large value keeps the guard from listing lane 0 for it.
-  float cr = 1.0e4f, ci = 0.0f;
+  float cr = 0.0f, ci = 0.0f;                                   // y[m-1] of the step's first output (lane 0)
   const int HT = (int)p.T - 1;
   unsigned short hb0 = 0, hb1 = 0;
   float hd0 = 0.0f;
@@ -204,49 +181,49 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16
 
   // ---- the ring --------------------------------------------------------------------------------------------------------------
   const unsigned long long gaddr = (unsigned long long)(p.iq + (size_t)stream * p.iq_stride);
-  uint32_t hi = (uint32_t)BLKB * (uint32_t)b1;                  // bytes of the row this run may touch: [.., hi)
+  uint32_t hi = (uint32_t)STEPB * (uint32_t)s1;                 // bytes of the row this run may touch: [.., hi)
   if (hi > 2u * p.N) hi = 2u * p.N;
   const qi4_t rsrc = {(int)(unsigned)gaddr, (int)(unsigned)(gaddr >> 32), (int)hi, 0x00020000};
   // (ALIGNED) the lane's 16 bytes of a chunk, swizzled: the piece that belongs at chunk + 16 lane of the ring is logical piece
   // lane ^ key, key = the block's index mod 8 (a chunk holds 1024 / BLKB blocks; D = 16: two variants, by the parity of the chunk)
   const int lsw0 = ALIGNED ? ((16 * lane) ^ (((((16 * lane) / BLKB)) & 7) << 4)) : 16 * lane;
   const int lsw1 = ALIGNED ? ((16 * lane) ^ (((((1024 + 16 * lane) / BLKB)) & 7) << 4)) : 16 * lane;   // odd chunks (differs for BLKB = 256 only)
-  const int gb = BLKB * bs;                                     // row offset of the grid's first byte: a multiple of 4 BLKB (whole 128-byte lines); -4 BLKB for from_prev
-  int vpos = gb + (ALIGNED ? 0 : 16 * lane);                    // row offset of the next chunk (ALIGNED: without the lane's part)
+  int vpos = STEPB * ks + (ALIGNED ? 0 : 16 * lane);            // row offset of the next chunk (ALIGNED: without the lane's part)
   auto slot_ptr = [&](int slot) { return (__attribute__((address_space(3))) void*)(smem + PRE + 1024 * slot); };
   auto lsw = [&](int chunk) { return (BLKB == 256 && (chunk & 1)) ? lsw1 : lsw0; };
-  // prologue: the block before the grid (the pre-halo: the first block's window reaches into it; BLKB / 16 lanes), then NSLOT chunks.
-  // For the stream's first run under SDRFM_F_OVERLAP the pre-halo and the warm-up quad are the last five blocks of the PREVIOUS
-  // call's row: lanes are switched between the two rows by EXEC, not by an out-of-range offset, so that no lane's piece is written
-  // twice (a chunk fetched in two parts counts twice in vmcnt: more than the first step's wait assumes, never less).  The first step's
-  // chunks (what the first step waits for) go out first, then the requests for the L2-resident tables, then the rest of the ring: the
-  // opening burst of all waves' first steps is what every wave's start waits behind.
-  constexpr int HL = BLKB / 16, HK = ALIGNED ? 7 : 0;           // lanes of the pre-halo; its swizzle key (block index -1)
-  const unsigned long long pa = from_prev ? (unsigned long long)(p.iq_prev + (size_t)stream * p.iq_prev_stride) + 2ull * p.N_prev - (WQB + 1) * BLKB : 0ull;
-  const qi4_t rprev = {(int)(unsigned)pa, (int)(unsigned)(pa >> 32), (WQB + 1) * BLKB, 0x00020000};   // the previous row's last WQB + 1 blocks: row offset x (< 0) sits at x + (WQB + 1) BLKB
-  if (warm && lane < HL) {
-    const int hv = 16 * (lane ^ HK);
-    if (from_prev) q_raw_buffer_load_lds(rprev, (__attribute__((address_space(3))) void*)smem, 16, hv, 0, 0, SDRFM_Q_AUX);
-    else q_raw_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)smem, 16, gb - BLKB + hv, 0, 0, SDRFM_Q_AUX);
-  }
+  // prologue: NSLOT chunks.  A warm-up step needs only its last four blocks and the block before them (bytes >= WB of the step,
+  // rounded to a line): the pieces before that are switched off by an out-of-range offset (the instruction still counts).  The
+  // first step's chunks (what the first step waits for) go out first, then the requests for the L2-resident tables, then the rest of
+  // the ring: the opening burst of all waves' first steps is what every wave's start waits behind.
   if constexpr (ALIGNED) {
+    // the first step (a warm-up step when `warm`; under SDRFM_F_OVERLAP the last step of the PREVIOUS call's row for the stream's first run)
+    const unsigned long long pa = from_prev ? (unsigned long long)(p.iq_prev + (size_t)stream * p.iq_prev_stride) + 2ull * p.N_prev - STEPB : gaddr;
+    const qi4_t rfirst = {(int)(unsigned)pa, (int)(unsigned)(pa >> 32), from_prev ? STEPB : (int)hi, 0x00020000};
+    const int vfirst = from_prev ? 0 : vpos;
 #pragma unroll
-    for (int q = 0; q < CS; ++q) {                              // the first step
-      const int off = gb + 1024 * q + lsw(q);
-      if (from_prev && off < 0) q_raw_buffer_load_lds(rprev, slot_ptr(q), 16, off + (WQB + 1) * BLKB, 0, 0, SDRFM_Q_AUX);
-      else q_raw_buffer_load_lds(rsrc, slot_ptr(q), 16, off, 0, 0, SDRFM_Q_AUX);
+    for (int q = 0; q < CS; ++q) {
+      const int off = 1024 * q + lsw(q);
+      q_raw_buffer_load_lds(rfirst, slot_ptr(q), 16, (warm && off < WB) ? OOBV : vfirst + off, 0, 0, SDRFM_Q_AUX);
     }
+  } else if (from_prev) {
+    // step -1 = the last STEPB bytes of the previous call's row: its bytes >= 1664 come from there (lanes 40.. of chunk 1, lanes ..31
+    // of chunk 2), the rest of chunk 2 is the head of this call's row.  Lanes are switched off by EXEC here, not by an out-of-range
+    // offset, so that no lane's piece is written twice.
+    static_assert(ALIGNED || WB == 1664, "the lane numbers below");
+    const unsigned long long pa = (unsigned long long)(p.iq_prev + (size_t)stream * p.iq_prev_stride) + 2ull * p.N_prev - STEPB;
+    const qi4_t rprev = {(int)(unsigned)pa, (int)(unsigned)(pa >> 32), STEPB, 0x00020000};
+    q_raw_buffer_load_lds(rsrc, slot_ptr(0), 16, OOBV, 0, 0, SDRFM_Q_AUX);
+    if (lane >= 40) q_raw_buffer_load_lds(rprev, slot_ptr(1), 16, 1024 + 16 * lane, 0, 0, SDRFM_Q_AUX);
+    if (lane < 32) q_raw_buffer_load_lds(rprev, slot_ptr(0), 16, 16 * lane, 0, 2048, SDRFM_Q_AUX);
+    else q_raw_buffer_load_lds(rsrc, slot_ptr(0), 16, vpos, 0, 2048, SDRFM_Q_AUX);
   } else {
+    const int v0 = warm ? OOBV : vpos;
+    const int v1 = (warm && lane < 40) ? OOBV : vpos + 1024;
+    q_raw_buffer_load_lds(rsrc, slot_ptr(0), 16, v0, 0, 0, SDRFM_Q_AUX);
+    q_raw_buffer_load_lds(rsrc, slot_ptr(1), 16, v1, 0, 0, SDRFM_Q_AUX);
     // (the instruction's immediate offset moves BOTH the memory address and the LDS address: a group of up to four chunks shares
     // one voffset register and one LDS base)
-    auto first_step_chunk = [&](int c, __attribute__((address_space(3))) void* lds, int imm) {
-      const int off = vpos + 1024 * c;                          // row offset of the lane's piece of grid chunk c
-      if (from_prev && off < 0) q_raw_buffer_load_lds(rprev, lds, 16, off - imm + (WQB + 1) * BLKB, 0, imm, SDRFM_Q_AUX);
-      else q_raw_buffer_load_lds(rsrc, lds, 16, off - imm, 0, imm, SDRFM_Q_AUX);
-    };
-    first_step_chunk(0, slot_ptr(0), 0);
-    first_step_chunk(1, slot_ptr(1), 0);
-    first_step_chunk(2, slot_ptr(0), 2048);
+    q_raw_buffer_load_lds(rsrc, slot_ptr(0), 16, vpos, 0, 2048, SDRFM_Q_AUX);
   }
   __builtin_amdgcn_sched_barrier(0);
   asm volatile("" ::: "memory");
@@ -263,27 +240,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16
       At[c - C0][t] = *reinterpret_cast<const qi4_t*>(p.A + ((size_t)((c * SDRFM_Q_DIGITS + t) * 64 + lane)) * 16);
 #endif
   const int sidx = (lane & 1) ? (int)0xDDDDDDDD : (int)0x88888888;   // 2:4 index word: a Q row keeps positions 1, 3 of every four, an I row 0, 2
-#if SDRFM_Q_GTAB
-  // gt[k] multiplies the k-th oldest d of a window: a table in LDS, read into VGPRs at every audio stage
-  float* const gt = reinterpret_cast<float*>(fl16) + FLW + 2;
-  static_assert(QTA <= 64 && (FLW + 2) % 4 == 0, "one lane per audio tap; ds_read_b128 of the table");
-  const float gt0 = lane < QTA ? p.g[QTA - 1 - lane] : 0.0f;
-#else
   float gr[QTA];                                                // gr[k] multiplies the k-th oldest d of a window
 #pragma unroll
   for (int k = 0; k < QTA; ++k)                                 // wave-uniform: kept in SGPRs (the tap tables take 60 VGPRs; four waves per SIMD need the rest)
     gr[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.g[QTA - 1 - k])));
-#endif
 
   // the repair path's taps (rare; see repair_flagged) as a table in LDS: hz[u] = h[QTP + 2 QD - 1 - u] for u >= 2 QD, zero below — sample i
   // of a repaired lane's window meets output m0 - 1 + o through hz[i - QD o + 2 QD].  It sits in the d buffer's first words, which nothing
-  // reads or writes (the d history of a stage sits in the QTA words right below DB0 + sigma).
-  static_assert(QTP + 2 * QD <= DB0 - (int)SDRFM_Q_TA && DB0 == 128, "the tap table of the repair path sits below the d history");
+  // reads or writes (a warm-up step parks only the d's of its last four blocks there: below).
+  static_assert(QTP + 2 * QD <= 96 && DB0 == 128, "the tap table of the repair path sits below the d's a warm-up step keeps");
   const float hz0 = lane >= 2 * QD ? p.hpad[QTP + 2 * QD - 1 - lane] : 0.0f;
   const float hz1 = lane < 2 * QD ? p.hpad[2 * QD - 1 - lane] : 0.0f;
   __builtin_amdgcn_sched_barrier(0);
   asm volatile("" ::: "memory");
-  if constexpr (ALIGNED) {                                      // the second step of the ring: exactly CS instructions (what a step's wait leaves in flight)
+  if constexpr (ALIGNED) {                                      // the second step of the ring (under SDRFM_F_OVERLAP: step 0 of this call's row for the stream's first run)
 #pragma unroll
     for (int q = 0; q < CS; ++q) q_raw_buffer_load_lds(rsrc, slot_ptr(CS + q), 16, vpos + STEPB + 1024 * q + lsw(CS + q), 0, 0, SDRFM_Q_AUX);
   } else {
@@ -303,14 +273,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16
   }
   db[lane] = hz0;
   if (lane < 2 * QD) db[64 + lane] = hz1;
-#if SDRFM_Q_GTAB
-  if (lane < QTA) gt[lane] = gt0;
-#endif
   __builtin_amdgcn_wave_barrier();                              // (one wave per workgroup: lanes exchange data through LDS in program order; this only pins that order for the compiler)
   int slot = 0;                                                 // ring slot of the next chunk
   int ringoff = 0;                                              // ring byte offset of the current step
-  int osm = 0;                                                  // steps in the d buffer since the last audio stage
-  int mbase = o0;                                               // output index of d-buffer word DB0 + sigma
+  int osm = warm ? -1 : 0;                                      // owned steps in the d buffer since the last audio stage
+  int mbase = 128 * s0;                                         // output index of d-buffer word DB0 + sigma
   const int baddr = BLKB * n + 16 * g;                          // window of block n starts at PRE + ringoff - BLKB + BLKB n
   // (ALIGNED) the same pieces through the swizzle: piece c of the window = ring bytes BLKB (n - 1) + 64 c + 16 g, .. + 16 (relative to the
   // step): block n - 1 + (64 c + 16 g) / BLKB, key = that block's index mod 8 (a step is 16 blocks: the key does not depend on the step)
@@ -326,8 +293,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16
   }
   const int srcaddr = 4 * (g > 0 ? lane - 16 : ((lane + 47) & 63));   // lane holding y[m-1] of this lane's first output
   const int dlane = 8 * n + 2 * g;
-  const int ylast = (int)p.M - 1 - o0;                          // the call's last output, relative to the grid
-  const int ylast_step = ylast >> 7, ylast_lane = ((ylast & 127) >> 3) + 16 * ((ylast & 7) >> 1);
+  const int ylast_step = ((int)p.M - 1) >> 7, ylast_lane = ((((int)p.M - 1) & 127) >> 3) + 16 * ((((int)p.M - 1) & 7) >> 1);
 
   // (A version software-pipelined by one stage — the window of step kk + 1 read, and the ring refilled, while the discriminators of
   // step kk run — measured 33.4 us against 30.5 us for this straight order on the same box: the earlier wait for the next step's bytes
@@ -408,34 +374,31 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16
   // youngest fetches" then also waits for the stores' acknowledgement AND for the fetches issued before them — a full round trip through
   // the memory system every five steps (measured: 4.5 of 27.5 us per call on configs[2]).  The outputs are parked in LDS and stored
   // after the run's last step (every ABS stages in a long run), whole 8-byte pairs when the row allows.
-  int npend = 0, jfl = jg0;                                     // parked stages; audio output index of the first parked word
+  int npend = 0, jfl = j0;                                      // parked stages; first parked output
   auto flush_audio = [&]() {
     __builtin_amdgcn_wave_barrier();
-    // Row elements [max(jfl, jlo), min(jfl + 128 npend, j1)) come from ab[e - jfl] (the outputs before jlo — a warm-up's — are the previous
-    // run's; those from j1 on the next one's), stored as 8-byte pairs aligned in MEMORY whatever the parity of jfl (4-byte stores cost
-    // read-modify-writes: round 3), single words at the two ends only.
 #if defined(SDRFM_Q_ABLATE) && (SDRFM_Q_ABLATE & 256)   // every wave stores to the same 2 KiB (same instructions, no write traffic to speak of)
-    float* row = p.audio - jfl;
+    float* out = p.audio;
     const int ln_ = lane;
 #else
     uint32_t st_ = stream;                                      // (derived here, from opaque copies: a pointer kept across the step loop costs registers there)
     int ln_ = lane;
     asm volatile("" : "+s"(st_), "+v"(ln_));
-    float* row = kargs()->audio + (size_t)st_ * kargs()->audio_stride;
+    float* out = kargs()->audio + (size_t)st_ * kargs()->audio_stride + jfl;
 #endif
-    const int lo = jfl > jlo ? jfl : jlo;
 #if defined(SDRFM_Q_ABLATE) && (SDRFM_Q_ABLATE & 128)
-    const int hi_ = (ab[lane] == 1234.5f) ? lo + 2 : lo;
+    const int cnt = (ab[lane] == 1234.5f) ? 2 : 0;
 #else
-    const int hi_ = (j1 < jfl + 128 * npend) ? j1 : jfl + 128 * npend;
+    const int cnt = (j1 - jfl < 128 * npend) ? j1 - jfl : 128 * npend;
 #endif
-    const int par = (int)((reinterpret_cast<uintptr_t>(row) >> 2) & 1u);   // row + e is 8-byte aligned where e + par is even
-    for (int e = lo - ((lo + par) & 1) + 2 * ln_; e < hi_; e += 128) {
-      const bool v0 = e >= lo, v1 = e + 1 < hi_;
-      const float a0 = v0 ? ab[e - jfl] : 0.0f, a1 = v1 ? ab[e + 1 - jfl] : 0.0f;
-      if (v0 && v1) *reinterpret_cast<qf2_t*>(row + e) = qf2_t{a0, a1};
-      else if (v0) row[e] = a0;
-      else if (v1) row[e + 1] = a1;
+    if ((reinterpret_cast<uintptr_t>(out) & 7) == 0) {
+      for (int i = 2 * ln_; i < cnt; i += 128) {
+        const qf2_t v = *reinterpret_cast<const qf2_t*>(ab + i);
+        if (i + 1 < cnt) *reinterpret_cast<qf2_t*>(out + i) = v;
+        else out[i] = v.x;
+      }
+    } else {
+      for (int i = ln_; i < cnt; i += 64) out[i] = ab[i];
     }
     jfl += 128 * npend;
     npend = 0;
@@ -534,12 +497,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16
   // remaining steps (a wave that is behind outranks one that is ahead), alone or on top of the rank: no better (25.9 - 26.4 us).
   float guard_r = p.guard_r, guard_a = p.guard_a;             // (in VGPRs: the loop's scalar registers are all taken)
   asm volatile("" : "+v"(guard_r), "+v"(guard_a));
-#ifdef SDRFM_Q_SCALE_VGPR   // experiment (round 5): the recombination's factors in VGPRs (an FMA with an SGPR operand issues at half rate) — measured 0.2 us
-  float q0v = p.q0, q2v = p.q2, cstv = p.cst;                  // per call SLOWER than leaving them in SGPRs (the kernel sits at its 128 VGPRs): profiles/r05_q_experiments.txt
-  asm volatile("" : "+v"(q0v), "+v"(q2v), "+v"(cstv));
-#else
-  const float q0v = p.q0, q2v = p.q2, cstv = p.cst;
-#endif
   const int wrank = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 4) & 15u);
   const int prio_at = p.prio_by_age ? nsteps / 2 : -1;
   for (int kk = 0; kk < nsteps; ++kk) {
@@ -583,7 +540,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int s01 = acc[0][r] + acc[1][r] * 256;              // exact: |S0| <= 2^20, |S1 << 8| <= 2^28
-      y[r] = __builtin_fmaf((float)s01, q0v, __builtin_fmaf((float)acc[2][r], q2v, cstv));
+      y[r] = __builtin_fmaf((float)s01, p.q0, __builtin_fmaf((float)acc[2][r], p.q2, p.cst));
     }
 #ifdef SDRFM_Q_PHASES
     asm volatile("" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
@@ -605,12 +562,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16
     const float d1 = q_discriminate(y[2], y[3], y[0], y[1]);   // (the pair that needs no neighbour first: its chain runs while the exchange is in flight)
     const float d0 = q_discriminate(y[0], y[1], pr, pi);
 #endif
-    {
+    if (osm >= 0 || n >= 12) {                                  // (a warm-up step: only the d's of its last four blocks are kept — the words below them hold the repair path's taps)
       float* dst = db + DB0 + sigma + 128 * osm + dlane;
       dst[0] = d0;
       dst[1] = d1;
     }
-    if (last_run && kk == ylast_step && lane == ylast_lane) kargs()->yprev_out[stream] = make_float2(y[2], y[3]);
+    if (last_run && ks + kk == ylast_step && lane == ylast_lane) kargs()->yprev_out[stream] = make_float2(y[2], y[3]);
 #if !(defined(SDRFM_Q_ABLATE) && (SDRFM_Q_ABLATE & 512))
     // ---- the conditioning guard: design Q's y is within E ~ 1e-4 (absolute) of the definition's fmaf chain, so its d is within
     // E / |y| + E / |p| of the definition's — fine while both magnitudes are large, not at a deep fade, and near d = +-pi the two may land
@@ -633,7 +590,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16
             [gr] "v"(guard_r), [ga] "v"(guard_a)
           : "scc");
       if (fm) {                                                                                // wave-uniform, rare
-        if (kk == nsteps - 1 && nlast < 16) fm &= 0x0001000100010001ull * ((1ull << nlast) - 1ull);   // the run's last step: only its first nlast blocks exist
+        if (warm && kk == 0) fm &= 0xF000F000F000F000ull;       // a warm-up step: only blocks 12..15 were fetched and matter
         if (fm) {
           const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(fm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fm, 0u));
           if ((fm >> lane) & 1ull) fl16[nflag + rank] = (unsigned short)(((osm + 1) << 6) | lane);
@@ -681,20 +638,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16
         dw[2 * i + 1] = v.y;
       }
       float a0 = 0.0f, a0b = 0.0f, a1 = 0.0f, a1b = 0.0f;
-#if SDRFM_Q_GTAB
-#pragma unroll
-      for (int q = 0; q < QTA / 8; ++q) {                       // (the same four chains in the same order: bit-identical to the taps-in-SGPRs form)
-        const qf4_t tl = *reinterpret_cast<const qf4_t*>(gt + 4 * q), th = *reinterpret_cast<const qf4_t*>(gt + QTA / 2 + 4 * q);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int k = 4 * q + i;
-          a0 = __builtin_fmaf(tl[i], dw[k], a0);
-          a0b = __builtin_fmaf(th[i], dw[QTA / 2 + k], a0b);
-          a1 = __builtin_fmaf(tl[i], dw[QDA + k], a1);
-          a1b = __builtin_fmaf(th[i], dw[QDA + QTA / 2 + k], a1b);
-        }
-      }
-#else
 #pragma unroll
       for (int k = 0; k < QTA / 2; ++k) {
         a0 = __builtin_fmaf(gr[k], dw[k], a0);
@@ -702,7 +645,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16
         a1 = __builtin_fmaf(gr[k], dw[QDA + k], a1);
         a1b = __builtin_fmaf(gr[QTA / 2 + k], dw[QDA + QTA / 2 + k], a1b);
       }
-#endif
       a0 += a0b;
       a1 += a1b;
       *reinterpret_cast<qf2_t*>(ab + 128 * npend + 2 * lane) = qf2_t{a0, a1};
@@ -809,7 +751,7 @@ __global__ void __launch_bounds__(64) k_q_read_stream(const uint8_t* base, unsig
 typedef void (*QKernel)(SdrfmQParams);
 struct QVariant { uint32_t c0, nslot, d, da, lds; QKernel k; const char* name; };
 template <int D, int DA, int NSLOT>
-constexpr uint32_t q_lds() { return (uint32_t)(QGeo<D, DA>::PRE + 1024 * NSLOT + 4 * (QGeo<D, DA>::DBW + ABW + FLW + GTW)); }
+constexpr uint32_t q_lds() { return (uint32_t)(QGeo<D, DA>::PRE + 1024 * NSLOT + 4 * (QGeo<D, DA>::DBW + ABW + FLW)); }
 #define QV(C0_, NS_) { C0_, NS_, 10, 5, q_lds<10, 5, NS_>(), k_mfir<C0_, NS_, 10, 5>, "k_mfir<" #C0_ "," #NS_ ">" }
 #define QVD(C0_, NS_, D_, DA_) { C0_, NS_, D_, DA_, q_lds<D_, DA_, NS_>(), k_mfir<C0_, NS_, D_, DA_>, "k_mfir<" #C0_ "," #NS_ "," #D_ "," #DA_ ">" }
 // D = 10 / DA = 5: the 2.4 MS/s front end of BASELINE (ring of 5 KiB; 10 and 15 for experiments).  D = 8 / DA = 8: 2.048 MS/s -> 256 kS/s ->
