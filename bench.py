@@ -54,6 +54,7 @@ def parse():
                     "SURVEY.md 8d (default, the headline); random = uniform random bytes, its worst-case class (noise only: the matrix-pipe kernel's "
                     "conditioning guard sends about one lane in ten to the repair path); a comparison figure, labelled as such")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-steady", action="store_true", help="skip the steady-state series (ten regions of 300 calls; fm workload)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--check", action="store_true", help="also verify a few streams against the oracle (not timed)")
     ap.add_argument("--workload", choices=["fm", "wbfm", "spectrum"], default="fm",
@@ -269,6 +270,8 @@ def timed(torch, dist, use_dist, stream, step, steps, finish=None, rest=0.0):
     if finish is not None:
         finish()
     ev1.record(stream)
+    while not ev1.query():                                        # (the closing synchronize then returns at once: a blocking wait's wake-up latency is not part of K steps)
+        pass
     fence()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -276,6 +279,25 @@ def timed(torch, dist, use_dist, stream, step, steps, finish=None, rest=0.0):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed, ev0.elapsed_time(ev1) / steps
+
+
+def steady_regions(torch, stream, step, finish=None, regions=10, steps=300):
+    """What a consumer that runs for seconds sees: `regions` regions of `steps` calls back to back (no rest between them), each between one pair of
+    HIP events on the launch stream -> ms per call of every region.  From a rested GPU the first regions run slower than the later ones: the
+    power management dips between ~1 ms and ~30 ms after a load starts (profiles/r05_clock_transient.txt) and then settles; a 20-step region sits
+    before the dip, a 300-step region from rest inside it, the last regions of this series behind it."""
+    out = []
+    for _ in range(regions):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(stream)
+        for i in range(steps):
+            step(i)
+        if finish is not None:
+            finish()
+        ev1.record(stream)
+        ev1.synchronize()
+        out.append(ev0.elapsed_time(ev1) / steps)
+    return out
 
 
 def per_launch_events(torch, stream, step, n):
@@ -368,8 +390,15 @@ def main():
             audio_pair = [audio, torch.zeros_like(audio)]
         stream.synchronize()
 
+    ovl_calls = {"n": 0}
+
     def step_ovl(i):
-        last["n"] = dm.process_batch_device(batches[i % nb], audio_pair[i & 1], overlap=True)
+        # the two audio buffers are taken in turn ACROSS regions, as a running caller's are: a region that started again with the buffer the
+        # previous region's last call wrote (i & 1 restarting at 0) had its first call made serially by the library (two consecutive calls
+        # must not write the same audio buffer), and the next few waited on the handle's stream for it — 2 us per call of a 20-call region
+        # (profiles/r05_driver_command_trace_before.json)
+        last["n"] = dm.process_batch_device(batches[i % nb], audio_pair[ovl_calls["n"] & 1], overlap=True)
+        ovl_calls["n"] += 1
 
     for i in range(args.warmup):
         (step_ovl if overlap else step_rot)(i)
@@ -410,6 +439,14 @@ def main():
         _, kernel_ms_sus = timed(torch, dist, use_dist, stream, step_rot, sus_steps, rest=REST_S)
     if overlap:
         _, kernel_ms_ovl_sus = (None, kernel_ms_ovl) if args.steps >= 300 else timed(torch, dist, use_dist, stream, step_ovl, 300, finish=dm.flush, rest=REST_S)
+    # steady state: ten regions of 300 calls back to back; the median of the last five (single-GPU runs: a scaling run's ranks are not held together here)
+    steady_ser = steady_ovl = None
+    if e2e is None and not use_dist and not args.no_steady:
+        time.sleep(REST_S)
+        steady_ser = steady_regions(torch, stream, step_rot)
+        if overlap:
+            time.sleep(REST_S)
+            steady_ovl = steady_regions(torch, stream, step_ovl, finish=dm.flush)
     # second, labelled figure: ONE resident input batch (fits the 256 MiB Infinity Cache) — what round 1 reported as `value`
     res_steps = min(args.steps, 100)
     for i in range(min(args.warmup, 10)):
@@ -483,6 +520,11 @@ def main():
                          "kernel_ms_isolated_avg": round(float(np.mean(kernel_ms)), 4),
                          "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
                          "algorithmic_bytes_per_launch": alg_bytes,
+                         **({"frac_steady": round(alg_bytes / (float(np.median(steady_ser[5:])) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                             "kernel_ms_regions_300": [round(x, 4) for x in steady_ser],
+                             "steady_note": "ten regions of 300 calls back to back from a rested GPU; frac_steady = the median of the last five (the state a consumer "
+                                            "that runs for seconds sees); frac_sustained = ONE 300-call region from rest, which sits inside the power management's dip "
+                                            "between ~1 and ~30 ms after a load starts (profiles/r05_clock_transient.txt)"} if steady_ser else {}),
                          **({"kernel_ms_avg_regions": [round(x, 4) for x in serial_regions],
                              "frac_best_region": round(alg_bytes / (min(serial_regions) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
                             if serial_regions and len(serial_regions) > 1 else {})},
@@ -501,6 +543,8 @@ def main():
                 "kernel": served_by, "ms_per_call": round(kernel_ms_ovl, 4),
                 "frac": round(alg_bytes / (kernel_ms_ovl * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                 "frac_sustained": round(alg_bytes / (kernel_ms_ovl_sus * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                **({"frac_steady": round(alg_bytes / (float(np.median(steady_ovl[5:])) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                    "ms_per_call_regions_300": [round(x, 4) for x in steady_ovl]} if steady_ovl else {}),
                 "note": "bytes per call / (event span of the timed region / K); `value` is measured on these calls"}
         if args.bit_exact:
             res["handle"] = "SDRFM_CFG_BIT_EXACT (fmaf-chain kernels only: NOT the default path)"

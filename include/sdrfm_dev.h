@@ -10,6 +10,7 @@
  *     sdrfm_q_guard                                design Q: the conditioning guard's thresholds for a tap set (csrc/qtaps.c; no GPU)
  *     sdrfm_debug_q_guard                          design Q: a handle's guard thresholds and how often its repair path ran
  *     sdrfm_debug_read_ceiling                     what a read-only stream with design Q's access pattern gets out of the memory system
+ *     sdrfm_debug_route                            design Q: which streams of a handle the bit-exact kernels serve (read, or set for a test)
  *   exported by the development library libsdrfm_dev.so only (built with -DSDRFM_DEV):
  *     sdrfm_debug_phase_cycles, sdrfm_debug_raw    instrumented kernels' counters (SDRFM_PHASE_PROFILE=1 at create)
  *     sdrfm_dev_read_debug                         per-wave time stamps of design S (SDRFM_STREAM_PROFILE=1)
@@ -45,6 +46,13 @@ int sdrfm_q_guard(const float* h, uint32_t T, const float* g, uint32_t Ta, float
  * lanes repaired / repair passes run since create (32-bit counters on the device).  Synchronises the handle.  SDRFM_NOT_SUPPORTED when the
  * handle has no matrix-pipe kernel (SDRFM_CFG_BIT_EXACT, other geometries). */
 int sdrfm_debug_q_guard(sdrfm_t* h, float* guard_r, float* guard_a, unsigned long long* lanes, unsigned long long* passes);
+
+/* Per-stream routing (csrc/sdrfm.hip: the handle's comment): a stream whose windows of design-Q calls are mostly repair work is served by the bit-exact
+ * kernels for a while, by a launch of their own beside design Q's launch over the other streams.  mask != NULL ([n_streams] bytes) SETS the assignment for a
+ * test (non-zero: the bit-exact kernels, for good; zero: design Q until the statistics say otherwise); mask == NULL takes in whatever statistics have arrived.
+ * *n_noisy (may be NULL) = streams the bit-exact kernels serve from the next call on; noisy_out (may be NULL, [n_streams] bytes) = which.
+ * SDRFM_NOT_SUPPORTED when the handle has no matrix-pipe kernel. */
+int sdrfm_debug_route(sdrfm_t* h, const uint8_t* mask, uint32_t* n_noisy, uint8_t* noisy_out);
 
 /* The measured read ceiling bench.py prints beside the 8 TB/s specification: a read-only LDS-DMA stream with design Q's access
  * pattern (one-wave workgroups, 12 per CU, 5 KiB in flight each, non-temporal) over nbufs device buffers of bytes_each bytes, `passes` passes

@@ -20,6 +20,7 @@
  * host.
  */
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdint>
@@ -81,7 +82,12 @@ struct CallParams {
   uint32_t dbg_tag;           // profiling build: 1 on the one launch whose wave start/end skew is recorded
   uint32_t fold_state;        // design B: the last segment's wave hands the state over (no state blocks in the grid)
   unsigned long long* dbg;    // phase-cycle accumulators (profiling build of the fast kernel only), else nullptr
+  const uint32_t* slist;      // nullptr: the launch serves streams 0 .. n_streams-1; else the i-th stream of the launch is stream slist[i] of the
+                              // handle (round 5: streams routed per stream between design Q and the bit-exact kernels; n_streams = the list's length)
 };
+
+// the handle's stream number of the launch's i-th stream
+__device__ __forceinline__ uint32_t launch_stream(const CallParams& p, uint32_t i) { return p.slist ? p.slist[i] : i; }
 
 // ---- virtual input: chunk index s in [-(T-1), N) ---------------------------------------------------------------
 __device__ __forceinline__ float2 load_x(const CallParams& p, uint32_t stream, int s) {
@@ -183,7 +189,7 @@ __global__ void __launch_bounds__(256) k_generic(CallParams p) {
   const uint32_t n_tile_blocks = p.n_streams * p.tiles_per_stream;
   if (blockIdx.x < n_tile_blocks) {
     // ------------------------------------------------------------------ audio tile
-    const uint32_t stream = blockIdx.x / p.tiles_per_stream;
+    const uint32_t stream = launch_stream(p, blockIdx.x / p.tiles_per_stream);
     const uint32_t tile = blockIdx.x % p.tiles_per_stream;
     const int j0 = (int)(tile * p.NA);
     int j1 = j0 + (int)p.NA;
@@ -233,7 +239,7 @@ __global__ void __launch_bounds__(256) k_generic(CallParams p) {
     }
   } else {
     __syncthreads();  // taps are in LDS
-    state_handover(p, blockIdx.x - n_tile_blocks, xs, NX_MAX, ys, hs);
+    state_handover(p, launch_stream(p, blockIdx.x - n_tile_blocks), xs, NX_MAX, ys, hs);
   }
 }
 
@@ -338,11 +344,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     for (uint32_t k = lane; k < (uint32_t)T; k += 64) hs[k] = p.h[k];
     __syncthreads();
     float2* ys = reinterpret_cast<float2*>(dbuf);             // Ta+1 float2 fit: checked on the host
-    state_handover(p, blockIdx.x - n_seg_blocks, reinterpret_cast<float2*>(xb), XBYTES / 8, ys, hs);
+    state_handover(p, launch_stream(p, blockIdx.x - n_seg_blocks), reinterpret_cast<float2*>(xb), XBYTES / 8, ys, hs);
     return;
   }
   const uint32_t sblk = blockIdx.x;
-  const uint32_t stream = sblk / p.tiles_per_stream;
+  const uint32_t stream = launch_stream(p, sblk / p.tiles_per_stream);
   const uint32_t seg = sblk % p.tiles_per_stream;
   const int j0 = (int)(seg * p.NA);
   int j1 = j0 + (int)p.NA;
@@ -662,10 +668,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 3)))
   if (blockIdx.x >= n_seg_blocks) {   // only launched when the state is not folded into the last segment (see below)
     for (uint32_t k = lane; k < (uint32_t)T; k += 64) hs[k] = p.h[k];
     __syncthreads();
-    state_handover(p, blockIdx.x - n_seg_blocks, reinterpret_cast<float2*>(xb), XBYTES / 8, reinterpret_cast<float2*>(dbuf), hs);
+    state_handover(p, launch_stream(p, blockIdx.x - n_seg_blocks), reinterpret_cast<float2*>(xb), XBYTES / 8, reinterpret_cast<float2*>(dbuf), hs);
     return;
   }
-  const uint32_t stream = blockIdx.x / p.tiles_per_stream;
+  const uint32_t stream = launch_stream(p, blockIdx.x / p.tiles_per_stream);
   const uint32_t seg = blockIdx.x % p.tiles_per_stream;
   const int j0 = (int)(seg * p.NA);
   int j1 = j0 + (int)p.NA;
@@ -1129,7 +1135,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 "design S ring schedule");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = (int)threadIdx.x;
-  const uint32_t stream = blockIdx.x / p.tiles_per_stream;
+  const uint32_t stream = launch_stream(p, blockIdx.x / p.tiles_per_stream);
   const int w = (int)(blockIdx.x % p.tiles_per_stream);         // wave index inside the stream
   const int segs = (int)(p.N / L);                              // lane segments of this stream in this call
   const int g0 = 63 * w - 1;                                    // segment of lane 0 (-1: before the call)
@@ -1477,7 +1483,7 @@ struct sdrfm {
   uint32_t prio_balance, fold_state_ok;   // design B knobs, fixed at create
   uint32_t end_prio;                      // design S: see CallParams
   uint32_t stream_profile;                // development build: d_dbg holds per-wave time stamps of design S
-  char kernel_name[64];
+  char kernel_name[112];
   char generic_name[64];
   char fast_name[64];
   // design Q (matrix-pipe FIR, sdrfm_q.hip): operand tables on the device, scale / offset, first K-chunk that holds taps
@@ -1494,15 +1500,26 @@ struct sdrfm {
   unsigned int* d_qstat;
   bool yprev_exact, hist_q_valid;
   // Which kernel serves a stream is also a matter of what the stream holds: noise-only input sends design Q to its repair path at
-  // almost every audio stage (3 x the time of a carrier's call; the bit-exact kernels: 1.4 x).  Every eighth wave reports its repair
-  // passes to a host-mapped word; when more than a quarter of the audio stages of a window of SDRFM_Q_ADAPT_WINDOW design-Q calls needed
-  // one, SDRFM_Q_ADAPT_BACKOFF eligible calls go to the bit-exact kernels, after which design Q is tried again.  The choice is a
-  // function of the calls made and their bytes, not of timing: windows report into two words in turn, a window is judged when the NEXT
-  // after that closes (its calls are sixteen calls old by then: the wait below does not block in practice), behind events recorded after its last calls.
-  unsigned int* q_adapt_host; unsigned int* q_adapt_dev;       // three words: window mod 3
-  hipEvent_t q_win_evt[3][3];                                  // [window mod 3][internal stream 0, 1, the handle's stream]
-  bool q_win_rec[3][3];
-  uint64_t q_stages_window, q_stages_of[3]; uint32_t q_window, q_windows_open, q_calls_in_window, q_backoff;
+  // almost every audio stage (3 x the time of a carrier's call; the bit-exact kernels: 1.4 x), and a kernel lasts as long as its slowest
+  // wave — so the choice is made PER STREAM (round 5; rounds 3 - 4: per handle).  Design Q's waves add their repair passes into a word per
+  // stream (device memory); a window of SDRFM_Q_ADAPT_WINDOW design-Q calls is read back on a side stream behind the completion events of
+  // the window's last kernels (hipExtLaunchKernelGGL stop events: no marker packets in the compute queues, no host wait anywhere: a
+  // finished read-back is noticed by hipEventQuery at a later call).  A stream more than a quarter of whose audio stages needed a repair
+  // pass is served by the bit-exact kernels for SDRFM_Q_ADAPT_BACKOFF calls (a launch of their own over the list of such streams, on an
+  // internal stream of its own beside design Q's launch over the others), then tried on design Q again.  Which kernel serves a stream at
+  // a given call therefore depends on WHEN the device's report is noticed; every choice is within the tolerance, a stream's audio is
+  // bit-identical to what its kernel gives alone, and SDRFM_CFG_BIT_EXACT pins the kernels.
+  uint32_t* rt_pass_dev[2]; uint32_t* rt_pass_host[2];         // repair passes per stream: the set the open window adds into / pinned read-back; two in turn
+  hipStream_t rt_mon;                                           // side stream of the read-backs
+  hipEvent_t rt_rb_done[2]; bool rt_rb_pending[2]; uint64_t rt_rb_stages[2];   // read-back of set i: its event; audio stages per stream its window covered
+  hipEvent_t rt_win_evt[2][3];                                  // completion events of a window's last kernels: [set][internal stream 0, 1, the handle's stream]
+  bool rt_win_need[3], rt_win_used[3], rt_win_stats;            // open window: stream holds kernels no event covers / holds kernels at all; the window counts
+  uint32_t rt_win_calls, rt_set; uint64_t rt_win_stages;
+  uint8_t* rt_noisy; uint64_t* rt_retry_at; uint32_t rt_n_noisy; uint64_t rt_calls, rt_next_retry;   // host: per stream, served by the bit-exact kernels until call rt_retry_at
+  uint32_t* rt_list_dev[2]; uint32_t* rt_list_host[2]; int rt_list_cur; bool rt_dirty;   // stream lists: the clean streams first, then the noisy ones
+  hipEvent_t rt_applied; bool rt_applied_pending;               // a new list version is in place (recorded on the handle's stream)
+  hipStream_t rt_bx; hipEvent_t rt_bx_done, rt_bx_fork, rt_bx_evt[2]; uint32_t rt_bx_slot; bool rt_bx_pending;   // the bit-exact sub-launches: a stream of their own (in order: each takes the state the one before left)
+  bool rt_off;                                                  // (development: design Q whatever the streams hold)
   // SDRFM_F_OVERLAP: two internal streams taken in turn, so that consecutive calls run concurrently on the device (a call's ramp-up
   // under the previous call's tail).  ovl_in orders a call behind what the handle's stream holds when it is made; join_overlap()
   // records ovl_done[k] behind the calls put on internal stream k and makes the handle's stream wait for it.
@@ -1521,6 +1538,9 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
 #define SDRFM_Q_ADAPT_WINDOW 8u      /* design-Q calls between two looks at the sampled repair statistics */
 #define SDRFM_Q_ADAPT_BACKOFF 1024u  /* eligible calls served by the bit-exact kernels after a window of noise-like input */
 static int join_overlap(sdrfm* h);
+static int route_create(sdrfm* h);
+static int route_reset(sdrfm* h);
+static int route_apply(sdrfm* h);
 
 #define HIP_TRY(expr, code)                                                                          \
   do {                                                                                               \
@@ -1530,6 +1550,75 @@ static int join_overlap(sdrfm* h);
       return (code);                                                                                 \
     }                                                                                                \
   } while (0)
+
+// ---- per-stream routing between design Q and the bit-exact kernels (the handle's comment has the scheme) ------------------------------
+static int route_create(sdrfm* h) {
+  const size_t ns = h->cfg.n_streams;
+  h->rt_noisy = static_cast<uint8_t*>(calloc(ns, 1));
+  h->rt_retry_at = static_cast<uint64_t*>(calloc(ns, sizeof(uint64_t)));
+  if (!h->rt_noisy || !h->rt_retry_at) return SDRFM_ENOMEM;
+  for (int i = 0; i < 2; ++i) {
+    HIP_TRY(hipMalloc(&h->rt_pass_dev[i], ns * sizeof(uint32_t)), SDRFM_ENOMEM);
+    HIP_TRY(hipMemset(h->rt_pass_dev[i], 0, ns * sizeof(uint32_t)), SDRFM_FAIL);
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->rt_pass_host[i]), ns * sizeof(uint32_t), hipHostMallocDefault), SDRFM_ENOMEM);
+    HIP_TRY(hipMalloc(&h->rt_list_dev[i], ns * sizeof(uint32_t)), SDRFM_ENOMEM);
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->rt_list_host[i]), ns * sizeof(uint32_t), hipHostMallocDefault), SDRFM_ENOMEM);
+    HIP_TRY(hipEventCreateWithFlags(&h->rt_rb_done[i], hipEventDisableTiming), SDRFM_ENOMEM);
+    for (int k = 0; k < 3; ++k) HIP_TRY(hipEventCreateWithFlags(&h->rt_win_evt[i][k], hipEventDisableTiming), SDRFM_ENOMEM);
+  }
+  HIP_TRY(hipEventCreateWithFlags(&h->rt_applied, hipEventDisableTiming), SDRFM_ENOMEM);
+  HIP_TRY(hipEventCreateWithFlags(&h->rt_bx_done, hipEventDisableTiming), SDRFM_ENOMEM);
+  HIP_TRY(hipEventCreateWithFlags(&h->rt_bx_fork, hipEventDisableTiming), SDRFM_ENOMEM);
+  for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreateWithFlags(&h->rt_bx_evt[i], hipEventDisableTiming), SDRFM_ENOMEM);
+  HIP_TRY(hipStreamCreateWithFlags(&h->rt_mon, hipStreamNonBlocking), SDRFM_ENOMEM);
+  HIP_TRY(hipStreamCreateWithFlags(&h->rt_bx, hipStreamNonBlocking), SDRFM_ENOMEM);
+  h->rt_next_retry = ~0ull;
+  return SDRFM_OK;
+}
+
+// Everything the device may still hold for this handle has been synchronised by the caller (sdrfm_reset): every stream back on design Q.
+static int route_reset(sdrfm* h) {
+  if (!h->rt_noisy) return SDRFM_OK;
+  const size_t ns = h->cfg.n_streams;
+  if (h->rt_bx) HIP_TRY(hipStreamSynchronize(h->rt_bx), SDRFM_FAIL);
+  if (h->rt_mon) HIP_TRY(hipStreamSynchronize(h->rt_mon), SDRFM_FAIL);
+  for (int k = 0; k < 2; ++k)
+    if (h->ovl_stream[k]) HIP_TRY(hipStreamSynchronize(h->ovl_stream[k]), SDRFM_FAIL);
+  for (int i = 0; i < 2; ++i) {
+    HIP_TRY(hipMemset(h->rt_pass_dev[i], 0, ns * sizeof(uint32_t)), SDRFM_FAIL);
+    h->rt_rb_pending[i] = false;
+  }
+  memset(h->rt_noisy, 0, ns);
+  h->rt_n_noisy = 0; h->rt_next_retry = ~0ull; h->rt_dirty = false; h->rt_applied_pending = false; h->rt_bx_pending = false; h->rt_calls = 0;
+  h->rt_win_calls = 0; h->rt_win_stages = 0; h->rt_win_stats = false;
+  for (int k = 0; k < 3; ++k) { h->rt_win_need[k] = false; h->rt_win_used[k] = false; }
+  return SDRFM_OK;
+}
+
+// Read-backs that have finished: a stream more than a quarter of whose audio stages needed a repair pass leaves design Q for a while.
+static void route_poll(sdrfm* h) {
+  for (int i = 0; i < 2; ++i) {
+    if (!h->rt_rb_pending[i] || hipEventQuery(h->rt_rb_done[i]) != hipSuccess) continue;
+    h->rt_rb_pending[i] = false;
+    const uint32_t* pass = h->rt_pass_host[i];
+    for (uint32_t s = 0; s < h->cfg.n_streams; ++s)
+      if (!h->rt_noisy[s] && (uint64_t)pass[s] * 4u > h->rt_rb_stages[i]) {
+        h->rt_noisy[s] = 1;
+        h->rt_retry_at[s] = h->rt_calls + SDRFM_Q_ADAPT_BACKOFF;
+        if (h->rt_retry_at[s] < h->rt_next_retry) h->rt_next_retry = h->rt_retry_at[s];
+        h->rt_dirty = true;
+      }
+  }
+  (void)hipGetLastError();                                       // (hipErrorNotReady of a pending query is not an error)
+  if (h->rt_calls >= h->rt_next_retry) {                         // streams whose time on the bit-exact kernels is over: design Q is tried again
+    h->rt_next_retry = ~0ull;
+    for (uint32_t s = 0; s < h->cfg.n_streams; ++s) {
+      if (!h->rt_noisy[s]) continue;
+      if (h->rt_retry_at[s] <= h->rt_calls) { h->rt_noisy[s] = 0; h->rt_dirty = true; }
+      else if (h->rt_retry_at[s] < h->rt_next_retry) h->rt_next_retry = h->rt_retry_at[s];
+    }
+  }
+}
 
 static uint32_t max_audio_for(const sdrfm_config& c, uint32_t nbytes) {
   const uint64_t n = nbytes / 2;
@@ -1542,6 +1631,8 @@ static void free_handle(sdrfm* h) {
   (void)hipSetDevice(h->device);
   for (int k = 0; k < 2; ++k)
     if (h->ovl_stream[k]) (void)hipStreamSynchronize(h->ovl_stream[k]);     // overlapped calls still use the buffers freed below
+  if (h->rt_bx) (void)hipStreamSynchronize(h->rt_bx);
+  if (h->rt_mon) (void)hipStreamSynchronize(h->rt_mon);
   if (h->d_h) (void)hipFree(h->d_h);
   if (h->d_g) (void)hipFree(h->d_g);
   for (int i = 0; i < 2; ++i) {
@@ -1557,9 +1648,24 @@ static void free_handle(sdrfm* h) {
   if (h->d_dbg) (void)hipFree(h->d_dbg);
   if (h->d_qA) (void)hipFree(h->d_qA);
   if (h->d_hpad) (void)hipFree(h->d_hpad);
-  if (h->q_adapt_host) (void)hipHostFree(h->q_adapt_host);
-  for (int k = 0; k < 9; ++k)
-    if (h->q_win_evt[k / 3][k % 3]) (void)hipEventDestroy(h->q_win_evt[k / 3][k % 3]);
+  for (int i = 0; i < 2; ++i) {
+    if (h->rt_pass_dev[i]) (void)hipFree(h->rt_pass_dev[i]);
+    if (h->rt_pass_host[i]) (void)hipHostFree(h->rt_pass_host[i]);
+    if (h->rt_list_dev[i]) (void)hipFree(h->rt_list_dev[i]);
+    if (h->rt_list_host[i]) (void)hipHostFree(h->rt_list_host[i]);
+    if (h->rt_rb_done[i]) (void)hipEventDestroy(h->rt_rb_done[i]);
+    for (int k = 0; k < 3; ++k)
+      if (h->rt_win_evt[i][k]) (void)hipEventDestroy(h->rt_win_evt[i][k]);
+  }
+  if (h->rt_applied) (void)hipEventDestroy(h->rt_applied);
+  if (h->rt_bx_done) (void)hipEventDestroy(h->rt_bx_done);
+  if (h->rt_bx_fork) (void)hipEventDestroy(h->rt_bx_fork);
+  for (int i = 0; i < 2; ++i)
+    if (h->rt_bx_evt[i]) (void)hipEventDestroy(h->rt_bx_evt[i]);
+  if (h->rt_mon) (void)hipStreamDestroy(h->rt_mon);
+  if (h->rt_bx) (void)hipStreamDestroy(h->rt_bx);
+  free(h->rt_noisy);
+  free(h->rt_retry_at);
   if (h->d_qstat) (void)hipFree(h->d_qstat);
   for (int i = 0; i < 2; ++i)
     if (h->d_hist_q[i]) (void)hipFree(h->d_hist_q[i]);
@@ -1749,9 +1855,7 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
           hipMalloc(&h->d_hpad, sizeof(hpad)) == hipSuccess && hipMemcpy(h->d_hpad, hpad, sizeof(hpad), hipMemcpyHostToDevice) == hipSuccess &&
           hipMalloc(&h->d_hist_q[0], 2 * SDRFM_Q_TP * ns) == hipSuccess && hipMalloc(&h->d_hist_q[1], 2 * SDRFM_Q_TP * ns) == hipSuccess &&
           hipMalloc(&h->d_qstat, 2 * sizeof(unsigned int)) == hipSuccess && hipMemset(h->d_qstat, 0, 2 * sizeof(unsigned int)) == hipSuccess &&
-          hipHostMalloc(reinterpret_cast<void**>(&h->q_adapt_host), 64, hipHostMallocMapped) == hipSuccess &&
-          hipHostGetDevicePointer(reinterpret_cast<void**>(&h->q_adapt_dev), h->q_adapt_host, 0) == hipSuccess) {
-        memset(h->q_adapt_host, 0, 64);
+          route_create(h) == SDRFM_OK) {
         h->q_scale = qs; h->q_cst = qc; h->q_c0 = c0 > 1 ? 1 : c0;
         h->q_guard_r = q_R; h->q_guard_a = q_A;
         h->q_nslot = sdrfm_q_default_nslot(cfg->fir_decim); h->q_waves_per_cu = 12;
@@ -1762,7 +1866,7 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
         if (const char* e = getenv("SDRFM_Q_GUARD_R")) h->q_guard_r = (float)atof(e);            // 0 and 4: the guard never fires (timing / soak experiments)
         if (const char* e = getenv("SDRFM_Q_GUARD_A")) h->q_guard_a = (float)atof(e);
         if (getenv("SDRFM_NO_Q")) { (void)hipFree(h->d_qA); h->d_qA = nullptr; }
-        if (getenv("SDRFM_Q_NO_ADAPT")) h->q_adapt_dev = nullptr;                                 // design Q whatever the stream holds (timing experiments)
+        if (getenv("SDRFM_Q_NO_ADAPT")) h->rt_off = true;                                         // design Q whatever the streams hold (timing experiments)
 #endif
         h->n_cu = (uint32_t)prop.multiProcessorCount;
         snprintf(h->fast_q_name, sizeof(h->fast_q_name), "fast-q T%u D%u Ta%u Da%u %s", cfg->fir_taps, cfg->fir_decim, cfg->audio_taps,
@@ -1845,9 +1949,8 @@ int sdrfm_reset(sdrfm_t* h) {
   }
   h->yprev_exact = true;                                          // y[-1] = 0, as the definition has it
   h->hist_q_valid = false;
-  h->q_backoff = 0; h->q_calls_in_window = 0; h->q_stages_window = 0; h->q_windows_open = 0;
-  if (h->q_adapt_host) { h->q_adapt_host[0] = 0; h->q_adapt_host[1] = 0; h->q_adapt_host[2] = 0; }   // (everything is synchronised above: no writer is left)
   HIP_TRY(hipStreamSynchronize(h->stream), SDRFM_FAIL);
+  { const int rrc = route_reset(h); if (rrc != SDRFM_OK) return rrc; }   // (behind the synchronisation: no kernel is left that could add to the statistics)
   h->cur = 0;
   h->phase_x = h->phase_d = 0;
   h->n_seen = 0;
@@ -1871,6 +1974,41 @@ static int join_overlap(sdrfm* h) {
       HIP_TRY(hipStreamWaitEvent(h->stream, h->ovl_done[k], 0), SDRFM_FAIL);
       h->ovl_pending[k] = false;
     }
+  if (h->rt_bx_pending) {                                        // the noisy streams' launches of the overlapped calls (one internal stream, in order)
+    HIP_TRY(hipEventRecord(h->rt_bx_done, h->rt_bx), SDRFM_FAIL);
+    HIP_TRY(hipStreamWaitEvent(h->stream, h->rt_bx_done, 0), SDRFM_FAIL);
+    h->rt_bx_pending = false;
+  }
+  return SDRFM_OK;
+}
+
+// A new assignment of streams to kernels: the list [clean streams | noisy streams] goes to the other version's buffers, and the state
+// every stream carries is made the same for both kinds of kernel first (y[-1] of the streams design Q served last becomes the
+// definition's, the raw-sample history design Q's repair path reads is refreshed for all) — behind everything issued so far, ahead of
+// everything issued from here on, by events alone (no host wait).
+static int route_apply(sdrfm* h) {
+  const sdrfm_config& c = h->cfg;
+  const uint32_t ns = c.n_streams;
+  { const int jrc = join_overlap(h); if (jrc != SDRFM_OK) return jrc; }
+  const int v = h->rt_list_cur ^ 1;
+  uint32_t* L = h->rt_list_host[v];
+  uint32_t nc = 0, nn = 0;
+  for (uint32_t s = 0; s < ns; ++s) if (!h->rt_noisy[s]) L[nc++] = s;
+  for (uint32_t s = 0; s < ns; ++s) if (h->rt_noisy[s]) L[nc + nn++] = s;
+  if (!h->yprev_exact && h->hist_q_valid)                        // (design Q served ns - rt_n_noisy streams at the previous call: the clean part of the list in use)
+    HIP_TRY(sdrfm_q_fix_yprev(h->d_hist_q[h->cur], h->d_hpad, h->d_yprev[h->cur], ns - h->rt_n_noisy, h->rt_n_noisy ? h->rt_list_dev[h->rt_list_cur] : nullptr,
+                              h->stream), SDRFM_FAIL);
+  if (c.fir_taps > 1)
+    HIP_TRY(hipMemcpy2DAsync(h->d_hist_q[h->cur] + 2 * (SDRFM_Q_TP - (c.fir_taps - 1)), 2 * SDRFM_Q_TP, h->d_hist_b[h->cur], 2 * (size_t)(c.fir_taps - 1),
+                             2 * (size_t)(c.fir_taps - 1), ns, hipMemcpyDeviceToDevice, h->stream), SDRFM_FAIL);
+  h->yprev_exact = true; h->hist_q_valid = true;
+  HIP_TRY(hipMemcpyAsync(h->rt_list_dev[v], L, (size_t)ns * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream), SDRFM_FAIL);
+  HIP_TRY(hipEventRecord(h->rt_applied, h->stream), SDRFM_FAIL);
+  h->rt_applied_pending = true;
+  for (int k = 0; k < 2; ++k)
+    if (h->ovl_stream[k]) HIP_TRY(hipStreamWaitEvent(h->ovl_stream[k], h->rt_applied, 0), SDRFM_FAIL);
+  HIP_TRY(hipStreamWaitEvent(h->rt_bx, h->rt_applied, 0), SDRFM_FAIL);
+  h->rt_list_cur = v; h->rt_n_noisy = nn; h->rt_dirty = false;
   return SDRFM_OK;
 }
 
@@ -1970,13 +2108,6 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
   const bool short_first = h->fast && h->fast->kind == 'b' && h->n_seen + 1 < c.fir_taps && M < y_aff + c.audio_taps;
   const bool fast_ok = h->fast && A > 0 && (h->phase_x % 2 == 0) && ((uintptr_t)d_iq % 4 == 0) && (iq_stride % 4 == 0) &&
                        N < (1u << 30) && !short_first;
-  const bool stream_ok = fast_ok && h->fast_s && h->phase_x == 0 && h->phase_d == 0 && (N % h->fast_s->seg) == 0 &&
-                         (M % c.audio_decim) == 0 && M >= c.audio_taps && ((uintptr_t)d_iq % 16 == 0) && (iq_stride % 16 == 0) &&
-                         h->fold_state_ok &&
-                         // a lane-segment wave is long (its 64 lanes walk 480 samples each, ~25 us alone on a SIMD): design S pays when
-                         // the call fills the machine (>= one wave per SIMD); a single dongle's call is served faster by design B,
-                         // which cuts its segments as short as the call needs
-                         (uint64_t)c.n_streams * ((N / h->fast_s->seg + 62) / 63) >= 4ull * h->n_cu;
   // Design Q serves whole numbers of audio periods at decimator phase 0 on 16-byte aligned rows, when the call holds enough steps
   // (128 outputs each) to put at least two waves on every CU; the first call after a reset must be long enough that the state it
   // hands over holds no output computed from the (inexpressible in bytes) zero history.  It also serves one dongle's second of IQ
@@ -1986,8 +2117,21 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
                     ((uintptr_t)d_iq % 16 == 0) && (iq_stride % 16 == 0) && N < (1u << 30) && M >= c.audio_taps &&
                     (h->n_seen + 1 >= c.fir_taps || M >= y_aff + c.audio_taps) &&
                     (uint64_t)c.n_streams * q_steps >= 2ull * h->n_cu;
-  const bool q_ok = q_fit && h->q_backoff == 0;
-  if (q_fit && h->q_backoff) --h->q_backoff;
+  // ---- which streams design Q serves at this call (the handle's comment: per-stream routing) -----------------------------------------------
+  const uint32_t ns_all = c.n_streams;
+  if (q_fit && h->rt_noisy && !h->rt_off) {
+    route_poll(h);
+    if (h->rt_dirty && !(h->rt_applied_pending && hipEventQuery(h->rt_applied) != hipSuccess)) {
+      const int arc = route_apply(h);
+      if (arc != SDRFM_OK) return arc;
+    }
+    (void)hipGetLastError();
+  }
+  const uint32_t n_noisy = (q_fit && h->rt_noisy) ? h->rt_n_noisy : 0u, n_clean = ns_all - n_noisy;
+  const bool q_ok = q_fit && n_clean > 0;                        // design Q serves n_clean streams (all of them when no stream is noisy)
+  const bool bx_all = !q_ok;                                     // the bit-exact kernels serve every stream, on the handle's stream (as every call design Q cannot take)
+  const bool mixed = q_ok && n_noisy > 0;                        // ... or the noisy ones beside design Q, on their own internal stream
+  ++h->rt_calls;
   // SDRFM_F_OVERLAP: the call goes to one of two internal streams and warms every stream up from the previous call's buffer instead
   // of reading the carried state, so that it depends on nothing the previous call computes (the state sets are still written, for
   // whatever call comes next without the flag).  Any other call first orders the handle's stream behind the overlapped ones.
@@ -2001,18 +2145,22 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
                                                        h->prev_ovl_audio_n * sizeof(float), reinterpret_cast<const uint8_t*>(d_audio),
                                                        audio_stride * sizeof(float), (size_t)A * sizeof(float), c.n_streams));
   if (!ovl) { const int jrc = join_overlap(h); if (jrc != SDRFM_OK) return jrc; }
-  if (!q_ok) {
+  if (bx_all) {
     // A bit-exact kernel takes over from design Q: the y[-1] it is handed must be the definition's (design Q's own is within 1e-4 of it,
     // which a small |y| would turn into a wrong d[0]): recomputed from the 64 raw samples design Q left.
     if (!h->yprev_exact && h->hist_q_valid)
-      HIP_TRY(sdrfm_q_fix_yprev(h->d_hist_q[h->cur], h->d_hpad, h->d_yprev[h->cur], c.n_streams, h->stream), SDRFM_FAIL);
+      HIP_TRY(sdrfm_q_fix_yprev(h->d_hist_q[h->cur], h->d_hpad, h->d_yprev[h->cur], c.n_streams, nullptr, h->stream), SDRFM_FAIL);
     h->yprev_exact = true; h->hist_q_valid = false;
     h->prev_ovl_audio = nullptr;
   }
+  p.slist = nullptr;
+  const uint32_t* list_dev = (h->rt_noisy && n_noisy) ? h->rt_list_dev[h->rt_list_cur] : nullptr;   // [clean streams][noisy streams]
+  char q_name[sizeof(h->kernel_name)] = "";
+  bool halo_bytes = q_ok;                                        // a kernel that reads its halo as bytes served (some of) the call
   if (q_ok) {
     SdrfmQParams q;
     hipStream_t qs = h->stream;
-    uint32_t k = 0;
+    uint32_t k = 2;                                               // stream slot of this launch: internal stream 0 / 1, or 2 = the handle's stream
     q.iq_prev = nullptr; q.iq_prev_stride = 0; q.N_prev = 0;
     if (ovl) {
       if (!h->ovl_done[1]) {                                      // (created piece by piece: a failure half-way leaves nothing half-used)
@@ -2035,6 +2183,7 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
         (void)hipGetLastError();
         HIP_TRY(hipEventRecord(h->ovl_in, h->stream), SDRFM_FAIL);
         HIP_TRY(hipStreamWaitEvent(qs, h->ovl_in, 0), SDRFM_FAIL);
+        if (mixed) HIP_TRY(hipStreamWaitEvent(h->rt_bx, h->ovl_in, 0), SDRFM_FAIL);
       }
       q.iq_prev = h->prev_iq; q.iq_prev_stride = h->prev_stride; q.N_prev = h->prev_nbytes / 2;
     }
@@ -2042,7 +2191,8 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
     q.yprev_in = p.yprev_in; q.yprev_out = p.yprev_out; q.hist_d_in = p.hist_d_in; q.hist_d_out = p.hist_d_out;
     q.hist_b_in = p.hist_b_in; q.hist_b_out = p.hist_b_out; q.hist_x_out = p.hist_x_out;
     q.A = h->d_qA; q.g = h->d_g; q.q0 = h->q_scale; q.q2 = 65536.0f * h->q_scale; q.cst = h->q_cst;
-    q.T = c.fir_taps; q.N = N; q.M = M; q.A_out = A; q.steps_total = q_steps; q.n_streams = c.n_streams; q.dbg = nullptr; q.prio_by_age = ovl ? 0u : 1u;
+    q.T = c.fir_taps; q.N = N; q.M = M; q.A_out = A; q.steps_total = q_steps; q.n_streams = n_clean; q.dbg = nullptr; q.prio_by_age = ovl ? 0u : 1u;
+    q.slist = list_dev;                                           // (its first n_clean entries)
     // the guard's repair path reads the last 64 raw samples before the call: left by the previous design-Q call, or taken now from the
     // T - 1 the other kernels keep (the 64th, which only y[-1] needs, is then not there — nor needed: their y[-1] is the definition's)
     if (!h->hist_q_valid && !ovl && c.fir_taps > 1)
@@ -2050,94 +2200,127 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
                                2 * (size_t)(c.fir_taps - 1), c.n_streams, hipMemcpyDeviceToDevice, h->stream), SDRFM_FAIL);
     q.hpad = h->d_hpad; q.hist_q_in = h->d_hist_q[h->cur]; q.hist_q_out = h->d_hist_q[h->cur ^ 1];
     q.guard_r = h->q_guard_r; q.guard_a = h->q_guard_a; q.yprev_exact = h->yprev_exact ? 1u : 0u; q.n_repaired = h->d_qstat;
-    q.n_adapt = h->q_adapt_dev ? h->q_adapt_dev + (h->q_window % 3u) : nullptr;
-    // runs (waves) per stream: fill the machine once; every run at least four owned steps (a run that does not start its stream
-    // recomputes one step), two when the call is too small to fill the machine otherwise
-    uint32_t runs = (h->q_waves_per_cu * h->n_cu) / c.n_streams;
-    const uint32_t min_steps = ((uint64_t)c.n_streams * (q_steps / 4) >= (uint64_t)h->q_waves_per_cu * h->n_cu / 2) ? 4u : 2u;
+    // runs (waves) per stream: fill the machine once; every run at least four owned steps (a run warms up over a quarter of a step), two
+    // when the call is too small to fill the machine otherwise
+    uint32_t runs = (h->q_waves_per_cu * h->n_cu) / n_clean;
+    const uint32_t min_steps = ((uint64_t)n_clean * (q_steps / 4) >= (uint64_t)h->q_waves_per_cu * h->n_cu / 2) ? 4u : 2u;
     if (runs > q_steps / min_steps) runs = q_steps / min_steps;
     if (runs < 1) runs = 1;
     q.runs = runs;
-    HIP_TRY(sdrfm_q_launch(q, h->q_c0, h->q_nslot, c.fir_decim, c.audio_decim, qs), SDRFM_FAIL);
+    // the window of per-stream repair statistics this call adds to (none while the set's previous read-back is still under way), and
+    // whether its kernel's completion carries one of the window's events (the window's last two calls: both internal streams are covered)
+    hipEvent_t done = nullptr;
+    q.stream_pass = nullptr;
+    if (h->rt_noisy && !h->rt_off) {
+      if (h->rt_win_calls == 0) h->rt_win_stats = !h->rt_rb_pending[h->rt_set];
+      if (h->rt_win_stats) {
+        q.stream_pass = h->rt_pass_dev[h->rt_set];
+        h->rt_win_used[k] = true;
+        if (h->rt_win_calls + 2 >= SDRFM_Q_ADAPT_WINDOW) { done = h->rt_win_evt[h->rt_set][k]; h->rt_win_need[k] = false; }
+        else h->rt_win_need[k] = true;
+      }
+    }
+    HIP_TRY(sdrfm_q_launch(q, h->q_c0, h->q_nslot, c.fir_decim, c.audio_decim, qs, done), SDRFM_FAIL);
     if (ovl) h->ovl_pending[k] = true;
     h->prev_ovl_audio = ovl ? d_audio : nullptr; h->prev_ovl_audio_stride = audio_stride; h->prev_ovl_audio_n = A;
     h->yprev_exact = false; h->hist_q_valid = true;
-    // the stream's content decides too (see the handle): sampled repair passes against sampled audio stages over the last window of calls
-    // (the word lags by the calls still in flight: the ratio errs on design Q's side)
-    // the stream's content decides too (see the handle): sampled repair passes against sampled audio stages, window by window
-    h->q_stages_window += ((uint64_t)c.n_streams * runs * ((q_steps / runs + c.audio_decim - 1) / c.audio_decim) + SDRFM_Q_ADAPT_SAMPLE - 1) / SDRFM_Q_ADAPT_SAMPLE;
-    if (h->q_adapt_dev && ++h->q_calls_in_window >= SDRFM_Q_ADAPT_WINDOW) {
-      const uint32_t w = h->q_window % 3u;
-      // behind this window's calls, on every stream they may have been put on
-      hipStream_t wst[3] = {h->ovl_stream[0], h->ovl_stream[1], h->stream};
-      for (int k = 0; k < 3; ++k) {
-        h->q_win_rec[w][k] = false;
-        if (!wst[k] || (k < 2 && !h->ovl_pending[k] && wst[k] != qs)) continue;
-        if (!h->q_win_evt[w][k]) HIP_TRY(hipEventCreateWithFlags(&h->q_win_evt[w][k], hipEventDisableTiming), SDRFM_ENOMEM);
-        HIP_TRY(hipEventRecord(h->q_win_evt[w][k], wst[k]), SDRFM_FAIL);
-        h->q_win_rec[w][k] = true;
-      }
-      h->q_stages_of[w] = h->q_stages_window;
-      auto wait_window = [&](uint32_t ww) -> hipError_t {
-        for (int k = 0; k < 3; ++k)
-          if (h->q_win_rec[ww][k]) { const hipError_t e = hipEventSynchronize(h->q_win_evt[ww][k]); if (e != hipSuccess) return e; }
-        return hipSuccess;
-      };
-      if (h->q_windows_open >= 2) {                                                   // judge the window before the last one
-        const uint32_t j = (w + 1u) % 3u;
-        HIP_TRY(wait_window(j), SDRFM_FAIL);
-        const uint32_t passes = *reinterpret_cast<volatile unsigned int*>(h->q_adapt_host + j);
-        h->q_adapt_host[j] = 0;                                                       // (the next window reports here)
-        if ((uint64_t)passes * 4u > h->q_stages_of[j]) {
-          // ... the two windows since are in flight still: let them finish before their words are cleared for the windows after the pause
-          HIP_TRY(wait_window((w + 2u) % 3u), SDRFM_FAIL);
-          HIP_TRY(wait_window(w), SDRFM_FAIL);
-          h->q_adapt_host[0] = 0; h->q_adapt_host[1] = 0; h->q_adapt_host[2] = 0;
-          h->q_backoff = SDRFM_Q_ADAPT_BACKOFF;
+    if (h->rt_noisy && !h->rt_off && h->rt_win_stats) {
+      h->rt_win_stages += (uint64_t)runs * ((q_steps / runs + c.audio_decim - 1) / c.audio_decim);   // audio stages of ONE stream's waves in this call
+      if (++h->rt_win_calls >= SDRFM_Q_ADAPT_WINDOW) {
+        // the window closes: read its statistics back behind its last kernels, on the side stream (nothing here waits, no packet enters a compute queue
+        // unless a stream holds kernels of the window that none of the attached events covers — call patterns other than "all on one stream" or "two in turn")
+        hipStream_t wst[3] = {h->ovl_stream[0], h->ovl_stream[1], h->stream};
+        const uint32_t i = h->rt_set;
+        for (int kk = 0; kk < 3; ++kk) {
+          if (!h->rt_win_used[kk]) continue;
+          if (h->rt_win_need[kk]) HIP_TRY(hipEventRecord(h->rt_win_evt[i][kk], wst[kk]), SDRFM_FAIL);
+          HIP_TRY(hipStreamWaitEvent(h->rt_mon, h->rt_win_evt[i][kk], 0), SDRFM_FAIL);
+          h->rt_win_used[kk] = false; h->rt_win_need[kk] = false;
         }
+        HIP_TRY(hipMemcpyAsync(h->rt_pass_host[i], h->rt_pass_dev[i], (size_t)ns_all * sizeof(uint32_t), hipMemcpyDeviceToHost, h->rt_mon), SDRFM_FAIL);
+        HIP_TRY(hipMemsetAsync(h->rt_pass_dev[i], 0, (size_t)ns_all * sizeof(uint32_t), h->rt_mon), SDRFM_FAIL);
+        HIP_TRY(hipEventRecord(h->rt_rb_done[i], h->rt_mon), SDRFM_FAIL);
+        h->rt_rb_pending[i] = true; h->rt_rb_stages[i] = h->rt_win_stages;
+        h->rt_set ^= 1u; h->rt_win_calls = 0; h->rt_win_stages = 0;
       }
-      h->q_windows_open = h->q_backoff ? 0u : (h->q_windows_open < 2 ? h->q_windows_open + 1 : 2);
-      h->q_stages_window = 0; h->q_calls_in_window = 0; ++h->q_window;
     }
-    snprintf(h->kernel_name, sizeof(h->kernel_name), "%s%s", h->fast_q_name, ovl ? " overlapped" : "");
-  } else if (stream_ok) {
-    const uint32_t segs = N / h->fast_s->seg;
-    p.tiles_per_stream = (segs + 62) / 63;                      // waves per stream: 63 useful lane segments each
-    p.fold_state = 1;
-    hipLaunchKernelGGL(h->fast_s->kernel[0], dim3(c.n_streams * p.tiles_per_stream), dim3(64), h->fast_s->xbytes, h->stream, p);
-    snprintf(h->kernel_name, sizeof(h->kernel_name), "%s", h->fast_s_name);
-  } else if (fast_ok) {
-    // split every stream into segments so that ~waves_target waves are resident; each segment >= min_subtiles sub-tiles
-    const uint32_t NYT = 64 * h->fast->R;
-    const uint32_t sub_total = (M + NYT - 1) / NYT;
-    uint32_t segs = h->waves_target / c.n_streams;
-    // a segment pays a fixed prologue, so it normally covers >= min_subtiles sub-tiles; when that would leave most of the
-    // GPU without a wave (few streams: the reference's one dongle), shorter segments win: one stream x 1 s runs in 9.6 us
-    // with single-sub-tile segments against 18.8 us with four
-    uint32_t ms = h->min_subtiles;
-    while (ms > 1 && (uint64_t)c.n_streams * (sub_total / ms) < h->waves_target / 2) ms >>= 1;
-    const uint32_t seg_cap = sub_total / ms;
-    if (segs > seg_cap) segs = seg_cap;
-    if (segs < 1) segs = 1;
-    p.NA = (A + segs - 1) / segs;
-    p.tiles_per_stream = (A + p.NA - 1) / p.NA;
-    uint32_t grid = c.n_streams * p.tiles_per_stream + c.n_streams;
-    // design B: state hand-over folded into the last segment's wave (needs M >= Ta so that the d ring alone holds the
-    // new history, and the last sub-tile must contain y[M-1], which the kernel arranges)
-    p.fold_state = (h->fast->kind == 'b' && M >= c.audio_taps && h->fold_state_ok) ? 1u : 0u;
-    if (p.fold_state) grid -= c.n_streams;
-    hipLaunchKernelGGL(h->fast->kernel[h->fast_mode], dim3(grid), dim3(64), h->fast_lds, h->stream, p);
-    snprintf(h->kernel_name, sizeof(h->kernel_name), "%s", h->fast_name);
-  } else {
-    p.NA = h->NA;
-    p.tiles_per_stream = (A + h->NA - 1) / h->NA;
-    const uint32_t grid = c.n_streams * p.tiles_per_stream + c.n_streams;
-    hipLaunchKernelGGL(k_generic, dim3(grid), dim3(256), h->lds_bytes, h->stream, p);
-    snprintf(h->kernel_name, sizeof(h->kernel_name), "%s", h->generic_name);
+    snprintf(q_name, sizeof(q_name), "%s%s", h->fast_q_name, ovl ? " overlapped" : "");
   }
-  if ((q_ok || stream_ok || (fast_ok && h->fast->kind == 'b')) && h->n_seen + 1 < c.fir_taps) {
-    // Designs B and S read their halo as bytes, which cannot express the zero history at the start of a stream: the few audio
-    // outputs that depend on inputs before the first real sample are recomputed by the generic kernel (tile 0..k only).
+  if (bx_all || mixed) {
+    // ---- the bit-exact kernels: every stream (on the handle's stream), or the noisy streams beside design Q's launch: on their own internal stream, in
+    // order among themselves (each takes the state the previous one left); a call made without SDRFM_F_OVERLAP forks that stream off the handle's stream
+    // and joins it again, so that the handle's stream is behind both launches when the call returns
+    const uint32_t nsub = bx_all ? ns_all : n_noisy;
+    hipStream_t bs = h->stream;
+    hipEvent_t bdone = nullptr;                                   // mixed: the launch's own completion event (a stop event: no marker packet)
+    if (mixed) {
+      bs = h->rt_bx;
+      bdone = h->rt_bx_evt[h->rt_bx_slot]; h->rt_bx_slot ^= 1u;
+      p.slist = list_dev + n_clean;
+      if (!ovl) {
+        HIP_TRY(hipEventRecord(h->rt_bx_fork, h->stream), SDRFM_FAIL);
+        HIP_TRY(hipStreamWaitEvent(bs, h->rt_bx_fork, 0), SDRFM_FAIL);
+      }
+    }
+    p.n_streams = nsub;
+    const bool stream_ok = fast_ok && h->fast_s && h->phase_x == 0 && h->phase_d == 0 && (N % h->fast_s->seg) == 0 &&
+                           (M % c.audio_decim) == 0 && M >= c.audio_taps && ((uintptr_t)d_iq % 16 == 0) && (iq_stride % 16 == 0) &&
+                           h->fold_state_ok &&
+                           // a lane-segment wave is long (its 64 lanes walk 480 samples each, ~25 us alone on a SIMD): design S pays when
+                           // the launch fills the machine (>= one wave per SIMD); a single dongle's call is served faster by design B,
+                           // which cuts its segments as short as the call needs
+                           (uint64_t)nsub * ((N / h->fast_s->seg + 62) / 63) >= 4ull * h->n_cu;
+    const char* bname = h->generic_name;
+    if (stream_ok) {
+      const uint32_t segs = N / h->fast_s->seg;
+      p.tiles_per_stream = (segs + 62) / 63;                      // waves per stream: 63 useful lane segments each
+      p.fold_state = 1;
+      hipExtLaunchKernelGGL(h->fast_s->kernel[0], dim3(nsub * p.tiles_per_stream), dim3(64), h->fast_s->xbytes, bs, nullptr, bdone, 0, p);
+      bname = h->fast_s_name; halo_bytes = true;
+    } else if (fast_ok) {
+      // split every stream into segments so that ~waves_target waves are resident; each segment >= min_subtiles sub-tiles
+      const uint32_t NYT = 64 * h->fast->R;
+      const uint32_t sub_total = (M + NYT - 1) / NYT;
+      uint32_t segs = h->waves_target / nsub;
+      // a segment pays a fixed prologue, so it normally covers >= min_subtiles sub-tiles; when that would leave most of the
+      // GPU without a wave (few streams: the reference's one dongle), shorter segments win: one stream x 1 s runs in 9.6 us
+      // with single-sub-tile segments against 18.8 us with four
+      uint32_t ms = h->min_subtiles;
+      while (ms > 1 && (uint64_t)nsub * (sub_total / ms) < h->waves_target / 2) ms >>= 1;
+      const uint32_t seg_cap = sub_total / ms;
+      if (segs > seg_cap) segs = seg_cap;
+      if (segs < 1) segs = 1;
+      p.NA = (A + segs - 1) / segs;
+      p.tiles_per_stream = (A + p.NA - 1) / p.NA;
+      uint32_t grid = nsub * p.tiles_per_stream + nsub;
+      // design B: state hand-over folded into the last segment's wave (needs M >= Ta so that the d ring alone holds the
+      // new history, and the last sub-tile must contain y[M-1], which the kernel arranges)
+      p.fold_state = (h->fast->kind == 'b' && M >= c.audio_taps && h->fold_state_ok) ? 1u : 0u;
+      if (p.fold_state) grid -= nsub;
+      hipExtLaunchKernelGGL(h->fast->kernel[h->fast_mode], dim3(grid), dim3(64), h->fast_lds, bs, nullptr, bdone, 0, p);
+      bname = h->fast_name; halo_bytes = halo_bytes || h->fast->kind == 'b';
+    } else {
+      p.NA = h->NA;
+      p.tiles_per_stream = (A + h->NA - 1) / h->NA;
+      const uint32_t grid = nsub * p.tiles_per_stream + nsub;
+      hipExtLaunchKernelGGL(k_generic, dim3(grid), dim3(256), h->lds_bytes, bs, nullptr, bdone, 0, p);
+    }
+    if (mixed) {
+      if (ovl) h->rt_bx_pending = true;                            // (joined by sdrfm_flush / the next call made without the flag)
+      else HIP_TRY(hipStreamWaitEvent(h->stream, bdone, 0), SDRFM_FAIL);
+      const char* sp = strchr(bname, ' ');                         // ("fast-b", "fast-s", "generic": the name's first word)
+      snprintf(h->kernel_name, sizeof(h->kernel_name), "%s + %.*s (%u streams)", q_name, (int)(sp ? sp - bname : (long)strlen(bname)), bname, n_noisy);
+    } else {
+      snprintf(h->kernel_name, sizeof(h->kernel_name), "%s", bname);
+    }
+    p.slist = nullptr; p.n_streams = ns_all;
+  } else {
+    snprintf(h->kernel_name, sizeof(h->kernel_name), "%s", q_name);
+  }
+  if (halo_bytes && h->n_seen + 1 < c.fir_taps) {
+    // Designs Q, B and S read their halo as bytes, which cannot express the zero history at the start of a stream: the few audio
+    // outputs that depend on inputs before the first real sample are recomputed by the generic kernel (tile 0..k only), for every stream
+    // (a call this early is never overlapped, so the handle's stream is behind every launch above).
     const uint32_t a_aff = (y_aff + c.audio_taps + c.audio_decim - 1) / c.audio_decim;  // audio outputs touching them
     CallParams q = p;
     q.NA = h->NA;
@@ -2381,6 +2564,36 @@ int sdrfm_debug_discriminate(int device, const float* yr, const float* yi, const
 
 /* Test hook: design Q's conditioning guard on this handle — its two thresholds and how many lanes (pairs of discriminator outputs) the
  * repair path has recomputed, in how many passes, since create.  SDRFM_NOT_SUPPORTED when the handle has no matrix-pipe kernel. */
+// Test hook (include/sdrfm_dev.h): which streams the bit-exact kernels serve.  mask != nullptr sets it (mask[s] != 0: stream s goes to the bit-exact kernels from
+// the next call on and stays there; 0: design Q, until the statistics say otherwise); *n_noisy / noisy_out[s] report the assignment in force after the call.
+int sdrfm_debug_route(sdrfm_t* h, const uint8_t* mask, uint32_t* n_noisy, uint8_t* noisy_out) {
+  if (!h) return SDRFM_EINVAL;
+  if (!h->d_qA || !h->rt_noisy) return SDRFM_NOT_SUPPORTED;
+  HIP_TRY(hipSetDevice(h->device), SDRFM_FAIL);
+  const uint32_t ns = h->cfg.n_streams;
+  if (mask) {
+    h->rt_next_retry = ~0ull;
+    for (uint32_t s = 0; s < ns; ++s) {
+      const uint8_t want = mask[s] ? 1 : 0;
+      if (h->rt_noisy[s] != want) h->rt_dirty = true;
+      h->rt_noisy[s] = want;
+      h->rt_retry_at[s] = ~0ull;
+    }
+    if (h->rt_dirty) {
+      if (h->rt_applied_pending) HIP_TRY(hipEventSynchronize(h->rt_applied), SDRFM_FAIL);   // (a test hook may wait)
+      const int arc = route_apply(h);
+      if (arc != SDRFM_OK) return arc;
+    }
+  } else {
+    route_poll(h);
+    if (h->rt_dirty && !(h->rt_applied_pending && hipEventQuery(h->rt_applied) != hipSuccess)) { const int arc = route_apply(h); if (arc != SDRFM_OK) return arc; }
+    (void)hipGetLastError();
+  }
+  if (n_noisy) *n_noisy = h->rt_n_noisy;
+  if (noisy_out) memcpy(noisy_out, h->rt_noisy, ns);
+  return SDRFM_OK;
+}
+
 int sdrfm_debug_q_guard(sdrfm_t* h, float* guard_r, float* guard_a, unsigned long long* lanes, unsigned long long* passes) {
   if (!h) return SDRFM_EINVAL;
   if (!h->d_qA) return SDRFM_NOT_SUPPORTED;

@@ -43,7 +43,9 @@ struct SdrfmQParams {
   float guard_a;                // ... or one of its two |d|'s is above this (the branch cut); guard_r = 0 and guard_a = 4 switch the guard off
   uint32_t yprev_exact;         // yprev_in holds the definition's y[-1] (reset, or the previous call ran on a bit-exact kernel): hist_q_in[0] is not valid then
   unsigned int* n_repaired;     // statistics (device, two words: repaired lanes, repair passes) or nullptr
-  unsigned int* n_adapt;        // host-mapped word or nullptr: repair passes of every eighth wave (SDRFM_Q_ADAPT_SAMPLE), for the host's choice of kernel
+  unsigned int* stream_pass;    // [n_streams of the handle] or nullptr: repair passes per stream, added up by the waves that ran any (the host routes a stream
+                                // whose windows are mostly repair work to the bit-exact kernels: sdrfm.hip)
+  const uint32_t* slist;        // nullptr: the launch serves streams 0 .. n_streams-1; else its i-th stream is stream slist[i] of the handle (n_streams = the list's length)
   unsigned long long* dbg;      // development build: per-wave time stamps (else nullptr)
 };
 
@@ -52,7 +54,6 @@ struct SdrfmQParams {
 #define SDRFM_Q_TA 32u           /* audio taps (every instance) */
 #define SDRFM_Q_DA 5u            /* audio decimation of the BASELINE front end */
 #define SDRFM_Q_STEP_OUT 128u    /* decimated outputs per wave step (16 columns x 8 outputs) */
-#define SDRFM_Q_ADAPT_SAMPLE 8u  /* one wave in this many reports its repair passes to the host */
 #define SDRFM_Q_TP 64u           /* the repair path's chain length: channel taps padded with zeros to this many (design Q serves T <= 64) */
 
 // is there an instance for FIR decimation d and audio decimation da (with SDRFM_Q_TA audio taps)?  its ring size in KiB
@@ -64,11 +65,11 @@ uint32_t sdrfm_q_lds_bytes(uint32_t nslot, uint32_t d, uint32_t da);
 int sdrfm_q_blocks_per_cu(uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da);
 // Enqueue one call: grid = n_streams * runs one-wave workgroups.  first_chunk = 0 or 1 (from sdrfm_q_build).
 // Returns hipSuccess or the launch error.
-hipError_t sdrfm_q_launch(const SdrfmQParams& p, uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da, hipStream_t stream);
+// done != nullptr: the event is signalled by the kernel's own completion (hipExtLaunchKernelGGL's stop event: no marker packet in the queue).
+hipError_t sdrfm_q_launch(const SdrfmQParams& p, uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da, hipStream_t stream, hipEvent_t done = nullptr);
 const char* sdrfm_q_kernel_symbol(uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da);
 // yprev[s] = the definition's y[-1] of stream s from the SDRFM_Q_TP raw samples in hist_q (a bit-exact kernel takes over from design Q)
-hipError_t sdrfm_q_fix_yprev(const uint8_t* hist_q, const float* hpad, float2* yprev, uint32_t n_streams, hipStream_t stream);
-// One-time per-process kernel attribute set-up (dynamic LDS above 64 KiB is never needed; kept for symmetry): returns 0.
-const char* sdrfm_q_kernel_symbol(uint32_t first_chunk, uint32_t nslot);
+// (of the streams list[0 .. n_streams), or of streams 0 .. n_streams-1 when list is nullptr)
+hipError_t sdrfm_q_fix_yprev(const uint8_t* hist_q, const float* hpad, float2* yprev, uint32_t n_streams, const uint32_t* list, hipStream_t stream);
 
 #endif

@@ -39,6 +39,7 @@
  * end of the stream's chunk hands the state over.
  */
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdint>
 #include <type_traits>
@@ -145,7 +146,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16
   float* const ab = db + DBW;                                   // parked audio outputs
   unsigned short* const fl16 = reinterpret_cast<unsigned short*>(ab + ABW);   // lanes waiting for the repair path: (step slot + 1) << 6 | lane
   const int lane = (int)threadIdx.x, n = lane & 15, g = lane >> 4;
-  const uint32_t stream = blockIdx.x / p.runs, run = blockIdx.x - stream * p.runs;
+  const uint32_t si = blockIdx.x / p.runs, run = blockIdx.x - si * p.runs;
+  const uint32_t stream = p.slist ? p.slist[si] : si;             // (round 5: a launch may serve a list of the handle's streams)
   // Runs are cut in QUADS of four blocks (32 outputs = the warm-up a run needs: QTA - 1 d's and the y before them; 4 BLKB bytes = whole
   // 128-byte lines).  Every wave but the stream's first one (when that takes the carried state) walks one warm-up quad before what it
   // owns; a wave's STEP GRID starts at its warm-up quad (not at a multiple of 16 blocks of the stream), so the warm-up costs a quarter
@@ -335,11 +337,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16
   constexpr int NB = 2 * NSC - 2 * C0;                          // 64-byte pieces a lane reads per step: 2 NSC, the last one (when D / 2 is odd)
   qi4_t B[NB];                                                  // lies beyond the window — the tables hold no tap there, it only completes
                                                                 // the last issue's B operand
-  auto read_step = [&](qi4_t (&dst)[NB]) {                      // wait for the step at `ringoff`, read its window, park the halo at a wrap
+  auto read_step = [&](qi4_t (&dst)[NB], [[maybe_unused]] bool first) {   // wait for the step at `ringoff`, read its window, park the halo at a wrap
 #ifdef SDRFM_Q_STAMPS
     const unsigned long long tw0 = __builtin_readcyclecounter();
 #endif
     // this step's bytes have landed: everything but the youngest chunk of the 2.5-chunk steps' ring / but the next step's CS chunks
+#ifdef SDRFM_Q_FIRSTWAIT   // experiment (round 5): the first step waits for its own 2.5 chunks only, not for the ring's fourth chunk as well
+    if (!ALIGNED && first) wait_vmcnt<(ALIGNED ? CS : NSLOT - 3)>();
+    else
+#endif
     wait_vmcnt<(ALIGNED ? CS : NSLOT - 4)>();
     asm volatile("" ::: "memory");
 #ifdef SDRFM_Q_LDSXOR   // experiment (round 3: slower at the full clock; round 4: re-measured in the sustained regime): byte - 128 once per byte, in the LDS
@@ -551,9 +557,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16
 #ifdef SDRFM_Q_PHASES
     t_last = __builtin_readcyclecounter();
 #endif
-    read_step(B);
+    read_step(B, kk == 0);
     Q_PHASE(1);                                                 // wait for the step's bytes, window reads issued
     refill_step(kk);
+#ifdef SDRFM_Q_EARLYSTORE   // experiment (round 5): the stages parked so far are stored BEFORE the run's last step computes (their acknowledgements then come
+    if (kk == nsteps - 1 && npend > 0) flush_audio();   // back during it: a wave ends only when its stores are acknowledged), the last stage alone after it
+#endif
     Q_PHASE(2);                                                 // LDS round trip of the window, refill issue
     // ---- K2 on the matrix pipe ------------------------------------------------------------------------------------------------
     qi4_t acc[SDRFM_Q_DIGITS];
@@ -731,8 +740,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16
     if (cnt.y) {
       atomicAdd(pe->n_repaired, cnt.x);
       atomicAdd(pe->n_repaired + 1, cnt.y);
-      if (pe->n_adapt && blockIdx.x % SDRFM_Q_ADAPT_SAMPLE == 3u)       // (host memory: only waves that did repair, only a sample of them)
-        __hip_atomic_fetch_add(pe->n_adapt, cnt.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (pe->stream_pass) atomicAdd(pe->stream_pass + stream, cnt.y);   // per stream (device memory, one address per stream: only waves that did repair)
     }
   }
 
@@ -764,9 +772,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16
 
 // y[-1] as the definition has it, from the 64 raw samples before the next call (hist_q) — for a bit-exact kernel that takes over from
 // design Q (whose own carried y[-1] is only within 1e-4 of it).  One lane per stream; the chain of sdrfm_math.h / DESIGN.md "Frozen spec".
-__global__ void __launch_bounds__(64) k_q_fix_yprev(const uint8_t* hist_q, const float* hpad, float2* yprev, uint32_t n_streams) {
-  const uint32_t s = blockIdx.x * 64 + threadIdx.x;
-  if (s >= n_streams) return;
+__global__ void __launch_bounds__(64) k_q_fix_yprev(const uint8_t* hist_q, const float* hpad, float2* yprev, uint32_t n_streams, const uint32_t* list) {
+  const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n_streams) return;
+  const uint32_t s = list ? list[i] : i;
   const uint8_t* b = hist_q + (size_t)(2 * QTP) * s;
   float ar = 0.0f, ai = 0.0f;
   for (int i = 0; i < QTP; ++i) {                               // oldest sample first: sample -QTP + i meets tap QTP - 1 - i
@@ -846,15 +855,16 @@ int sdrfm_q_blocks_per_cu(uint32_t first_chunk, uint32_t nslot, uint32_t d, uint
   return nb;
 }
 
-hipError_t sdrfm_q_fix_yprev(const uint8_t* hist_q, const float* hpad, float2* yprev, uint32_t n_streams, hipStream_t stream) {
-  hipLaunchKernelGGL(k_q_fix_yprev, dim3((n_streams + 63) / 64), dim3(64), 0, stream, hist_q, hpad, yprev, n_streams);
+hipError_t sdrfm_q_fix_yprev(const uint8_t* hist_q, const float* hpad, float2* yprev, uint32_t n_streams, const uint32_t* list, hipStream_t stream) {
+  hipLaunchKernelGGL(k_q_fix_yprev, dim3((n_streams + 63) / 64), dim3(64), 0, stream, hist_q, hpad, yprev, n_streams, list);
   return hipGetLastError();
 }
 
-hipError_t sdrfm_q_launch(const SdrfmQParams& p, uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da, hipStream_t stream) {
+hipError_t sdrfm_q_launch(const SdrfmQParams& p, uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da, hipStream_t stream, hipEvent_t done) {
   const QVariant* v = q_find(first_chunk, nslot, d, da);
   if (!v) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(v->k, dim3(p.n_streams * p.runs), dim3(64), v->lds, stream, p);
+  if (done) hipExtLaunchKernelGGL(v->k, dim3(p.n_streams * p.runs), dim3(64), v->lds, stream, nullptr, done, 0, p);
+  else hipLaunchKernelGGL(v->k, dim3(p.n_streams * p.runs), dim3(64), v->lds, stream, p);
   return hipGetLastError();
 }
 

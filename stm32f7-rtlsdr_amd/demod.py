@@ -101,6 +101,23 @@ class FmDemod:
         self._ck(st, "sdrfm_debug_q_guard")
         return {"guard_r": r.value, "guard_a": a.value, "lanes": lanes.value, "passes": passes.value}
 
+    def route(self, mask=None):
+        """sdrfm_debug_route (include/sdrfm_dev.h): which streams the bit-exact kernels serve beside the matrix-pipe kernel — a numpy array of 0 / 1 per stream,
+        after setting it (mask: one entry per stream, non-zero = the bit-exact kernels) or after taking in the statistics that have arrived (mask=None); None when
+        the handle has no matrix-pipe kernel."""
+        import numpy as np
+        ns = self.cfg.n_streams
+        out = (C.c_uint8 * ns)()
+        n = C.c_uint32()
+        m = None
+        if mask is not None:
+            m = (C.c_uint8 * ns)(*[1 if x else 0 for x in mask])
+        st = self._lib.sdrfm_debug_route(self._h, m, C.byref(n), out)
+        if st == 3:
+            return None
+        self._ck(st, "sdrfm_debug_route")
+        return np.frombuffer(out, dtype=np.uint8).copy()
+
     def phase_cycles(self):
         """sdrfm_debug_phase_cycles: dict of cumulative shader cycles per kernel phase (profiling builds only)."""
         out = (C.c_uint64 * 8)()

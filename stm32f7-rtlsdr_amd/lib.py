@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
 
 
 # include/sdrfm_dev.h: test hooks the product library also exports / development-library-only aids (not the drop-in boundary)
-TEST_HOOK_SYMBOLS = ["sdrfm_host_atan2f", "sdrfm_host_discriminate", "sdrfm_debug_discriminate", "sdrfm_q_build", "sdrfm_q_guard", "sdrfm_debug_q_guard", "sdrfm_debug_read_ceiling"]
+TEST_HOOK_SYMBOLS = ["sdrfm_host_atan2f", "sdrfm_host_discriminate", "sdrfm_debug_discriminate", "sdrfm_q_build", "sdrfm_q_guard", "sdrfm_debug_q_guard", "sdrfm_debug_read_ceiling", "sdrfm_debug_route"]
 DEV_ONLY_SYMBOLS = ["sdrfm_debug_phase_cycles", "sdrfm_debug_raw", "sdrfm_dev_read_debug"]
 
 
@@ -135,6 +135,8 @@ def load_library(dev=False):
     lib.sdrfm_debug_read_ceiling.restype = C.c_int
     lib.sdrfm_debug_q_guard.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.sdrfm_debug_q_guard.restype = C.c_int
+    lib.sdrfm_debug_route.argtypes = [vp, C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]
+    lib.sdrfm_debug_route.restype = C.c_int
     lib.sdrfm_wbfm_create.argtypes = [C.POINTER(WbfmConfig), C.POINTER(vp)]
     lib.sdrfm_wbfm_create.restype = C.c_int
     lib.sdrfm_wbfm_destroy.argtypes = [vp]

@@ -1,0 +1,164 @@
+"""Per-stream routing between the matrix-pipe kernel (design Q) and the bit-exact kernels (csrc/sdrfm.hip: the handle's comment).
+
+256 real dongles are not all tuned to a station: the reference's front end tunes one fixed frequency
+(Middlewares/ST/STM32_USB_Host_Library/Class/RTLSDR/Src/tuner_e4k.c:1097) and hands over whatever is there (usbh_rtlsdr.c:1058-1101).  A noise-only stream
+sends design Q to its repair path at almost every audio stage, and a kernel lasts as long as its slowest wave — so the streams whose windows of design-Q
+calls are mostly repair work are served by the bit-exact kernels (a launch of their own, beside design Q's launch over the others).  Checked here: the
+statistics find exactly the noise-only streams, without the host ever waiting; every distinct row equals the oracle at the plain 1e-5 across the change of
+kernel; a stream's audio is bit-identical to what its kernel gives alone; calls return without blocking."""
+import time
+
+import numpy as np
+import pytest
+
+from conftest import scaled_err, TOL
+
+pytestmark = pytest.mark.gpu
+
+
+def _mixed_rows(pkg, ns, nsamp, noisy_every, first_id=900):
+    """8 distinct carrier rows and 4 distinct noise rows tiled over ns streams; stream s is noise-only when s % noisy_every == 1."""
+    fm = pkg.make_iq(8, nsamp, mode="fm", first_id=first_id)
+    rnd = pkg.make_iq(4, nsamp, mode="random", first_id=first_id + 100)
+    mask = np.array([1 if (noisy_every and s % noisy_every == 1) else 0 for s in range(ns)], dtype=np.uint8)
+    src = [("r", s % 4) if mask[s] else ("f", s % 8) for s in range(ns)]
+    iq = np.stack([rnd[i] if k == "r" else fm[i] for k, i in src])
+    return iq, mask, src, fm, rnd
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_statistics_route_exactly_the_noise_only_streams_and_the_audio_stays_the_oracles(pkg, oracle_mod, overlap):
+    import torch
+    h, g = pkg.default_config(64)
+    ns, nsamp, ncalls = 256, 24000, 48
+    iq, mask, src, fm, rnd = _mixed_rows(pkg, ns, ncalls * nsamp, 8)          # 32 of 256 streams (12.5 %) hold noise
+    dev = torch.from_numpy(iq).cuda()
+    out = torch.zeros((ncalls, ns, nsamp // 50), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    names = []
+    with pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=ns, max_bytes_per_call=2 * nsamp)) as dm:
+        for k in range(ncalls):
+            # (a view of the capture per call: consecutive calls read different, adjacent rows — what SDRFM_F_OVERLAP asks for)
+            assert dm.process_batch_device(dev[:, 2 * k * nsamp:], out[k], nbytes=2 * nsamp, overlap=overlap) == nsamp // 50
+            names.append(dm.kernel_name)
+            if k % 8 == 7:
+                time.sleep(0.005)                                              # (the device's report arrives while the host does something else: no synchronisation)
+        routed = dm.route()
+        dm.synchronize()
+    assert names[0].startswith("fast-q") and "+" not in names[0], names[0]
+    assert np.array_equal(routed, mask), (routed.sum(), mask.sum())
+    first = min(k for k, n in enumerate(names) if "+" in n)
+    assert 8 <= first <= 40, names                                             # a window of 8 calls, read back behind its last kernels, noticed at a later call
+    assert all(("+" in n and "(32 streams)" in n) for n in names[first:]), names[first:]
+    got = out.cpu().numpy()
+    seen = set()
+    for s in range(ns):
+        if src[s] in seen:
+            continue
+        seen.add(src[s])
+        row = rnd[src[s][1]] if src[s][0] == "r" else fm[src[s][1]]
+        want = oracle_mod.Oracle(h, g).process(row)
+        assert scaled_err(np.concatenate([got[k, s] for k in range(ncalls)]), want) <= TOL, (s, src[s])
+    # every copy of a row gives the same bits whatever else the batch holds
+    for s in range(ns):
+        t = next(t for t in range(ns) if src[t] == src[s])
+        assert np.array_equal(got[:, s].view(np.uint32), got[:, t].view(np.uint32)), (s, t)
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_a_routed_streams_audio_is_bit_identical_to_what_its_kernel_gives_alone(pkg, overlap):
+    """Assignment set by the test hook (every fourth stream to the bit-exact kernels, carriers or not): the design-Q streams equal an all-design-Q handle's
+    audio bit for bit, the others a SDRFM_CFG_BIT_EXACT handle's — also across the call at which the assignment changes."""
+    import torch
+    h, g = pkg.default_config(64)
+    ns, nsamp, ncalls = 256, 48000, 6
+    iq, _, _, _, _ = _mixed_rows(pkg, ns, ncalls * nsamp, 5, first_id=1300)    # some rows of noise among them: the repair path runs on both sides
+    dev = torch.from_numpy(iq).cuda()
+    mask = np.array([1 if s % 4 == 2 else 0 for s in range(ns)], dtype=np.uint8)
+    outs = {}
+    for tag, cfg, route_at in (("q", {}, None), ("x", {"bit_exact": True}, None), ("mixed", {}, 2)):
+        out = torch.zeros((ncalls, ns, nsamp // 50), dtype=torch.float32, device="cuda")
+        with pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=ns, max_bytes_per_call=2 * nsamp, **cfg)) as dm:
+            for k in range(ncalls):
+                if route_at is not None and k == route_at:
+                    assert np.array_equal(dm.route(mask), mask)
+                dm.process_batch_device(dev[:, 2 * k * nsamp:], out[k], nbytes=2 * nsamp, overlap=overlap)
+                if tag == "mixed" and k >= route_at:
+                    assert "+" in dm.kernel_name and "(64 streams)" in dm.kernel_name, dm.kernel_name
+            dm.synchronize()
+        outs[tag] = out.cpu().numpy().view(np.uint32)
+    q, x, m = outs["q"], outs["x"], outs["mixed"]
+    assert np.array_equal(m[:2], q[:2])                                        # before the change: design Q for all
+    on_q = mask == 0
+    assert np.array_equal(m[3:][:, ~on_q], x[3:][:, ~on_q])                          # the routed streams: the bit-exact kernels' bits
+    assert np.array_equal(m[3:][:, on_q], q[3:][:, on_q])                            # the others: design Q's bits, whatever shares the batch
+    # the call at which the assignment changes: the routed streams take over with the definition's y[-1] (as a SDRFM_CFG_BIT_EXACT handle carries it);
+    # the design-Q streams' first outputs after it meet that y[-1] instead of design Q's own (within 1e-4 of it): equal within the tolerance
+    # (... and with the 31 discriminator outputs design Q left, which differ from the bit-exact kernels' in the last ulps of the arctangent)
+    for got, ref in ((m[2][~on_q], x[2][~on_q]), (m[2][on_q], q[2][on_q])):
+        a, b = got.view(np.float32), ref.view(np.float32)
+        assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0)) <= 2e-6
+        assert np.array_equal(got[:, 8:], ref[:, 8:])
+
+
+def test_calls_return_without_waiting_for_the_device(pkg):
+    """include/sdrfm.h: a SDRFM_F_DEVICE_PTRS call returns without synchronising — also when a window of statistics closes while earlier windows are still
+    running (rounds 3 - 4 waited on an event there): 96 calls of ~50 us of device time each are issued in a fraction of the time the device needs for them."""
+    import torch
+    h, g = pkg.default_config(64)
+    ns, nsamp, ncalls = 512, 240000, 96
+    iq = torch.from_numpy(pkg.make_iq(ns, nsamp, mode="fm", first_id=77)).cuda()
+    bufs = [iq, iq.clone(), iq.clone()]
+    aud = [torch.zeros((ns, nsamp // 50), dtype=torch.float32, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    with pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=ns, max_bytes_per_call=2 * nsamp)) as dm:
+        for ovl in (False, True):
+            for k in range(8):
+                dm.process_batch_device(bufs[k % 3], aud[k & 1], overlap=ovl)
+            dm.synchronize()
+            t0 = time.perf_counter()
+            for k in range(ncalls):
+                dm.process_batch_device(bufs[k % 3], aud[k & 1], overlap=ovl)
+            t_issue = time.perf_counter() - t0
+            dm.synchronize()
+            t_all = time.perf_counter() - t0
+            assert t_issue < 0.5 * t_all, (ovl, t_issue, t_all)
+
+
+def test_a_stream_is_tried_on_design_q_again_and_reset_starts_over(pkg, oracle_mod):
+    """A noisy stream leaves design Q for SDRFM_Q_ADAPT_BACKOFF (1024) calls, is then tried again (and sent back when it is still noise); sdrfm_reset puts
+    every stream back on design Q at once — including right behind overlapped calls on rows of noise (the statistics of kernels still in flight
+    must not reach the windows after the reset)."""
+    import torch
+    h, g = pkg.default_config(64)
+    ns, nsamp = 256, 24000
+    iq, mask, src, fm, rnd = _mixed_rows(pkg, ns, 4 * nsamp, 16, first_id=2100)
+    dev = torch.from_numpy(iq).cuda()
+    out = [torch.zeros((ns, nsamp // 50), dtype=torch.float32, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    with pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=ns, max_bytes_per_call=2 * nsamp)) as dm:
+        hist = []
+        for k in range(1200):
+            dm.process_batch_device(dev[:, 2 * (k % 4) * nsamp:], out[k & 1], nbytes=2 * nsamp, overlap=True)
+            if k % 8 == 7:
+                time.sleep(0.002)
+            hist.append(int(dm.route().sum()))
+        assert hist[6] == 0 and max(hist) == int(mask.sum())                  # (the first window closes with the eighth call)
+        up = hist.index(int(mask.sum()))
+        assert up <= 40, up
+        down = next(k for k in range(up, len(hist)) if hist[k] == 0)
+        assert up + 1000 <= down <= up + 1100, (up, down)                       # tried again after the back-off ...
+        assert hist[-1] == int(mask.sum()) or max(hist[down:]) == int(mask.sum())   # ... and found noisy again
+        # reset right behind overlapped calls on noise: every stream is design Q's again, and the carriers that follow stay there
+        for k in range(6):
+            dm.process_batch_device(dev[:, 2 * (k % 4) * nsamp:], out[k & 1], nbytes=2 * nsamp, overlap=True)
+        dm.reset()
+        assert int(dm.route().sum()) == 0
+        clean = torch.from_numpy(np.tile(fm[:, :2 * 4 * nsamp], (ns // 8, 1))).cuda()
+        for k in range(40):
+            dm.process_batch_device(clean[:, 2 * (k % 4) * nsamp:], out[k & 1], nbytes=2 * nsamp, overlap=(k > 0))
+            if k % 8 == 7:
+                time.sleep(0.002)
+            assert dm.kernel_name.startswith("fast-q") and "+" not in dm.kernel_name, (k, dm.kernel_name)
+        assert int(dm.route().sum()) == 0
+        dm.synchronize()

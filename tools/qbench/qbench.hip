@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 #include "../../stm32f7-rtlsdr_amd/csrc/sdrfm_q.h"
@@ -194,10 +195,20 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int i = 0; i < 5; ++i) { p.iq = d_iq + (size_t)(i % NB) * batch; CK(sdrfm_q_launch(p, c0, nslot, D, Da, st)); }
   CK(hipStreamSynchronize(st));
-  CK(hipEventRecord(e0, st));
-  for (int i = 0; i < iters; ++i) { p.iq = d_iq + (size_t)(i % NB) * batch; CK(sdrfm_q_launch(p, c0, nslot, D, Da, st)); }
-  CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
-  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  // (a short serial region meets a different clock state every time on some boxes: QBENCH_REGIONS regions, the MEDIAN is reported, as bench.py does)
+  const int nreg = getenv("QBENCH_REGIONS") ? atoi(getenv("QBENCH_REGIONS")) : 1;
+  std::vector<float> regs;
+  for (int rg = 0; rg < nreg; ++rg) {
+    if (rg) { CK(hipStreamSynchronize(st)); for (int i = 0; i < 5; ++i) { p.iq = d_iq + (size_t)(i % NB) * batch; CK(sdrfm_q_launch(p, c0, nslot, D, Da, st)); } CK(hipStreamSynchronize(st)); }
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i) { p.iq = d_iq + (size_t)(i % NB) * batch; CK(sdrfm_q_launch(p, c0, nslot, D, Da, st)); }
+    CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+    float msr; CK(hipEventElapsedTime(&msr, e0, e1));
+    regs.push_back(msr);
+  }
+  if (nreg > 1) { printf("{\"serial_regions_us_per_launch\":["); for (size_t i = 0; i < regs.size(); ++i) printf("%s%.2f", i ? "," : "", regs[i] * 1e3 / iters); printf("]}\n"); }
+  std::sort(regs.begin(), regs.end());
+  float ms = regs[regs.size() / 2];
   if (getenv("QBENCH_TWO")) {   // the same launches alternating between TWO streams (no dependency between consecutive launches): what would overlapping calls give?
     hipStream_t s2[2];
     const char* how = getenv("QBENCH_TWO");
@@ -213,14 +224,28 @@ int main(int argc, char** argv) {
       for (uint32_t i = 0; i < 16; ++i) mask[i] = 0xffffffffu;
       CK(hipExtStreamCreateWithCUMask(&s2[0], words, mask)); CK(hipExtStreamCreateWithCUMask(&s2[1], words, mask));
     } else { CK(hipStreamCreateWithFlags(&s2[0], hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2[1], hipStreamNonBlocking)); }
+    const bool tprev = getenv("QBENCH_TWO_PREV") != nullptr;    // as the library's SDRFM_F_OVERLAP calls: every stream's first run warms up from the previous call's buffer
     hipEvent_t f0, f1, j1; CK(hipEventCreate(&f0)); CK(hipEventCreate(&f1)); CK(hipEventCreate(&j1));
     p.prio_by_age = 0;                                             // (as the library does for overlapped calls)
     for (int i = 0; i < 6; ++i) { p.iq = d_iq + (size_t)(i % NB) * batch; CK(sdrfm_q_launch(p, c0, nslot, D, Da, s2[i & 1])); }
     CK(hipStreamSynchronize(s2[0])); CK(hipStreamSynchronize(s2[1]));
-    CK(hipEventRecord(f0, s2[0])); CK(hipStreamWaitEvent(s2[1], f0, 0));
-    for (int i = 0; i < iters; ++i) { p.iq = d_iq + (size_t)(i % NB) * batch; CK(sdrfm_q_launch(p, c0, nslot, D, Da, s2[i & 1])); }
-    CK(hipEventRecord(j1, s2[1])); CK(hipStreamWaitEvent(s2[0], j1, 0)); CK(hipEventRecord(f1, s2[0])); CK(hipEventSynchronize(f1));
-    float ms2; CK(hipEventElapsedTime(&ms2, f0, f1));
+    std::vector<float> regs2;
+    float ms2 = 0;
+    for (int rg = 0; rg < nreg; ++rg) {
+      CK(hipEventRecord(f0, s2[0])); CK(hipStreamWaitEvent(s2[1], f0, 0));
+      for (int i = 0; i < iters; ++i) {
+        p.iq = d_iq + (size_t)(i % NB) * batch;
+        if (tprev) { p.iq_prev = d_iq + (size_t)((i + NB - 1) % NB) * batch; p.iq_prev_stride = stride; p.N_prev = nsamp; }
+        CK(sdrfm_q_launch(p, c0, nslot, D, Da, s2[i & 1]));
+      }
+      p.iq_prev = nullptr;
+      CK(hipEventRecord(j1, s2[1])); CK(hipStreamWaitEvent(s2[0], j1, 0)); CK(hipEventRecord(f1, s2[0])); CK(hipEventSynchronize(f1));
+      CK(hipEventElapsedTime(&ms2, f0, f1));
+      regs2.push_back(ms2);
+    }
+    if (nreg > 1) { printf("{\"two_stream_regions_us_per_launch\":["); for (size_t i = 0; i < regs2.size(); ++i) printf("%s%.2f", i ? "," : "", regs2[i] * 1e3 / iters); printf("]}\n"); }
+    std::sort(regs2.begin(), regs2.end());
+    ms2 = regs2[regs2.size() / 2];
     printf("{\"two_streams_us_per_launch\":%.2f,\"one_stream_us_per_launch\":%.2f}\n", ms2 * 1e3 / iters, ms * 1e3 / iters);
   }
   if (getenv("QBENCH_STAMPS")) {   // one more launch with per-wave stamps (kernel built with -DSDRFM_Q_STAMPS), summarised per XCC 0
