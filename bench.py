@@ -50,9 +50,11 @@ def parse():
     ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic streams generated on the host per rank; the other "
                     "rows and the other rotated batches are byte-rotations of them made on the device (0 = generate every row)")
     ap.add_argument("--batches", type=int, default=0, help="input batches the timed loop rotates over (0 = as many as exceed the L3, >= 3)")
-    ap.add_argument("--iq-class", choices=["fm", "random"], default="fm", help="fm workload: the synthetic input class — fm = the FM test signal of "
+    ap.add_argument("--iq-class", default="fm", help="fm workload: the synthetic input class — fm = the FM test signal of "
                     "SURVEY.md 8d (default, the headline); random = uniform random bytes, its worst-case class (noise only: the matrix-pipe kernel's "
-                    "conditioning guard sends about one lane in ten to the repair path); a comparison figure, labelled as such")
+                    "conditioning guard sends about one lane in ten to the repair path); mixed:P = P per cent of the streams (evenly spread) hold uniform "
+                    "random bytes, the others the FM test signal (dongles that are not tuned to a station: the library routes them per stream); "
+                    "comparison figures, labelled as such")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-steady", action="store_true", help="skip the steady-state series (ten regions of 300 calls; fm workload)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -71,7 +73,10 @@ def parse():
     ap.add_argument("--end-to-end", action="store_true",
                     help="fm workload: every step also scatters the IQ batch from rank 0 to all ranks and gathers the audio back "
                          "over RCCL (SURVEY 8e C1/C2); reported separately from the compute-only default")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if not (args.iq_class in ("fm", "random") or (args.iq_class.startswith("mixed:") and args.iq_class[6:].isdigit() and 0 < int(args.iq_class[6:]) < 100)):
+        ap.error("--iq-class: fm, random or mixed:P (P per cent, 1..99)")
+    return args
 
 
 def self_launch(args):
@@ -199,6 +204,11 @@ def cpu_baseline(pkg, h, g, iq_host, seconds, threads):
     return out
 
 
+def noisy_rows(ns, percent):
+    """the streams of a mixed:P batch that hold noise: P per cent of them, evenly spread"""
+    return [s for s in range(ns) if ((s + 1) * percent) // 100 > (s * percent) // 100]
+
+
 def make_batches(torch, pkg, stream, ns, nsamp, fs, rank, distinct, nbatches, mode="fm"):
     """nbatches device-resident input batches [ns, 2*nsamp] u8 that are CONSECUTIVE pieces of every stream: batch b holds samples
     [b nsamp, (b + 1) nsamp) of a capture nbatches x nsamp samples long, as the buffers of a front end that hands over a running
@@ -212,6 +222,9 @@ def make_batches(torch, pkg, stream, ns, nsamp, fs, rank, distinct, nbatches, mo
     distinct = ns if distinct <= 0 else min(distinct, ns)
     total = nbatches * nsamp
     t0 = time.perf_counter()
+    mixed_percent = int(mode.split(":")[1]) if mode.startswith("mixed:") else 0
+    if mixed_percent:
+        mode = "fm"
     base_host = pkg.make_iq(distinct, total, mode=mode, fs=fs, first_id=rank * ns)
     t_gen = time.perf_counter() - t0
     with torch.cuda.stream(stream):
@@ -225,8 +238,15 @@ def make_batches(torch, pkg, stream, ns, nsamp, fs, rank, distinct, nbatches, mo
                 batches[b][r0:r0 + n] = rows[:n, 2 * b * nsamp:2 * (b + 1) * nsamp]
             del rows
         del base
+        if mixed_percent:
+            rows = torch.tensor(noisy_rows(ns, mixed_percent), dtype=torch.long, device="cuda")
+            gen = torch.Generator(device="cuda")
+            gen.manual_seed(1234 + rank)
+            for b in range(nbatches):
+                batches[b][rows] = torch.randint(0, 256, (rows.numel(), 2 * nsamp), dtype=torch.uint8, device="cuda", generator=gen)
     stream.synchronize()
-    first_host = np.ascontiguousarray(base_host[: min(ns, 64), : 2 * nsamp]) if distinct >= min(ns, 64) else batches[0][: min(ns, 64)].cpu().numpy()
+    first_host = (np.ascontiguousarray(base_host[: min(ns, 64), : 2 * nsamp]) if distinct >= min(ns, 64) and not mixed_percent
+                  else batches[0][: min(ns, 64)].cpu().numpy())
     return batches, np.ascontiguousarray(first_host), t_gen
 
 
@@ -400,6 +420,14 @@ def main():
         last["n"] = dm.process_batch_device(batches[i % nb], audio_pair[ovl_calls["n"] & 1], overlap=True)
         ovl_calls["n"] += 1
 
+    if args.iq_class != "fm":
+        # a capture that has been running for a while: the library's per-stream statistics (windows of 8 calls, read back asynchronously) have settled
+        for i in range(96):
+            (step_ovl if overlap else step_rot)(i)
+            if i % 8 == 7:
+                time.sleep(0.002)
+        dm.flush()
+        dm.synchronize()
     for i in range(args.warmup):
         (step_ovl if overlap else step_rot)(i)
     dm.flush()
@@ -493,7 +521,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32 audio; K2 = u8 x 24-bit fixed-point taps on the i8 matrix pipe, exact i32 sums, one f32 recombination (design Q); K3 / K4 f32; "
                       "ill-conditioned phases recomputed with the f32 fmaf chain" if dm.kernel_name.startswith("fast-q") else "f32 (fmaf chains throughout)"),
-            "data": "synthetic" if args.iq_class == "fm" else "synthetic, uniform random bytes (SURVEY.md 8d's worst-case class: NOT the headline input)",
+            "data": ("synthetic" if args.iq_class == "fm" else
+                     "synthetic, uniform random bytes (SURVEY.md 8d's worst-case class: NOT the headline input)" if args.iq_class == "random" else
+                     "synthetic, %s per cent of the streams uniform random bytes, the others the FM test signal (NOT the headline input)" % args.iq_class.split(":")[1]),
             "mode": "end-to-end (RCCL scatter of IQ from rank 0 + gather of audio every step)" if args.end_to_end else
                     ("compute-only (IQ resident per GPU); timed calls made with SDRFM_F_OVERLAP: consecutive calls may run concurrently on the device"
                      if overlap else "compute-only (IQ resident per GPU); calls one after the other"),
@@ -530,6 +560,11 @@ def main():
                             if serial_regions and len(serial_regions) > 1 else {})},
             "gen_seconds": round(t_gen, 2),
         }
+        routed = dm.route()
+        if routed is not None and (args.iq_class != "fm" or int(routed.sum())):
+            res["routing"] = {"streams_on_bit_exact_kernels": int(routed.sum()), "streams": ns, "kernels_last_call": dm.kernel_name,
+                              "note": "per-stream routing (DESIGN.md 4.Q): streams whose windows of design-Q calls were mostly repair work are served by the "
+                                      "bit-exact kernels, a launch of their own beside design Q's"}
         if guard:
             res["guard"] = {"guard_r": round(guard["guard_r"], 4), "pi_minus_guard_a": round(3.141592653589793 - guard["guard_a"], 7),
                             "lanes_repaired_since_create": guard["lanes"], "repair_passes_since_create": guard["passes"],

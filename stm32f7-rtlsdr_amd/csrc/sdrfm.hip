@@ -1428,9 +1428,13 @@ const FastVariant kFastVariants[] = {
     SDRFM_STREAM(64, 10, 8, 6, 32, 5), SDRFM_STREAM(32, 10, 8, 6, 32, 5),
     // 2.4 MS/s -> 240 kS/s -> 48 kHz: the rate the firmware programs (usbh_rtlsdr.c:898) and the BASELINE configs
     SDRFM_FASTB2_ABL(64, 10, 12, 32, 5), SDRFM_FASTB2_LITE(64, 10, 8, 32, 5), SDRFM_FASTB(16, 10, 12), SDRFM_FASTB2_LITE(32, 10, 12, 32, 5),
+    // R = 4: the noisy streams' launch beside design Q's (per-stream routing): 6.8 KB of LDS per wave — a slot one of design Q's waves (10.9 KB) leaves
+    // takes one, which the 19 KB of the R = 12 instance cannot count on while design Q's waves keep coming
+    SDRFM_FASTB2_LITE(64, 10, 4, 32, 5), SDRFM_FASTB2_LITE(32, 10, 4, 32, 5), SDRFM_FASTB2_LITE(16, 10, 4, 32, 5),
     // the other rates RTLSDR_set_sample_rate accepts and a dongle is commonly run at:
     // 2.048 MS/s -> 256 kS/s -> 32 kHz, 1.024 MS/s -> 256 kS/s -> 32 kHz, 3.2 MS/s -> 200 kS/s -> 40 kHz
     SDRFM_FASTB2_LITE(64, 8, 12, 32, 8), SDRFM_FASTB2_LITE(16, 8, 12, 32, 8), SDRFM_FASTB2_LITE(64, 4, 12, 32, 8), SDRFM_FASTB2_LITE(64, 16, 8, 32, 5),
+    SDRFM_FASTB2_LITE(64, 8, 4, 32, 8), SDRFM_FASTB2_LITE(16, 8, 4, 32, 8), SDRFM_FASTB2_LITE(64, 16, 4, 32, 5),
 #ifdef SDRFM_DEV
     // design A (float tile): kept as the measured alternative; ablation modes only on the documented shape
     SDRFM_FAST(64, 10, 3), SDRFM_FAST_LITE(16, 10, 2), SDRFM_FAST_LITE(32, 10, 2),
@@ -1470,6 +1474,7 @@ struct sdrfm {
   // fast kernel (when one is instantiated for this T/D)
   const FastVariant* fast;
   const FastVariant* fast_s;  // design S variant of this geometry, if one is instantiated (serves the calls it is eligible for)
+  const FastVariant* fast_mix; size_t fast_mix_lds;   // design B with the smallest tile (R = 4): the noisy streams' launch beside design Q's
   uint32_t n_cu;              // compute units of the device
   char fast_s_name[64];
   size_t fast_lds;
@@ -1518,7 +1523,9 @@ struct sdrfm {
   uint8_t* rt_noisy; uint64_t* rt_retry_at; uint32_t rt_n_noisy; uint64_t rt_calls, rt_next_retry;   // host: per stream, served by the bit-exact kernels until call rt_retry_at
   uint32_t* rt_list_dev[2]; uint32_t* rt_list_host[2]; int rt_list_cur; bool rt_dirty;   // stream lists: the clean streams first, then the noisy ones
   hipEvent_t rt_applied; bool rt_applied_pending;               // a new list version is in place (recorded on the handle's stream)
-  hipStream_t rt_bx; hipEvent_t rt_bx_done, rt_bx_fork, rt_bx_evt[2]; uint32_t rt_bx_slot; bool rt_bx_pending;   // the bit-exact sub-launches: a stream of their own (in order: each takes the state the one before left)
+  hipStream_t rt_bx; hipEvent_t rt_bx_done; bool rt_bx_pending;   // overlapped calls: the noisy streams' launches on a stream with a hardware queue of its own (a CU-mask stream)
+  hipEvent_t rt_bx_evt[2]; uint32_t rt_bx_slot; hipStream_t rt_bx_last;   // the bit-exact sub-launches: completion events (stop events), and the stream the latest went to
+                                                                // (each takes the state the one before left: on another stream it waits for that one's event)
   bool rt_off;                                                  // (development: design Q whatever the streams hold)
   // SDRFM_F_OVERLAP: two internal streams taken in turn, so that consecutive calls run concurrently on the device (a call's ramp-up
   // under the previous call's tail).  ovl_in orders a call behind what the handle's stream holds when it is made; join_overlap()
@@ -1567,11 +1574,13 @@ static int route_create(sdrfm* h) {
     for (int k = 0; k < 3; ++k) HIP_TRY(hipEventCreateWithFlags(&h->rt_win_evt[i][k], hipEventDisableTiming), SDRFM_ENOMEM);
   }
   HIP_TRY(hipEventCreateWithFlags(&h->rt_applied, hipEventDisableTiming), SDRFM_ENOMEM);
-  HIP_TRY(hipEventCreateWithFlags(&h->rt_bx_done, hipEventDisableTiming), SDRFM_ENOMEM);
-  HIP_TRY(hipEventCreateWithFlags(&h->rt_bx_fork, hipEventDisableTiming), SDRFM_ENOMEM);
   for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreateWithFlags(&h->rt_bx_evt[i], hipEventDisableTiming), SDRFM_ENOMEM);
+  HIP_TRY(hipEventCreateWithFlags(&h->rt_bx_done, hipEventDisableTiming), SDRFM_ENOMEM);
+  // (rt_bx stays null: a third stream for the noisy streams' launches was tried two ways and lost both times — profiles/r05_mixed_batches.txt.  An ordinary
+  // stream shares the handle's stream's hardware queue (streams of one priority share a small pool): its kernels sat between that stream's event markers and
+  // every overlapped call waited for the previous call's launch; a CU-mask stream (a queue of its own) ran the overlapped calls at 53 us against 36 - 41 us
+  // with the launch ahead of design Q's on the call's own stream.)
   HIP_TRY(hipStreamCreateWithFlags(&h->rt_mon, hipStreamNonBlocking), SDRFM_ENOMEM);
-  HIP_TRY(hipStreamCreateWithFlags(&h->rt_bx, hipStreamNonBlocking), SDRFM_ENOMEM);
   h->rt_next_retry = ~0ull;
   return SDRFM_OK;
 }
@@ -1580,16 +1589,17 @@ static int route_create(sdrfm* h) {
 static int route_reset(sdrfm* h) {
   if (!h->rt_noisy) return SDRFM_OK;
   const size_t ns = h->cfg.n_streams;
-  if (h->rt_bx) HIP_TRY(hipStreamSynchronize(h->rt_bx), SDRFM_FAIL);
   if (h->rt_mon) HIP_TRY(hipStreamSynchronize(h->rt_mon), SDRFM_FAIL);
   for (int k = 0; k < 2; ++k)
     if (h->ovl_stream[k]) HIP_TRY(hipStreamSynchronize(h->ovl_stream[k]), SDRFM_FAIL);
+  if (h->rt_bx) HIP_TRY(hipStreamSynchronize(h->rt_bx), SDRFM_FAIL);
+  h->rt_bx_pending = false;
   for (int i = 0; i < 2; ++i) {
     HIP_TRY(hipMemset(h->rt_pass_dev[i], 0, ns * sizeof(uint32_t)), SDRFM_FAIL);
     h->rt_rb_pending[i] = false;
   }
   memset(h->rt_noisy, 0, ns);
-  h->rt_n_noisy = 0; h->rt_next_retry = ~0ull; h->rt_dirty = false; h->rt_applied_pending = false; h->rt_bx_pending = false; h->rt_calls = 0;
+  h->rt_n_noisy = 0; h->rt_next_retry = ~0ull; h->rt_dirty = false; h->rt_applied_pending = false; h->rt_bx_last = nullptr; h->rt_calls = 0;
   h->rt_win_calls = 0; h->rt_win_stages = 0; h->rt_win_stats = false;
   for (int k = 0; k < 3; ++k) { h->rt_win_need[k] = false; h->rt_win_used[k] = false; }
   return SDRFM_OK;
@@ -1631,8 +1641,8 @@ static void free_handle(sdrfm* h) {
   (void)hipSetDevice(h->device);
   for (int k = 0; k < 2; ++k)
     if (h->ovl_stream[k]) (void)hipStreamSynchronize(h->ovl_stream[k]);     // overlapped calls still use the buffers freed below
-  if (h->rt_bx) (void)hipStreamSynchronize(h->rt_bx);
   if (h->rt_mon) (void)hipStreamSynchronize(h->rt_mon);
+  if (h->rt_bx) (void)hipStreamSynchronize(h->rt_bx);
   if (h->d_h) (void)hipFree(h->d_h);
   if (h->d_g) (void)hipFree(h->d_g);
   for (int i = 0; i < 2; ++i) {
@@ -1658,12 +1668,11 @@ static void free_handle(sdrfm* h) {
       if (h->rt_win_evt[i][k]) (void)hipEventDestroy(h->rt_win_evt[i][k]);
   }
   if (h->rt_applied) (void)hipEventDestroy(h->rt_applied);
-  if (h->rt_bx_done) (void)hipEventDestroy(h->rt_bx_done);
-  if (h->rt_bx_fork) (void)hipEventDestroy(h->rt_bx_fork);
   for (int i = 0; i < 2; ++i)
     if (h->rt_bx_evt[i]) (void)hipEventDestroy(h->rt_bx_evt[i]);
   if (h->rt_mon) (void)hipStreamDestroy(h->rt_mon);
   if (h->rt_bx) (void)hipStreamDestroy(h->rt_bx);
+  if (h->rt_bx_done) (void)hipEventDestroy(h->rt_bx_done);
   free(h->rt_noisy);
   free(h->rt_retry_at);
   if (h->d_qstat) (void)hipFree(h->d_qstat);
@@ -1920,6 +1929,14 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
       break;
     }
   }
+  if (h->fast && h->fast->kind == 'b' && h->d_qA)
+    for (const FastVariant& v : kFastVariants) {
+      if (v.kind != 'b' || v.R != 4 || v.T != cfg->fir_taps || v.D != cfg->fir_decim || (v.Ta && (v.Ta != cfg->audio_taps || v.Da != cfg->audio_decim))) continue;
+      const uint32_t NYT = 64 * v.R, DOFF = (cfg->audio_taps - 1 + 3u) & ~3u;
+      if (cfg->audio_taps - 1 > NYT || DOFF + NYT < 2 * (cfg->audio_taps + 1) || h->AB != 1) continue;
+      h->fast_mix = &v;
+      h->fast_mix_lds = (size_t)v.xbytes + (size_t)(DOFF + NYT + v.T + cfg->audio_taps) * 4;
+    }
   const int rc = sdrfm_reset(h);
   if (rc != SDRFM_OK) { free_handle(h); return rc; }
   *out = h;
@@ -1974,7 +1991,7 @@ static int join_overlap(sdrfm* h) {
       HIP_TRY(hipStreamWaitEvent(h->stream, h->ovl_done[k], 0), SDRFM_FAIL);
       h->ovl_pending[k] = false;
     }
-  if (h->rt_bx_pending) {                                        // the noisy streams' launches of the overlapped calls (one internal stream, in order)
+  if (h->rt_bx_pending) {                                        // the noisy streams' launches of the overlapped calls
     HIP_TRY(hipEventRecord(h->rt_bx_done, h->rt_bx), SDRFM_FAIL);
     HIP_TRY(hipStreamWaitEvent(h->stream, h->rt_bx_done, 0), SDRFM_FAIL);
     h->rt_bx_pending = false;
@@ -2007,7 +2024,7 @@ static int route_apply(sdrfm* h) {
   h->rt_applied_pending = true;
   for (int k = 0; k < 2; ++k)
     if (h->ovl_stream[k]) HIP_TRY(hipStreamWaitEvent(h->ovl_stream[k], h->rt_applied, 0), SDRFM_FAIL);
-  HIP_TRY(hipStreamWaitEvent(h->rt_bx, h->rt_applied, 0), SDRFM_FAIL);
+  if (h->rt_bx) HIP_TRY(hipStreamWaitEvent(h->rt_bx, h->rt_applied, 0), SDRFM_FAIL);
   h->rt_list_cur = v; h->rt_n_noisy = nn; h->rt_dirty = false;
   return SDRFM_OK;
 }
@@ -2128,7 +2145,8 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
     (void)hipGetLastError();
   }
   const uint32_t n_noisy = (q_fit && h->rt_noisy) ? h->rt_n_noisy : 0u, n_clean = ns_all - n_noisy;
-  const bool q_ok = q_fit && n_clean > 0;                        // design Q serves n_clean streams (all of them when no stream is noisy)
+  const bool q_ok = q_fit && n_clean > 0 && 2 * n_noisy < ns_all; // design Q serves n_clean streams (all of them when no stream is noisy); with half of the streams
+                                                                 // noisy the bit-exact kernels take the whole batch (design S fills the machine then)
   const bool bx_all = !q_ok;                                     // the bit-exact kernels serve every stream, on the handle's stream (as every call design Q cannot take)
   const bool mixed = q_ok && n_noisy > 0;                        // ... or the noisy ones beside design Q, on their own internal stream
   ++h->rt_calls;
@@ -2157,36 +2175,121 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
   const uint32_t* list_dev = (h->rt_noisy && n_noisy) ? h->rt_list_dev[h->rt_list_cur] : nullptr;   // [clean streams][noisy streams]
   char q_name[sizeof(h->kernel_name)] = "";
   bool halo_bytes = q_ok;                                        // a kernel that reads its halo as bytes served (some of) the call
+  bool behind_in = false;                                        // overlapped call: the handle's stream holds work the launches have to be ordered behind
+  if (ovl || mixed) {
+    if (!h->ovl_done[1]) {                                      // (created piece by piece: a failure half-way leaves nothing half-used)
+      if (!h->ovl_in) HIP_TRY(hipEventCreateWithFlags(&h->ovl_in, hipEventDisableTiming), SDRFM_ENOMEM);
+      // Two streams only overlap when they sit on different hardware queues, and the runtime hands streams of one priority a small
+      // shared pool of queues (two streams created back to back were seen on the same one: the calls then ran one after the other).
+      // Queues are pooled per priority, so the two internal streams take the two priorities ordinary streams do not use.
+      int pr_least = 0, pr_greatest = 0;
+      HIP_TRY(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest), SDRFM_FAIL);
+      for (int i = 0; i < 2; ++i) {
+        if (!h->ovl_stream[i]) HIP_TRY(hipStreamCreateWithPriority(&h->ovl_stream[i], hipStreamNonBlocking, i == 0 ? pr_greatest : pr_least), SDRFM_ENOMEM);
+        if (!h->ovl_done[i]) HIP_TRY(hipEventCreateWithFlags(&h->ovl_done[i], hipEventDisableTiming), SDRFM_ENOMEM);
+      }
+    }
+    // behind whatever the handle's stream still holds (it may produce iq); an idle stream — the steady state of a caller whose
+    // buffers are filled elsewhere — costs one query instead of two packets
+    if (ovl && hipStreamQuery(h->stream) != hipSuccess) {
+      (void)hipGetLastError();
+      HIP_TRY(hipEventRecord(h->ovl_in, h->stream), SDRFM_FAIL);
+      behind_in = true;
+    }
+  }
+  // the stream this call's launches go to: one of the two internal streams in turn (overlapped calls), or the handle's stream
+  hipStream_t qs = h->stream;
+  uint32_t k = 2;                                                 // its slot: internal stream 0 / 1, or 2 = the handle's stream
+  if (ovl) { k = h->ovl_next; h->ovl_next ^= 1u; qs = h->ovl_stream[k]; if (behind_in) HIP_TRY(hipStreamWaitEvent(qs, h->ovl_in, 0), SDRFM_FAIL); }
+  const char* bx_name = nullptr;
+  // Mixed calls share the machine between the two launches: a stream costs the bit-exact kernels about twice what it costs design Q, so design Q's
+  // grid is cut for its share of the CUs' wave slots (fewer runs per stream) and design B's for the LDS that leaves (its launch goes out first: its
+  // waves are the longer ones).
+  uint32_t q_slots = h->q_waves_per_cu, bx_waves = h->waves_target;
+  if (mixed) {
+    const double share = (2.0 * n_noisy) / ((double)n_clean + 2.0 * n_noisy);
+    q_slots = (uint32_t)((double)h->q_waves_per_cu * (1.0 - share) + 0.5);
+    if (q_slots + 1 > h->q_waves_per_cu) q_slots = h->q_waves_per_cu - 1;
+    if (q_slots < 2) q_slots = 2;
+    const size_t q_lds = sdrfm_q_lds_bytes(h->q_nslot, c.fir_decim, c.audio_decim);
+    const size_t left = 163840u > q_slots * q_lds ? 163840u - q_slots * q_lds : 0u;
+    const size_t b_lds = h->fast_mix ? h->fast_mix_lds : h->fast_lds;
+    uint32_t per_cu = b_lds ? (uint32_t)(left / b_lds) : 1u;
+    if (per_cu < 1) per_cu = 1;
+    bx_waves = h->n_cu * per_cu;
+  }
+  if (bx_all || mixed) {
+    // ---- the bit-exact kernels: every stream (on the handle's stream), or the noisy streams beside design Q's launch: on their own internal stream, in
+    // order among themselves (each takes the state the previous one left); a call made without SDRFM_F_OVERLAP forks that stream off the handle's stream
+    // and joins it again, so that the handle's stream is behind both launches when the call returns
+    const uint32_t nsub = bx_all ? ns_all : n_noisy;
+    hipStream_t bs = h->stream;
+    hipEvent_t bdone = nullptr;                                   // mixed: the launch's own completion event (a stop event: no marker packet)
+    if (mixed) {
+      // The noisy streams' launch goes ahead of design Q's on the call's own stream: no third stream (streams of one priority share a small pool of
+      // hardware queues — one was seen on the queue of the handle's stream, and every dependence across queues costs ~10 us of a queue's time), no
+      // fork and join.  Overlapped calls run it beside the OTHER internal stream's call; it takes the state the previous such launch left, which sits
+      // on that other stream then: behind its completion event (launched a whole call earlier: a wait that is over when it is reached).
+      bs = (ovl && h->rt_bx) ? h->rt_bx : qs;                      // (overlapped calls: beside both internal streams' launches, on the stream with a queue of its own)
+      if (bs == h->rt_bx) { h->rt_bx_pending = true; if (behind_in) HIP_TRY(hipStreamWaitEvent(bs, h->ovl_in, 0), SDRFM_FAIL); }
+      bdone = h->rt_bx_evt[h->rt_bx_slot]; h->rt_bx_slot ^= 1u;
+      if (h->rt_bx_last && h->rt_bx_last != bs) HIP_TRY(hipStreamWaitEvent(bs, h->rt_bx_evt[h->rt_bx_slot], 0), SDRFM_FAIL);   // (the slot just left: the previous launch's event)
+      h->rt_bx_last = bs;
+      p.slist = list_dev + n_clean;
+    }
+    p.n_streams = nsub;
+    const bool stream_ok = fast_ok && h->fast_s && h->phase_x == 0 && h->phase_d == 0 && (N % h->fast_s->seg) == 0 &&
+                           (M % c.audio_decim) == 0 && M >= c.audio_taps && ((uintptr_t)d_iq % 16 == 0) && (iq_stride % 16 == 0) &&
+                           h->fold_state_ok &&
+                           // a lane-segment wave is long (its 64 lanes walk 480 samples each, ~25 us alone on a SIMD): design S pays when
+                           // the launch fills the machine (>= one wave per SIMD); a single dongle's call is served faster by design B,
+                           // which cuts its segments as short as the call needs
+                           (uint64_t)nsub * ((N / h->fast_s->seg + 62) / 63) >= 4ull * h->n_cu &&
+                           !mixed;   // (beside design Q's launch: design B's small tile — a wave of design S needs 16 KB of LDS and lasts 25 us)
+    const char* bname = h->generic_name;
+    if (stream_ok) {
+      const uint32_t segs = N / h->fast_s->seg;
+      p.tiles_per_stream = (segs + 62) / 63;                      // waves per stream: 63 useful lane segments each
+      p.fold_state = 1;
+      hipExtLaunchKernelGGL(h->fast_s->kernel[0], dim3(nsub * p.tiles_per_stream), dim3(64), h->fast_s->xbytes, bs, nullptr, bdone, 0, p);
+      bname = h->fast_s_name; halo_bytes = true;
+    } else if (fast_ok) {
+      // split every stream into segments so that ~waves_target waves are resident; each segment >= min_subtiles sub-tiles
+      const FastVariant* fv = (mixed && h->fast_mix) ? h->fast_mix : h->fast;
+      const size_t flds = (mixed && h->fast_mix) ? h->fast_mix_lds : h->fast_lds;
+      const uint32_t NYT = 64 * fv->R;
+      const uint32_t sub_total = (M + NYT - 1) / NYT;
+      uint32_t segs = bx_waves / nsub;
+      // a segment pays a fixed prologue, so it normally covers >= min_subtiles sub-tiles; when that would leave most of the
+      // GPU without a wave (few streams: the reference's one dongle), shorter segments win: one stream x 1 s runs in 9.6 us
+      // with single-sub-tile segments against 18.8 us with four
+      uint32_t ms = h->min_subtiles;
+      while (ms > 1 && (uint64_t)nsub * (sub_total / ms) < bx_waves / 2) ms >>= 1;
+      const uint32_t seg_cap = sub_total / ms;
+      if (segs > seg_cap) segs = seg_cap;
+      if (segs < 1) segs = 1;
+      p.NA = (A + segs - 1) / segs;
+      p.tiles_per_stream = (A + p.NA - 1) / p.NA;
+      uint32_t grid = nsub * p.tiles_per_stream + nsub;
+      // design B: state hand-over folded into the last segment's wave (needs M >= Ta so that the d ring alone holds the
+      // new history, and the last sub-tile must contain y[M-1], which the kernel arranges)
+      p.fold_state = (fv->kind == 'b' && M >= c.audio_taps && h->fold_state_ok) ? 1u : 0u;
+      if (p.fold_state) grid -= nsub;
+      hipExtLaunchKernelGGL(fv->kernel[fv == h->fast ? h->fast_mode : 0], dim3(grid), dim3(64), flds, bs, nullptr, bdone, 0, p);
+      bname = h->fast_name; halo_bytes = halo_bytes || fv->kind == 'b';
+    } else {
+      p.NA = h->NA;
+      p.tiles_per_stream = (A + h->NA - 1) / h->NA;
+      const uint32_t grid = nsub * p.tiles_per_stream + nsub;
+      hipExtLaunchKernelGGL(k_generic, dim3(grid), dim3(256), h->lds_bytes, bs, nullptr, bdone, 0, p);
+    }
+    bx_name = bname;
+    p.slist = nullptr; p.n_streams = ns_all;
+  }
   if (q_ok) {
     SdrfmQParams q;
-    hipStream_t qs = h->stream;
-    uint32_t k = 2;                                               // stream slot of this launch: internal stream 0 / 1, or 2 = the handle's stream
     q.iq_prev = nullptr; q.iq_prev_stride = 0; q.N_prev = 0;
-    if (ovl) {
-      if (!h->ovl_done[1]) {                                      // (created piece by piece: a failure half-way leaves nothing half-used)
-        if (!h->ovl_in) HIP_TRY(hipEventCreateWithFlags(&h->ovl_in, hipEventDisableTiming), SDRFM_ENOMEM);
-        // Two streams only overlap when they sit on different hardware queues, and the runtime hands streams of one priority a small
-        // shared pool of queues (two streams created back to back were seen on the same one: the calls then ran one after the other).
-        // Queues are pooled per priority, so the two internal streams take the two priorities ordinary streams do not use.
-        int pr_least = 0, pr_greatest = 0;
-        HIP_TRY(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest), SDRFM_FAIL);
-        for (int i = 0; i < 2; ++i) {
-          if (!h->ovl_stream[i]) HIP_TRY(hipStreamCreateWithPriority(&h->ovl_stream[i], hipStreamNonBlocking, i == 0 ? pr_greatest : pr_least), SDRFM_ENOMEM);
-          if (!h->ovl_done[i]) HIP_TRY(hipEventCreateWithFlags(&h->ovl_done[i], hipEventDisableTiming), SDRFM_ENOMEM);
-        }
-      }
-      k = h->ovl_next; h->ovl_next ^= 1u;
-      qs = h->ovl_stream[k];
-      // behind whatever the handle's stream still holds (it may produce iq); an idle stream — the steady state of a caller whose
-      // buffers are filled elsewhere — costs one query instead of two packets
-      if (hipStreamQuery(h->stream) != hipSuccess) {
-        (void)hipGetLastError();
-        HIP_TRY(hipEventRecord(h->ovl_in, h->stream), SDRFM_FAIL);
-        HIP_TRY(hipStreamWaitEvent(qs, h->ovl_in, 0), SDRFM_FAIL);
-        if (mixed) HIP_TRY(hipStreamWaitEvent(h->rt_bx, h->ovl_in, 0), SDRFM_FAIL);
-      }
-      q.iq_prev = h->prev_iq; q.iq_prev_stride = h->prev_stride; q.N_prev = h->prev_nbytes / 2;
-    }
+    if (ovl) { q.iq_prev = h->prev_iq; q.iq_prev_stride = h->prev_stride; q.N_prev = h->prev_nbytes / 2; }
     q.iq = d_iq; q.iq_stride = iq_stride; q.audio = d_audio; q.audio_stride = audio_stride;
     q.yprev_in = p.yprev_in; q.yprev_out = p.yprev_out; q.hist_d_in = p.hist_d_in; q.hist_d_out = p.hist_d_out;
     q.hist_b_in = p.hist_b_in; q.hist_b_out = p.hist_b_out; q.hist_x_out = p.hist_x_out;
@@ -2202,8 +2305,8 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
     q.guard_r = h->q_guard_r; q.guard_a = h->q_guard_a; q.yprev_exact = h->yprev_exact ? 1u : 0u; q.n_repaired = h->d_qstat;
     // runs (waves) per stream: fill the machine once; every run at least four owned steps (a run warms up over a quarter of a step), two
     // when the call is too small to fill the machine otherwise
-    uint32_t runs = (h->q_waves_per_cu * h->n_cu) / n_clean;
-    const uint32_t min_steps = ((uint64_t)n_clean * (q_steps / 4) >= (uint64_t)h->q_waves_per_cu * h->n_cu / 2) ? 4u : 2u;
+    uint32_t runs = (q_slots * h->n_cu) / n_clean;
+    const uint32_t min_steps = ((uint64_t)n_clean * (q_steps / 4) >= (uint64_t)q_slots * h->n_cu / 2) ? 4u : 2u;
     if (runs > q_steps / min_steps) runs = q_steps / min_steps;
     if (runs < 1) runs = 1;
     q.runs = runs;
@@ -2246,76 +2349,11 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
     }
     snprintf(q_name, sizeof(q_name), "%s%s", h->fast_q_name, ovl ? " overlapped" : "");
   }
-  if (bx_all || mixed) {
-    // ---- the bit-exact kernels: every stream (on the handle's stream), or the noisy streams beside design Q's launch: on their own internal stream, in
-    // order among themselves (each takes the state the previous one left); a call made without SDRFM_F_OVERLAP forks that stream off the handle's stream
-    // and joins it again, so that the handle's stream is behind both launches when the call returns
-    const uint32_t nsub = bx_all ? ns_all : n_noisy;
-    hipStream_t bs = h->stream;
-    hipEvent_t bdone = nullptr;                                   // mixed: the launch's own completion event (a stop event: no marker packet)
-    if (mixed) {
-      bs = h->rt_bx;
-      bdone = h->rt_bx_evt[h->rt_bx_slot]; h->rt_bx_slot ^= 1u;
-      p.slist = list_dev + n_clean;
-      if (!ovl) {
-        HIP_TRY(hipEventRecord(h->rt_bx_fork, h->stream), SDRFM_FAIL);
-        HIP_TRY(hipStreamWaitEvent(bs, h->rt_bx_fork, 0), SDRFM_FAIL);
-      }
-    }
-    p.n_streams = nsub;
-    const bool stream_ok = fast_ok && h->fast_s && h->phase_x == 0 && h->phase_d == 0 && (N % h->fast_s->seg) == 0 &&
-                           (M % c.audio_decim) == 0 && M >= c.audio_taps && ((uintptr_t)d_iq % 16 == 0) && (iq_stride % 16 == 0) &&
-                           h->fold_state_ok &&
-                           // a lane-segment wave is long (its 64 lanes walk 480 samples each, ~25 us alone on a SIMD): design S pays when
-                           // the launch fills the machine (>= one wave per SIMD); a single dongle's call is served faster by design B,
-                           // which cuts its segments as short as the call needs
-                           (uint64_t)nsub * ((N / h->fast_s->seg + 62) / 63) >= 4ull * h->n_cu;
-    const char* bname = h->generic_name;
-    if (stream_ok) {
-      const uint32_t segs = N / h->fast_s->seg;
-      p.tiles_per_stream = (segs + 62) / 63;                      // waves per stream: 63 useful lane segments each
-      p.fold_state = 1;
-      hipExtLaunchKernelGGL(h->fast_s->kernel[0], dim3(nsub * p.tiles_per_stream), dim3(64), h->fast_s->xbytes, bs, nullptr, bdone, 0, p);
-      bname = h->fast_s_name; halo_bytes = true;
-    } else if (fast_ok) {
-      // split every stream into segments so that ~waves_target waves are resident; each segment >= min_subtiles sub-tiles
-      const uint32_t NYT = 64 * h->fast->R;
-      const uint32_t sub_total = (M + NYT - 1) / NYT;
-      uint32_t segs = h->waves_target / nsub;
-      // a segment pays a fixed prologue, so it normally covers >= min_subtiles sub-tiles; when that would leave most of the
-      // GPU without a wave (few streams: the reference's one dongle), shorter segments win: one stream x 1 s runs in 9.6 us
-      // with single-sub-tile segments against 18.8 us with four
-      uint32_t ms = h->min_subtiles;
-      while (ms > 1 && (uint64_t)nsub * (sub_total / ms) < h->waves_target / 2) ms >>= 1;
-      const uint32_t seg_cap = sub_total / ms;
-      if (segs > seg_cap) segs = seg_cap;
-      if (segs < 1) segs = 1;
-      p.NA = (A + segs - 1) / segs;
-      p.tiles_per_stream = (A + p.NA - 1) / p.NA;
-      uint32_t grid = nsub * p.tiles_per_stream + nsub;
-      // design B: state hand-over folded into the last segment's wave (needs M >= Ta so that the d ring alone holds the
-      // new history, and the last sub-tile must contain y[M-1], which the kernel arranges)
-      p.fold_state = (h->fast->kind == 'b' && M >= c.audio_taps && h->fold_state_ok) ? 1u : 0u;
-      if (p.fold_state) grid -= nsub;
-      hipExtLaunchKernelGGL(h->fast->kernel[h->fast_mode], dim3(grid), dim3(64), h->fast_lds, bs, nullptr, bdone, 0, p);
-      bname = h->fast_name; halo_bytes = halo_bytes || h->fast->kind == 'b';
-    } else {
-      p.NA = h->NA;
-      p.tiles_per_stream = (A + h->NA - 1) / h->NA;
-      const uint32_t grid = nsub * p.tiles_per_stream + nsub;
-      hipExtLaunchKernelGGL(k_generic, dim3(grid), dim3(256), h->lds_bytes, bs, nullptr, bdone, 0, p);
-    }
-    if (mixed) {
-      if (ovl) h->rt_bx_pending = true;                            // (joined by sdrfm_flush / the next call made without the flag)
-      else HIP_TRY(hipStreamWaitEvent(h->stream, bdone, 0), SDRFM_FAIL);
-      const char* sp = strchr(bname, ' ');                         // ("fast-b", "fast-s", "generic": the name's first word)
-      snprintf(h->kernel_name, sizeof(h->kernel_name), "%s + %.*s (%u streams)", q_name, (int)(sp ? sp - bname : (long)strlen(bname)), bname, n_noisy);
-    } else {
-      snprintf(h->kernel_name, sizeof(h->kernel_name), "%s", bname);
-    }
-    p.slist = nullptr; p.n_streams = ns_all;
+  if (mixed) {
+    const char* sp = strchr(bx_name, ' ');                         // ("fast-b", "fast-s", "generic": the name's first word)
+    snprintf(h->kernel_name, sizeof(h->kernel_name), "%s + %.*s (%u streams)", q_name, (int)(sp ? sp - bx_name : (long)strlen(bx_name)), bx_name, n_noisy);
   } else {
-    snprintf(h->kernel_name, sizeof(h->kernel_name), "%s", q_name);
+    snprintf(h->kernel_name, sizeof(h->kernel_name), "%s", bx_all ? bx_name : q_name);
   }
   if (halo_bytes && h->n_seen + 1 < c.fir_taps) {
     // Designs Q, B and S read their halo as bytes, which cannot express the zero history at the start of a stream: the few audio
