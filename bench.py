@@ -290,7 +290,8 @@ def timed(torch, dist, use_dist, stream, step, steps, finish=None, rest=0.0):
     if finish is not None:
         finish()
     ev1.record(stream)
-    while not ev1.query():                                        # (the closing synchronize then returns at once: a blocking wait's wake-up latency is not part of K steps)
+    t_poll = time.perf_counter()
+    while not ev1.query() and time.perf_counter() - t_poll < 30.0:   # (the closing synchronize then returns at once: a blocking wait's wake-up latency is not part of K steps)
         pass
     fence()
     elapsed = time.perf_counter() - t0
