@@ -538,7 +538,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16
   // 0 = oldest), which closes the gap: 26.5 -> 25.7 us per call.  (For the whole run it over-corrects: the oldest waves end last.)
   // Not for overlapped calls — two kernels share the SIMDs there and the ranks mean something else: measured +0.3 us.  Priorities by
   // remaining steps (a wave that is behind outranks one that is ahead), alone or on top of the rank: no better (25.9 - 26.4 us).
+#ifdef SDRFM_Q_GUARD_L1
+  float guard_r = 2.0f * p.guard_r, guard_a = p.guard_a;
+#else
   float guard_r = p.guard_r, guard_a = p.guard_a;             // (in VGPRs: the loop's scalar registers are all taken)
+#endif
   asm volatile("" : "+v"(guard_r), "+v"(guard_a));
 #ifdef SDRFM_Q_SCALE_VGPR   // experiment (round 5): the recombination's factors in VGPRs (an FMA with an SGPR operand issues at half rate) — measured 0.2 us
   float q0v = p.q0, q2v = p.q2, cstv = p.cst;                  // per call SLOWER than leaving them in SGPRs (the kernel sits at its 128 VGPRs): profiles/r05_q_experiments.txt
@@ -629,10 +633,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16
     {
       float t0, t1, t2;
       unsigned long long fm, fm2;
+#ifdef SDRFM_Q_GUARD_L1   // experiment (round 5): |re| + |im| (a full-rate add) instead of max(|re|, |im|) against twice the radius: flags a superset
+      asm("v_add_f32_e64 %[t0], |%[y0]|, |%[y1]|\n\t"
+          "v_add_f32_e64 %[t1], |%[y2]|, |%[y3]|\n\t"
+          "v_add_f32_e64 %[t2], |%[pr]|, |%[pi]|\n\t"
+          "v_min3_f32 %[t0], %[t0], %[t1], %[t2]\n\t"
+#else
       asm("v_max_f32_e64 %[t0], |%[y0]|, |%[y1]|\n\t"
           "v_max_f32_e64 %[t1], |%[y2]|, |%[y3]|\n\t"
           "v_max_f32_e64 %[t2], |%[pr]|, |%[pi]|\n\t"
           "v_min3_f32 %[t0], %[t0], %[t1], %[t2]\n\t"
+#endif
           "v_max_f32_e64 %[t1], |%[d0]|, |%[d1]|\n\t"
           "v_cmp_lt_f32_e64 %[fm], %[t0], %[gr]\n\t"
           "v_cmp_gt_f32_e64 %[fm2], %[t1], %[ga]\n\t"
