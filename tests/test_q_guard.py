@@ -86,3 +86,24 @@ def test_guarded_emulation_at_the_other_front_end_rates(pkg, T, D, Da, fs):
         got, want, _ = qe.design_q_audio(iq, h, g, D=D, Da=Da, guard=guard)
         e = np.abs(got.astype(np.float64) - want) / np.maximum(np.abs(want), 1.0)
         assert e.max() <= 1e-6, (mode, e.max())
+
+
+@pytest.mark.parametrize("T", [64, 16])
+@pytest.mark.parametrize("cls", ["oob_carrier", "oob_carrier_fm", "weak_inband", "adjacent_plus_weak", "periodic"])
+def test_guarded_emulation_where_the_guard_is_thinnest(pkg, T, cls):
+    """strong out-of-band carriers with A |H(f)| between one and three guard radii (a neighbouring station: large partial sums, |y| just
+    above the radius, for whole audio windows), weak in-band carriers of 2 .. 8 LSB, both together, and periodic byte patterns whose chain roundings are
+    systematic (tools/q_classes.py) — through the emulation with the DEVICE's arctangent and its OWN chain repair, against the oracle at the plain criterion."""
+    import q_classes as qc
+    import q_emulate as qe
+    h, g = pkg.default_config(T)
+    guard = guard_of(pkg, h, g)
+    rng = np.random.default_rng(1000 * T + len(cls))
+    worst, st = 0.0, {}
+    for _ in range(3):
+        iq = qc.make_row(cls, 60000, h, guard[0], rng)
+        got, want, _ = qe.design_q_audio(iq, h, g, guard=guard, stats=st)
+        e = np.abs(got.astype(np.float64) - want) / np.maximum(np.abs(want), 1.0)
+        worst = max(worst, float(e.max()))
+    assert worst <= TOL, (cls, T, worst, st)
+    assert worst <= 2e-6, (cls, T, worst, st)                      # (measured: <= 1e-6; the tolerance is 1e-5)

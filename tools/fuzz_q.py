@@ -7,14 +7,17 @@ out (round 3's version excused ill-conditioned phases; since round 4 the kernel'
 uniform random bytes are in every case.  usage: fuzz_q.py [seconds] [seed]"""
 import importlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes as C
 import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import q_classes as qc
 pkg = importlib.import_module("stm32f7-rtlsdr_amd")
 from oracle.oracle import Oracle
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 t_end, cases, calls_q, fails, worst_exact, worst_oracle = time.time() + budget, 0, 0, 0, 0.0, 0.0
-calls_ovl = 0; lanes_repaired = 0
+calls_ovl = 0; lanes_repaired = 0; thin_rows = {}
 while time.time() < t_end:
     T = int(rng.choice([16, 32, 64, 64, 48, 90, 33]))
     D, Da, fs = [(10, 5, 2.4e6), (10, 5, 2.4e6), (8, 8, 2.048e6), (16, 5, 3.2e6)][int(rng.integers(4))]      # the three front-end rates design Q has instances for
@@ -42,6 +45,16 @@ while time.time() < t_end:
     nd = min(ns, 6)
     rows = np.concatenate([pkg.make_iq(max(nd - 2, 1), total, mode="fm", fs=fs, first_id=int(rng.integers(1 << 20))),
                            pkg.make_iq(2, total, mode=str(rng.choice(["random", "const", "counter"])), first_id=int(rng.integers(1 << 20)))])[:nd]
+    # round 5: where the guard is thinnest — strong out-of-band carriers with A |H(f)| in one .. three guard radii (with and without FM),
+    # weak in-band carriers, both together, periodic byte patterns (tools/q_classes.py) — in two cases out of three, on up to four of the distinct rows
+    thin = rng.random() < 0.67
+    if thin:
+        gr_, ga_ = C.c_float(), C.c_float()
+        hh, gg = np.ascontiguousarray(h, np.float32), np.ascontiguousarray(g, np.float32)
+        if pkg.load_library().sdrfm_q_guard(hh.ctypes.data, hh.size, gg.ctypes.data, gg.size, C.byref(gr_), C.byref(ga_)) == 0:
+            for s_ in range(min(nd, 4)):
+                cls_ = str(rng.choice(qc.CLASSES)); thin_rows[cls_] = thin_rows.get(cls_, 0) + 1
+                rows[s_] = qc.make_row(cls_, total, h, gr_.value, rng, fs=fs)
     stride = 2 * total + int(rng.choice([0, 16, 48, 2, 6]))
     dev = torch.zeros((ns, stride), dtype=torch.uint8, device="cuda")
     dev[:, :2 * total] = torch.from_numpy(np.tile(rows, ((ns + nd - 1) // nd, 1))[:ns]).cuda()
@@ -89,5 +102,5 @@ while time.time() < t_end:
             np.savez_compressed(os.path.join(os.environ["FUZZ_DUMP"], "case_%d_%d.npz" % (seed, cases)), h=h, g=g, ns=ns, stride=stride, rows=rows,
                                 sizes=np.array(sizes), resets=np.array([i for i, x in enumerate([e for e in log if e == "reset" or (isinstance(e, tuple) and isinstance(e[0], int))]) if x == "reset"]))
 print("design-Q soak: cases %d  calls served by fast-q %d (%d of them overlapped)  failures %d  worst vs bit-exact kernels %.3g  worst vs oracle %.3g  "
-      "lanes through the repair path %d  (seed %d, %.0f s; plain criterion, every output)" % (cases, calls_q, calls_ovl, fails, worst_exact, worst_oracle, lanes_repaired, seed, budget))
+      "lanes through the repair path %d  rows of the guard's thin-spot classes %s  (seed %d, %.0f s; plain criterion, every output)" % (cases, calls_q, calls_ovl, fails, worst_exact, worst_oracle, lanes_repaired, thin_rows, seed, budget))
 sys.exit(1 if fails else 0)

@@ -50,12 +50,51 @@ def fma32(a, b, c):
     return f32(f32(a).astype(np.float64) * f32(b).astype(np.float64) + f32(c).astype(np.float64))
 
 
-def design_q_audio(iq, h, g, ndig=3, D=10, Da=5, guard=None, stats=None):
+def q_atan2_dev(im, re):
+    """design Q's own arctangent (csrc/sdrfm_q.hip q_discriminate), fp32 operation by operation: the larger magnitude clamped at 2^-120, v = min / max through
+    a reciprocal (numpy's correctly rounded one: the device's v_rcp_f32 is within 1 ulp of it), the 6-coefficient minimax polynomial in v^2, the two
+    reflections, the sign of im.  (0, 0) -> 0 through the clamp."""
+    re, im = f32(re), f32(im)
+    ax, ay = np.abs(re), np.abs(im)
+    mx = np.maximum(np.maximum(ax, ay), np.float32(2.0 ** -120))
+    mn = np.minimum(ax, ay)
+    v = f32(mn * f32(np.float32(1.0) / mx))
+    s2 = f32(v * v)
+    q = np.full_like(v, np.float32(float.fromhex("0x1.e34882p-8")))
+    for c in ("-0x1.22fc74p-5", "0x1.509024p-4", "-0x1.12688cp-3", "0x1.96c562p-3", "-0x1.554086p-2"):
+        q = fma32(q, s2, np.float32(float.fromhex(c)))
+    a = fma32(v, f32(s2 * q), v)
+    a = np.where(ay > ax, f32(np.float32(float.fromhex("0x1.921fb6p+0")) - a), a)
+    a = np.where(re < 0, f32(np.float32(float.fromhex("0x1.921fb6p+1")) - a), a)
+    return np.copysign(a, im).astype(np.float32)
+
+
+def chain_y(iq, h, D, m):
+    """the DEFINITION's y[m] for the output indices m (all windows inside the stream): acc = fmaf(h[k], x, acc), oldest sample first, x = byte - 127.5 —
+    the repair path's arithmetic (csrc/sdrfm_q.hip repair_flagged), which is the oracle's (oracle/sdrfm_oracle.c) written out here independently"""
+    T = len(h)
+    b = iq.astype(np.float32)
+    x = np.stack([b[0::2], b[1::2]], axis=1) - np.float32(127.5)
+    m = np.asarray(m, dtype=np.int64)
+    acc = np.zeros((m.size, 2), np.float32)
+    for k in range(T - 1, -1, -1):                                  # oldest sample first: tap k meets sample (m + 1) D - 1 - k
+        acc = fma32(np.float32(h[k]), x[(m + 1) * D - 1 - k], acc)
+    return acc
+
+
+def host_discriminate(lib, yr, yi, pr, pi):
+    """the definition's K3 as the device's repair path evaluates it (sdrfm_math.h sdrfm_discriminate, same source and rounding: the library's host hook)"""
+    return np.array([lib.sdrfm_host_discriminate(float(a), float(b), float(c), float(d)) for a, b, c, d in zip(yr, yi, pr, pi)], dtype=np.float32)
+
+
+def design_q_audio(iq, h, g, ndig=3, D=10, Da=5, guard=None, stats=None, device_atan=True):
     """One stream from reset, zero history handled like the product does: the first outputs come from the exact spec (the
     generic kernel patches them), so only steady-state arithmetic is judged here.
     guard = (guard_r, guard_a) emulates the kernel's conditioning guard (csrc/sdrfm_q.hip): outputs are held in pairs (2 i, 2 i + 1) by one
     lane; a pair one of whose three y's (y[2 i - 1], y[2 i], y[2 i + 1]) has max(|re|, |im|) < guard_r, or one of whose |d|'s exceeds
-    guard_a, gets both d's from the definition's own y's (the oracle's).  stats (a dict) receives the number of repaired pairs."""
+    guard_a, gets both d's from the definition's chain recomputed HERE from the raw bytes (chain_y) and the definition's discriminator (round 5;
+    round 4 took them from the oracle, which checked the flagging rule but not the repair arithmetic).  device_atan: the unflagged d's use design Q's
+    own 6-coefficient arctangent (q_atan2_dev), not libm's.  stats (a dict) receives the number of repaired pairs."""
     T, Ta = len(h), len(g)
     b = iq.astype(np.int64)
     xi8 = np.stack([b[0::2] - 128, b[1::2] - 128], axis=1)          # [N, 2]
@@ -93,7 +132,7 @@ def design_q_audio(iq, h, g, ndig=3, D=10, Da=5, guard=None, stats=None):
     yr, yi, pr, pi = y[:, 0], y[:, 1], prev[:, 0], prev[:, 1]
     re = fma32(yr, pr, f32(yi * pi))
     im = f32(f32(yi * pr) - f32(yr * pi))
-    d = np.where((re == 0) & (im == 0), np.float32(0), np.arctan2(im, re).astype(np.float32))
+    d = q_atan2_dev(im, re) if device_atan else np.where((re == 0) & (im == 0), np.float32(0), np.arctan2(im, re).astype(np.float32))
     if guard is not None:
         gr_, ga_ = np.float32(guard[0]), np.float32(guard[1])
         linf = np.maximum(np.abs(y[:, 0]), np.abs(y[:, 1]))
@@ -102,11 +141,23 @@ def design_q_audio(iq, h, g, ndig=3, D=10, Da=5, guard=None, stats=None):
         small = np.minimum(np.minimum(linf_p[0:Mp:2], linf[0:Mp:2]), linf[1:Mp:2]) < gr_
         cut = np.maximum(np.abs(d[0:Mp:2]), np.abs(d[1:Mp:2])) > ga_
         flag = np.repeat(small | cut, 2)
-        yprev_o = np.vstack([np.zeros((1, 2), np.float32), yo[:-1]])
-        re_o = fma32(yo[:, 0], yprev_o[:, 0], f32(yo[:, 1] * yprev_o[:, 1]))
-        im_o = f32(f32(yo[:, 1] * yprev_o[:, 0]) - f32(yo[:, 0] * yprev_o[:, 1]))
-        d_o = np.where((re_o == 0) & (im_o == 0), np.float32(0), np.arctan2(im_o, re_o).astype(np.float32))
-        d[:Mp][flag] = d_o[:Mp][flag]
+        # the repair: the three y's under a flagged pair by the definition's chain FROM THE BYTES (not taken from the oracle), the definition's discriminator as
+        # the library evaluates it; the stream's first outputs (windows reaching before sample 0) keep the oracle's y, as the product's generic kernel patches them
+        pairs = np.nonzero(small | cut)[0]
+        if pairs.size:
+            mm = np.unique(np.concatenate([2 * pairs - 1, 2 * pairs, 2 * pairs + 1]))
+            mm = mm[(mm >= 0) & (mm < M)]
+            inside = ok[mm]
+            yc = np.array(yo[mm], dtype=np.float32)
+            if inside.any():
+                yc[inside] = chain_y(iq, h, D, mm[inside])
+            lut = {int(v): i for i, v in enumerate(mm)}
+            lib = pkg.load_library()
+            for o in (0, 1):
+                mo = 2 * pairs + o
+                cur = yc[[lut[int(v)] for v in mo]]
+                prv = np.array([yc[lut[int(v) - 1]] if int(v) > 0 else (0.0, 0.0) for v in mo], dtype=np.float32).reshape(-1, 2)
+                d[mo] = host_discriminate(lib, cur[:, 0], cur[:, 1], prv[:, 0], prv[:, 1])
         if stats is not None:
             stats["pairs"] = stats.get("pairs", 0) + Mp // 2
             stats["repaired"] = stats.get("repaired", 0) + int((small | cut).sum())
