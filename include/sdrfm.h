@@ -29,8 +29,16 @@
  * definition's fp32 chain, i.e. within 1e-6 of the definition's AUDIO wherever the phase of y[m] conj(y[m-1]) is well conditioned; where
  * it is not — |y| small (a deep fade: noise-only input gets there, a carrier does not) or d within reach of +-pi (the branch cut) — its
  * conditioning guard recomputes the affected d's with the definition's own chain from the raw bytes, so that they are the bit-identical
- * kernels' d's.  The audio of every kernel is therefore within the 1e-5 tolerance (|a - b| <= 1e-5 max(|b|, 1), for audio taps of about
- * unit absolute sum) of the definition for ANY input bytes; measured <= 7e-7 on every input class.
+ * kernels' d's.  How far "within reach" goes rests on a bound E on |y_fast-q - y_definition| that is STATISTICAL: E = 1.25 sqrt(T) 127.5 sum|h| 2^-24
+ * (csrc/qtaps.c; 28 standard deviations of what uniform random bytes produce, 9 of a full-scale carrier's), where the chain's worst case —
+ * every one of its T roundings falling the same way — is T 127.5 sum|h| 2^-24, 6.4 times as much at T = 64.  So "fast-q" within the 1e-5
+ * tolerance (|a - b| <= 1e-5 max(|b|, 1), for audio taps of about unit absolute sum) is a measured statement, not a proven one: no
+ * violation, worst 8.4e-7, in the device soak over every input class — uniform random bytes, constant and counter bytes, carriers, and
+ * the classes built to probe the bound (strong out-of-band carriers at one to three guard radii, 2 - 8 LSB carriers, periodic byte
+ * patterns: tools/q_classes.py, profiles/r05_fuzz_q.txt).  SDRFM_CFG_BIT_EXACT is the guarantee: the bit-identical kernels only.
+ * A stream whose windows of calls are mostly repair work (noise only) is moved to the bit-identical kernels for a while, per stream
+ * (DESIGN.md 4.Q "routing"); which kernel serves a stream at a given call depends on when the device's statistics are noticed — every
+ * choice is within the tolerance, none waits for the device.
  *
  * There is NO CPU fallback in this library: every entry point that computes runs hand-written HIP kernels
  * on a gfx950 device and fails with SDRFM_NO_DEVICE when none is usable.
@@ -71,13 +79,17 @@ enum {
                                        never the matrix-pipe kernel ("fast-q"), whose audio is within the tolerance of that definition for any
                                        input (see above) but not bit-identical to it.  Without the flag "fast-q" serves low-pass channel
                                        filters of up to 64 taps (sum|h| <= 2 |sum h|: a performance rule, not a correctness condition) at
-                                       D = 10, 32 audio taps / 5 — unless the stream turns out to be noise only, which the bit-identical
-                                       kernels serve faster; every other configuration runs the bit-identical kernels anyway */
+                                       D = 10, 32 audio taps / 5 (and at D = 8 / 8, D = 16 / 5) — but for the streams that turn out to be
+                                       noise only, which the bit-identical kernels serve faster: those are routed to them per stream;
+                                       every other configuration runs the bit-identical kernels anyway */
 #define SDRFM_CFG_NO_ZEROCOPY   2u  /* URB-sized host calls use the staged H2D/D2H path instead of mapped host memory (tests) */
 
 /* flags for sdrfm_process_batch */
 #define SDRFM_F_DEVICE_PTRS 1u    /* iq and audio are device pointers on cfg.device; call is enqueued on the
-                                     handle's stream and returns without synchronising.  The handle's own stream is
+                                     handle's stream and returns without synchronising or waiting for the device in any way
+                                     (rounds 3 - 4 could wait on an event of an earlier window of calls here; since round 5 the
+                                     per-stream statistics are read back on a side stream and looked at with hipEventQuery:
+                                     tests/test_route_gpu.py test_calls_return_without_waiting_for_the_device).  The handle's own stream is
                                      created non-blocking: it does NOT order itself against the null stream or any
                                      other stream, so work that produces iq or touches audio elsewhere must be
                                      synchronised by the caller, or the caller's stream given via sdrfm_set_stream */

@@ -8,7 +8,10 @@ bytes (SURVEY.md 8d's worst-case class).
   q_guard_deep_fade_T32.npz    seed 7 case 217, row 1, samples 500000 .. 532000 of 3.9 M: the 32-tap default filter; output 1804 of the cut
                                (51804 of the case) has |y| = 0.0035 against a median of 22: an unguarded design Q is 1.16e-5 off in one audio sample.
 
-usage: make_golden_q_guard.py case_7_1033.npz case_7_217.npz   (the soak's dumps; not kept in the repo — 15 MB).  Expected audio = the oracle's."""
+usage: make_golden_q_guard.py case_7_1033.npz case_7_217.npz   (the soak's dumps; not kept in the repo — 15 MB).  Expected audio = the oracle's.
+       make_golden_q_guard.py --regenerate [--check]       from a clean checkout: the taps, bytes, call sizes and resets are read from the committed fixtures
+                                                            themselves and the expected audio is re-derived from them with the oracle (--check: compare with
+                                                            what the fixtures hold instead of rewriting them; exit status 1 on a difference)."""
 import os
 import sys
 
@@ -40,5 +43,21 @@ def main(a, b):
                         audio=expected(z["h"], z["g"], row, sizes, set()))
 
 
+def regenerate(check):
+    ok = True
+    for name in ("q_guard_branch_cut_T64.npz", "q_guard_deep_fade_T32.npz"):
+        path = os.path.join(HERE, name)
+        z = np.load(path)
+        audio = expected(z["h"], z["g"], z["iq"], [int(x) for x in z["sizes"]], {int(x) for x in z["reset_before"]})
+        same = np.array_equal(audio.view(np.uint32), z["audio"].view(np.uint32))
+        print("%s: %d audio samples, %s the committed ones" % (name, audio.size, "bit-identical to" if same else "DIFFERENT from"))
+        ok = ok and same
+        if not check:
+            np.savez_compressed(path, h=z["h"], g=z["g"], iq=z["iq"], sizes=z["sizes"], reset_before=z["reset_before"], audio=audio)
+    return ok
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--regenerate":
+        sys.exit(0 if regenerate("--check" in sys.argv[2:]) else 1)
     main(*sys.argv[1:3])

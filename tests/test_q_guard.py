@@ -107,3 +107,11 @@ def test_guarded_emulation_where_the_guard_is_thinnest(pkg, T, cls):
         worst = max(worst, float(e.max()))
     assert worst <= TOL, (cls, T, worst, st)
     assert worst <= 2e-6, (cls, T, worst, st)                      # (measured: <= 1e-6; the tolerance is 1e-5)
+
+
+def test_the_guard_fixtures_regenerate_from_a_clean_checkout():
+    """the expected audio of tests/golden/q_guard_*.npz is re-derived from the bytes the fixtures themselves hold (no soak dump needed)."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(GOLD, "make_golden_q_guard.py"), "--regenerate", "--check"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("bit-identical") == 2, r.stdout
