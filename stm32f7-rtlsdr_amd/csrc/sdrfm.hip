@@ -1533,6 +1533,7 @@ struct sdrfm {
   hipEvent_t rt_bx_evt[2]; uint32_t rt_bx_slot; hipStream_t rt_bx_last;   // the bit-exact sub-launches: completion events (stop events), and the stream the latest went to
                                                                 // (each takes the state the one before left: on another stream it waits for that one's event)
   bool rt_off;                                                  // (development: design Q whatever the streams hold)
+  bool rt_anyorder;                                             // the noisy streams' launch goes out behind design Q's with hipExtAnyOrderLaunch (no barrier bit)
   // SDRFM_F_OVERLAP: two internal streams taken in turn, so that consecutive calls run concurrently on the device (a call's ramp-up
   // under the previous call's tail).  ovl_in orders a call behind what the handle's stream holds when it is made; join_overlap()
   // records ovl_done[k] behind the calls put on internal stream k and makes the handle's stream wait for it.
@@ -1589,6 +1590,7 @@ static int route_create(sdrfm* h) {
   // with the launch ahead of design Q's on the call's own stream.)
   HIP_TRY(hipStreamCreateWithFlags(&h->rt_mon, hipStreamNonBlocking), SDRFM_ENOMEM);
   h->rt_next_retry = ~0ull;
+  h->rt_anyorder = true;
   return SDRFM_OK;
 }
 
@@ -2225,13 +2227,16 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
     if (per_cu < 1) per_cu = 1;
     bx_waves = h->n_cu * per_cu;
   }
-  if (bx_all || mixed) {
+  // (the bit-exact launch as a closure: it goes out ahead of design Q's launch, or — any-order launches, below — right behind it)
+  bool bx_anyorder_now = false;
+  auto launch_bx = [&]() -> int {
     // ---- the bit-exact kernels: every stream (on the handle's stream), or the noisy streams beside design Q's launch: on their own internal stream, in
     // order among themselves (each takes the state the previous one left); a call made without SDRFM_F_OVERLAP forks that stream off the handle's stream
     // and joins it again, so that the handle's stream is behind both launches when the call returns
     const uint32_t nsub = bx_all ? ns_all : n_noisy;
     hipStream_t bs = h->stream;
     hipEvent_t bdone = nullptr;                                   // mixed: the launch's own completion event (a stop event: no marker packet)
+    const uint32_t bflags = bx_anyorder_now ? (uint32_t)hipExtAnyOrderLaunch : 0u;
     if (mixed) {
       // The noisy streams' launch goes ahead of design Q's on the call's own stream: no third stream (streams of one priority share a small pool of
       // hardware queues — one was seen on the queue of the handle's stream, and every dependence across queues costs ~10 us of a queue's time), no
@@ -2240,7 +2245,7 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
       bs = (ovl && h->rt_bx) ? h->rt_bx : qs;                      // (overlapped calls: beside both internal streams' launches, on the stream with a queue of its own)
       if (bs == h->rt_bx) { h->rt_bx_pending = true; if (behind_in) HIP_TRY(hipStreamWaitEvent(bs, h->ovl_in, 0), SDRFM_FAIL); }
       bdone = h->rt_bx_evt[h->rt_bx_slot]; h->rt_bx_slot ^= 1u;
-      if (h->rt_bx_last && h->rt_bx_last != bs) HIP_TRY(hipStreamWaitEvent(bs, h->rt_bx_evt[h->rt_bx_slot], 0), SDRFM_FAIL);   // (the slot just left: the previous launch's event)
+      if (!bx_anyorder_now && h->rt_bx_last && h->rt_bx_last != bs) HIP_TRY(hipStreamWaitEvent(bs, h->rt_bx_evt[h->rt_bx_slot], 0), SDRFM_FAIL);   // (the slot just left: the previous launch's event)
       h->rt_bx_last = bs;
       p.slist = list_dev + n_clean;
     }
@@ -2258,7 +2263,7 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
       const uint32_t segs = N / h->fast_s->seg;
       p.tiles_per_stream = (segs + 62) / 63;                      // waves per stream: 63 useful lane segments each
       p.fold_state = 1;
-      hipExtLaunchKernelGGL(h->fast_s->kernel[0], dim3(nsub * p.tiles_per_stream), dim3(64), h->fast_s->xbytes, bs, nullptr, bdone, 0, p);
+      hipExtLaunchKernelGGL(h->fast_s->kernel[0], dim3(nsub * p.tiles_per_stream), dim3(64), h->fast_s->xbytes, bs, nullptr, bdone, bflags, p);
       bname = h->fast_s_name; halo_bytes = true;
     } else if (fast_ok) {
       // split every stream into segments so that ~waves_target waves are resident; each segment >= min_subtiles sub-tiles
@@ -2282,17 +2287,24 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
       // new history, and the last sub-tile must contain y[M-1], which the kernel arranges)
       p.fold_state = (fv->kind == 'b' && M >= c.audio_taps && h->fold_state_ok) ? 1u : 0u;
       if (p.fold_state) grid -= nsub;
-      hipExtLaunchKernelGGL(fv->kernel[fv == h->fast ? h->fast_mode : 0], dim3(grid), dim3(64), flds, bs, nullptr, bdone, 0, p);
+      hipExtLaunchKernelGGL(fv->kernel[fv == h->fast ? h->fast_mode : 0], dim3(grid), dim3(64), flds, bs, nullptr, bdone, bflags, p);
       bname = h->fast_name; halo_bytes = halo_bytes || fv->kind == 'b';
     } else {
       p.NA = h->NA;
       p.tiles_per_stream = (A + h->NA - 1) / h->NA;
       const uint32_t grid = nsub * p.tiles_per_stream + nsub;
-      hipExtLaunchKernelGGL(k_generic, dim3(grid), dim3(256), h->lds_bytes, bs, nullptr, bdone, 0, p);
+      hipExtLaunchKernelGGL(k_generic, dim3(grid), dim3(256), h->lds_bytes, bs, nullptr, bdone, bflags, p);
     }
     bx_name = bname;
     p.slist = nullptr; p.n_streams = ns_all;
-  }
+    return SDRFM_OK;
+  };
+  // hipExtAnyOrderLaunch: the noisy streams' launch carries no barrier bit, so it starts beside the design-Q launch that precedes it in the SAME queue (which
+  // waited for everything before it): both share the machine from the first microsecond without a second queue or a dependence between queues.
+  const bool bx_anyorder = mixed && h->rt_anyorder;
+  if ((bx_all || mixed) && !bx_anyorder) { const int brc = launch_bx(); if (brc != SDRFM_OK) return brc; }
+  // (any-order: the wait for the previous such launch — on the other internal stream — has to sit ahead of design Q's launch, whose barrier bit honours it)
+  if (bx_anyorder && h->rt_bx_last && h->rt_bx_last != qs) HIP_TRY(hipStreamWaitEvent(qs, h->rt_bx_evt[h->rt_bx_slot ^ 1u], 0), SDRFM_FAIL);
   if (q_ok) {
     SdrfmQParams q;
     q.iq_prev = nullptr; q.iq_prev_stride = 0; q.N_prev = 0;
@@ -2357,6 +2369,7 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
     }
     snprintf(q_name, sizeof(q_name), "%s%s", h->fast_q_name, ovl ? " overlapped" : "");
   }
+  if (bx_anyorder) { bx_anyorder_now = true; const int brc = launch_bx(); if (brc != SDRFM_OK) return brc; }
   if (mixed) {
     const char* sp = strchr(bx_name, ' ');                         // ("fast-b", "fast-s", "generic": the name's first word)
     snprintf(h->kernel_name, sizeof(h->kernel_name), "%s + %.*s (%u streams)", q_name, (int)(sp ? sp - bx_name : (long)strlen(bx_name)), bx_name, n_noisy);
