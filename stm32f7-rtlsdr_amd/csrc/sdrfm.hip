@@ -1590,7 +1590,7 @@ static int route_create(sdrfm* h) {
   // with the launch ahead of design Q's on the call's own stream.)
   HIP_TRY(hipStreamCreateWithFlags(&h->rt_mon, hipStreamNonBlocking), SDRFM_ENOMEM);
   h->rt_next_retry = ~0ull;
-  h->rt_anyorder = true;
+  h->rt_anyorder = false;                                        // (measured on gfx950: the flag is ignored — hip_ext.h says as much for GFX9 — and the order design Q, design B is the slower one: profiles/r05_mixed_batches.txt)
   return SDRFM_OK;
 }
 
