@@ -1549,7 +1549,7 @@ struct sdrfm {
 
 static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nbytes, float* d_audio, size_t audio_stride,
                    uint32_t* n_audio, uint32_t call_flags = 0);
-#define SDRFM_Q_ADAPT_WINDOW 8u      /* design-Q calls between two looks at the sampled repair statistics */
+#define SDRFM_Q_ADAPT_WINDOW 16u     /* design-Q calls per window of per-stream repair statistics (8 in rounds 3 - 4: a window that closes at the third call of a burst from rest meets a host that is barely ahead of the device) */
 #define SDRFM_Q_ADAPT_BACKOFF 1024u  /* eligible calls served by the bit-exact kernels after a window of noise-like input */
 static int join_overlap(sdrfm* h);
 static int route_create(sdrfm* h);
