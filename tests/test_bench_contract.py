@@ -31,12 +31,12 @@ def test_traffic_lookup_matches_kernel_and_workload_size():
 
 def test_newest_round_traffic_feeds_the_headline_kernel():
     """The default bench line (design Q, configs[2]) takes `roofline.traffic` from the newest committed counter passes of the same kernel and size
-    (round 4: taken at the final kernel commit, with the conditioning guard in)."""
+    (round 5: re-taken at the final kernel commit — runs cut in quads, the audio taps' LDS table)."""
     b = _bench()
-    head = json.load(open(os.path.join(ROOT, "profiles", "traffic_r04b.json")))      # (re-taken at the round's last kernel commit)
+    head = json.load(open(os.path.join(ROOT, "profiles", "traffic_r05.json")))       # (re-taken at the round's last kernel commit)
     assert head["kernel_name"].startswith("fast-q") and "k_mfir" in head["rocprof_kernel"]
     t = b.latest_traffic(head["kernel_name"], head["algorithmic_bytes_per_launch"])
-    assert t is not None and t["file"].startswith(("traffic_r04b", "r04b_")) and t["hbm_bytes_per_launch"] == head["hbm_bytes_per_launch"]
+    assert t is not None and t["file"].startswith(("traffic_r05", "r05_")) and t["hbm_bytes_per_launch"] == head["hbm_bytes_per_launch"]
     assert 1.0 <= t["hbm_bytes_per_launch"] / head["algorithmic_bytes_per_launch"] < 1.06       # warm-up re-reads: ~2 % of the bytes
     # the pipe figures of the kernels that are not bound by the HBM come from the same round's passes
     d = b.latest_pmc_derived("wbfm-fused (k_wbfm_steps<8,10>)")
@@ -51,7 +51,7 @@ def test_newest_round_traffic_feeds_the_headline_kernel():
 def test_traffic_never_below_algorithmic_bytes():
     """A committed summary whose traffic is below the algorithmic bytes would mean a broken counter pass."""
     import glob
-    for fn in glob.glob(os.path.join(ROOT, "profiles", "r0[234]*_pmc.json")):
+    for fn in glob.glob(os.path.join(ROOT, "profiles", "r0[2345]*_pmc.json")):
         d = json.load(open(fn))
         assert d["hbm_bytes_per_launch"] >= 0.999 * d["algorithmic_bytes_per_launch"], fn
         assert d.get("commit") and d["commit"] != "wip", fn
@@ -63,3 +63,13 @@ def test_rotation_exceeds_the_infinity_cache():
         nb = b.pick_batches(types.SimpleNamespace(batches=0), bytes_per_batch)
         assert nb >= 3 and (nb - 1) * bytes_per_batch > 1.5 * b.L3_BYTES      # between two uses of a batch: more than the L3 holds
     assert b.pick_batches(types.SimpleNamespace(batches=7), 1) == 7
+
+
+def test_mixed_input_class_spreads_the_noisy_streams_evenly():
+    """bench.py --iq-class mixed:P: P per cent of the streams, evenly spread, hold noise (the per-stream routing's workload)."""
+    b = _bench()
+    for ns, pct in ((256, 5), (256, 10), (256, 25), (512, 10)):
+        rows = b.noisy_rows(ns, pct)
+        assert abs(len(rows) - ns * pct / 100.0) <= 1.0, (ns, pct, len(rows))
+        gaps = [y - x for x, y in zip(rows, rows[1:])]
+        assert max(gaps) - min(gaps) <= 1, (ns, pct)
