@@ -437,10 +437,12 @@ def main():
     # INCLUDING any inter-launch gap; per-launch event timings come from a short untimed pass afterwards.
     kernel_ms_ovl = kernel_ms_ovl_sus = None
     served_by = None
+    routed_timed = routed_kernel = None
     serial_regions = None
     if overlap:
         elapsed, kernel_ms_ovl = timed(torch, dist, use_dist, stream, step_ovl, args.steps, finish=dm.flush)
         served_by = dm.kernel_name
+        routed_timed, routed_kernel = dm.route(), served_by      # (the assignment the timed region ran with: a stream is tried on design Q again every 1024 calls)
         if "overlapped" not in served_by:                        # a handle the matrix-pipe kernel does not serve (--bit-exact, other taps): the
             overlap = False                                      # library makes the calls one after the other; time them as such (below)
     if overlap:
@@ -458,6 +460,7 @@ def main():
         kernel_ms_avg = sorted(serial_regions)[len(serial_regions) // 2]
     else:
         elapsed, kernel_ms_avg = timed(torch, dist, use_dist, stream, step_rot, args.steps)
+        routed_timed, routed_kernel = dm.route(), dm.kernel_name
     n_audio = last["n"]
     kernel_ms = per_launch_events(torch, stream, step_rot, min(args.steps, 20))
     # sustained figure: at least 300 back-to-back steps (a short timed region runs at the boost clock)
@@ -561,11 +564,12 @@ def main():
                             if serial_regions and len(serial_regions) > 1 else {})},
             "gen_seconds": round(t_gen, 2),
         }
-        routed = dm.route()
+        routed = routed_timed
         if routed is not None and (args.iq_class != "fm" or int(routed.sum())):
-            res["routing"] = {"streams_on_bit_exact_kernels": int(routed.sum()), "streams": ns, "kernels_last_call": dm.kernel_name,
-                              "note": "per-stream routing (DESIGN.md 4.Q): streams whose windows of design-Q calls were mostly repair work are served by the "
-                                      "bit-exact kernels, a launch of their own beside design Q's"}
+            res["routing"] = {"streams_on_bit_exact_kernels": int(routed.sum()), "streams": ns, "kernels_timed_region": routed_kernel,
+                              "note": "per-stream routing (DESIGN.md 4.Q), as the timed region ended: streams whose windows of design-Q calls were mostly repair "
+                                      "work are served by the bit-exact kernels — design B workgroups inside design Q's launch (k_mix) for the BASELINE shape, "
+                                      "a launch of their own ahead of design Q's for the others"}
         if guard:
             res["guard"] = {"guard_r": round(guard["guard_r"], 4), "pi_minus_guard_a": round(3.141592653589793 - guard["guard_a"], 7),
                             "lanes_repaired_since_create": guard["lanes"], "repair_passes_since_create": guard["passes"],

@@ -68,6 +68,13 @@ int sdrfm_q_blocks_per_cu(uint32_t first_chunk, uint32_t nslot, uint32_t d, uint
 // done != nullptr: the event is signalled by the kernel's own completion (hipExtLaunchKernelGGL's stop event: no marker packet in the queue).
 hipError_t sdrfm_q_launch(const SdrfmQParams& p, uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da, hipStream_t stream, hipEvent_t done = nullptr);
 const char* sdrfm_q_kernel_symbol(uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da);
+// ---- one launch for a mixed batch (sdrfm_q.hip: k_mix): b_blocks design-B workgroups (tile R = b_R; b as k_fastb takes it, fold_state = 1) over the
+// streams of b.slist, then q.n_streams * q.runs design-Q workgroups.  An instance exists for the BASELINE shape (LDS bytes of one workgroup; 0 = none).
+struct CallParams;   // sdrfm_b.h
+uint32_t sdrfm_q_mix_lds(uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da, uint32_t T, uint32_t b_R);
+int sdrfm_q_mix_blocks_per_cu(uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da, uint32_t T, uint32_t b_R);
+hipError_t sdrfm_q_launch_mix(const SdrfmQParams& q, uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da, const CallParams& b, uint32_t b_blocks,
+                              uint32_t b_R, hipStream_t stream, hipEvent_t done);
 // yprev[s] = the definition's y[-1] of stream s from the SDRFM_Q_TP raw samples in hist_q (a bit-exact kernel takes over from design Q)
 // (of the streams list[0 .. n_streams), or of streams 0 .. n_streams-1 when list is nullptr)
 hipError_t sdrfm_q_fix_yprev(const uint8_t* hist_q, const float* hpad, float2* yprev, uint32_t n_streams, const uint32_t* list, hipStream_t stream);

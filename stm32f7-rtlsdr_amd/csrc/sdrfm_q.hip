@@ -46,6 +46,7 @@
 
 #include "sdrfm_math.h"
 #include "sdrfm_q.h"
+#include "sdrfm_b.h"
 
 typedef int qi4_t __attribute__((ext_vector_type(4)));
 typedef int qi8_t __attribute__((ext_vector_type(8)));
@@ -132,8 +133,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 #define Q_PHASE(i) do { } while (0)
 #endif
 
+// The body of one workgroup (one wave): `bid` is its index among the launch's design-Q workgroups (the kernel's bid, or — in k_mix
+// below — its index among the workgroups that run this body).
 template <int C0, int NSLOT, int D, int DA>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16 ? 3 : 4))) k_mfir(SdrfmQParams p) {
+__device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t bid) {
   using G = QGeo<D, DA>;
   [[maybe_unused]] constexpr int NCH = G::NCH;
   constexpr int QD = D, QDA = DA, NSC = G::NSC, BLKB = G::BLKB, STEPB = G::STEPB, PRE = G::PRE, DBW = G::DBW, RWIN = G::RWIN;
@@ -146,7 +149,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16
   float* const ab = db + DBW;                                   // parked audio outputs
   unsigned short* const fl16 = reinterpret_cast<unsigned short*>(ab + ABW);   // lanes waiting for the repair path: (step slot + 1) << 6 | lane
   const int lane = (int)threadIdx.x, n = lane & 15, g = lane >> 4;
-  const uint32_t si = blockIdx.x / p.runs, run = blockIdx.x - si * p.runs;
+  const uint32_t si = bid / p.runs, run = bid - si * p.runs;
   const uint32_t stream = p.slist ? p.slist[si] : si;             // (round 5: a launch may serve a list of the handle's streams)
   // Runs are cut in QUADS of four blocks (32 outputs = the warm-up a run needs: QTA - 1 d's and the y before them; 4 BLKB bytes = whole
   // 128-byte lines).  Every wave but the stream's first one (when that takes the carried state) walks one warm-up quad before what it
@@ -160,7 +163,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16
   if (q0 >= q1) return;
   if (lane == 0) *reinterpret_cast<uint2*>(fl16 + 128) = make_uint2(0u, 0u);   // repair statistics of this wave (before any LDS-DMA is in flight: no wait)
 #ifdef SDRFM_Q_STAMPS   // development harness (tools/qbench): per-wave time stamps, 8 words per wave
-  unsigned long long* const tsp = p.dbg ? p.dbg + 16 * (size_t)blockIdx.x : nullptr;
+  unsigned long long* const tsp = p.dbg ? p.dbg + 16 * (size_t)bid : nullptr;
   unsigned long long t_wait = 0, t_first = 0;
   const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
   const unsigned long long c_entry = __builtin_readcyclecounter();
@@ -781,6 +784,26 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16
 #endif
 }
 
+
+template <int C0, int NSLOT, int D, int DA>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16 ? 3 : 4))) k_mfir(SdrfmQParams p) {
+  mfir_body<C0, NSLOT, D, DA>(p, blockIdx.x);
+}
+
+// =================================================================================================================
+//  One launch for a mixed batch (round 5, DESIGN.md 4.Q "Routing"): the first `nb` one-wave workgroups run design B (sdrfm_b.h: the bit-exact
+//  kernel with the smallest tile, R = 4) over the noise-only streams of b.slist, the others design Q over the streams of q.slist.  Two launches
+//  on one queue run one after the other (the barrier bit), two queues cost a dependence between queues (~10 - 18 us each: profiles/
+//  r05_mixed_batches.txt); one grid holds both kinds of wave on every CU from the first microsecond.  The long waves (design B: about twice
+//  design Q's work per stream) have the low workgroup numbers, so they are dispatched first.  Each body is the one its own kernel runs: the
+//  bits a stream gets do not depend on what shares the launch.
+// =================================================================================================================
+template <int C0, int NSLOT, int D, int DA, int T, int R>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) k_mix(SdrfmQParams q, CallParams b, uint32_t nb) {
+  if (blockIdx.x < nb) fastb_body<T, D, R, (int)SDRFM_Q_TA, DA, 0>(b, blockIdx.x);
+  else mfir_body<C0, NSLOT, D, DA>(q, blockIdx.x - nb);
+}
+
 // y[-1] as the definition has it, from the 64 raw samples before the next call (hist_q) — for a bit-exact kernel that takes over from
 // design Q (whose own carried y[-1] is only within 1e-4 of it).  One lane per stream; the chain of sdrfm_math.h / DESIGN.md "Frozen spec".
 __global__ void __launch_bounds__(64) k_q_fix_yprev(const uint8_t* hist_q, const float* hpad, float2* yprev, uint32_t n_streams, const uint32_t* list) {
@@ -843,7 +866,44 @@ const QVariant* q_find(uint32_t c0, uint32_t nslot, uint32_t d, uint32_t da) {
   return nullptr;
 }
 
+// ---- the one-launch kernel of a mixed batch: the BASELINE shape only (other shapes launch the two kernels one after the other) ------------------
+typedef void (*MixKernel)(SdrfmQParams, CallParams, uint32_t);
+struct MixVariant { uint32_t c0, nslot, d, da, T, R, lds; MixKernel k; };
+template <int T, int D, int R, int TA>
+constexpr uint32_t b_lds() { return (uint32_t)fastb_xbytes(T, D, R) + 4u * (uint32_t)(((TA - 1 + 3) & ~3) + 64 * R + T + TA); }   // as sdrfm.hip sizes design B's workgroup
+template <int C0, int NSLOT, int D, int DA, int T, int R>
+constexpr uint32_t mix_lds() { return q_lds<D, DA, NSLOT>() > b_lds<T, D, R, (int)SDRFM_Q_TA>() ? q_lds<D, DA, NSLOT>() : b_lds<T, D, R, (int)SDRFM_Q_TA>(); }
+#define MV(C0_, NS_, D_, DA_, T_, R_) { C0_, NS_, D_, DA_, T_, R_, mix_lds<C0_, NS_, D_, DA_, T_, R_>(), k_mix<C0_, NS_, D_, DA_, T_, R_> }
+const MixVariant kMixVariants[] = {MV(0, 5, 10, 5, 64, 4)};   // (design B's tile R = 8 — 12.9 KB of LDS — measured no faster than R = 4)
+
+const MixVariant* mix_find(uint32_t c0, uint32_t nslot, uint32_t d, uint32_t da, uint32_t T, uint32_t R) {
+  if (c0 > 1) c0 = 1;
+  for (const MixVariant& v : kMixVariants)
+    if (v.c0 == c0 && v.nslot == nslot && v.d == d && v.da == da && v.T == T && v.R == R) return &v;
+  return nullptr;
+}
+
 }  // namespace
+
+uint32_t sdrfm_q_mix_lds(uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da, uint32_t T, uint32_t R) {
+  const MixVariant* v = mix_find(first_chunk, nslot, d, da, T, R);
+  return v ? v->lds : 0u;
+}
+
+int sdrfm_q_mix_blocks_per_cu(uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da, uint32_t T, uint32_t R) {
+  const MixVariant* v = mix_find(first_chunk, nslot, d, da, T, R);
+  int nb = 0;
+  if (!v || hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(v->k), 64, v->lds) != hipSuccess) return 0;
+  return nb;
+}
+
+hipError_t sdrfm_q_launch_mix(const SdrfmQParams& q, uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da, const CallParams& b, uint32_t b_blocks,
+                              uint32_t b_R, hipStream_t stream, hipEvent_t done) {
+  const MixVariant* v = mix_find(first_chunk, nslot, d, da, b.T, b_R);
+  if (!v || b.Ta != SDRFM_Q_TA || b.Da != da || b.D != d) return hipErrorInvalidValue;
+  hipExtLaunchKernelGGL(v->k, dim3(b_blocks + q.n_streams * q.runs), dim3(64), v->lds, stream, nullptr, done, 0, q, b, b_blocks);
+  return hipGetLastError();
+}
 
 uint32_t sdrfm_q_default_nslot(uint32_t d) { return d == 10 ? 5u : (d == 8 ? 4u : (d == 16 ? 8u : 0u)); }
 

@@ -3,7 +3,8 @@
 256 real dongles are not all tuned to a station: the reference's front end tunes one fixed frequency
 (Middlewares/ST/STM32_USB_Host_Library/Class/RTLSDR/Src/tuner_e4k.c:1097) and hands over whatever is there (usbh_rtlsdr.c:1058-1101).  A noise-only stream
 sends design Q to its repair path at almost every audio stage, and a kernel lasts as long as its slowest wave — so the streams whose windows of design-Q
-calls are mostly repair work are served by the bit-exact kernels (a launch of their own, beside design Q's launch over the others).  Checked here: the
+calls are mostly repair work are served by the bit-exact kernels: design-B workgroups inside design Q's launch (the BASELINE shape: csrc/sdrfm_q.hip k_mix), or
+a launch of their own ahead of design Q's (the other shapes).  Checked here: the
 statistics find exactly the noise-only streams, without the host ever waiting; every distinct row equals the oracle at the plain 1e-5 across the change of
 kernel; a stream's audio is bit-identical to what its kernel gives alone; calls return without blocking."""
 import time
@@ -49,7 +50,7 @@ def test_statistics_route_exactly_the_noise_only_streams_and_the_audio_stays_the
     assert np.array_equal(routed, mask), (routed.sum(), mask.sum())
     first = min(k for k, n in enumerate(names) if "+" in n)
     assert 16 <= first <= 56, names                                            # a window of 16 calls, read back behind its last kernels, noticed at a later call
-    assert all(("+" in n and "(32 streams)" in n) for n in names[first:]), names[first:]
+    assert all(("+" in n and "(32 streams) in one launch" in n) for n in names[first:]), names[first:]   # (the BASELINE shape: k_mix)
     got = out.cpu().numpy()
     seen = set()
     for s in range(ns):
@@ -65,12 +66,14 @@ def test_statistics_route_exactly_the_noise_only_streams_and_the_audio_stays_the
         assert np.array_equal(got[:, s].view(np.uint32), got[:, t].view(np.uint32)), (s, t)
 
 
-@pytest.mark.parametrize("overlap", [True, False])
-def test_a_routed_streams_audio_is_bit_identical_to_what_its_kernel_gives_alone(pkg, overlap):
+@pytest.mark.parametrize("taps,overlap", [(64, True), (64, False), (16, True), (16, False)])
+def test_a_routed_streams_audio_is_bit_identical_to_what_its_kernel_gives_alone(pkg, taps, overlap):
     """Assignment set by the test hook (every fourth stream to the bit-exact kernels, carriers or not): the design-Q streams equal an all-design-Q handle's
-    audio bit for bit, the others a SDRFM_CFG_BIT_EXACT handle's — also across the call at which the assignment changes."""
+    audio bit for bit, the others a SDRFM_CFG_BIT_EXACT handle's — also across the call at which the assignment changes.  64 taps: both kinds of workgroup in
+    one launch (an overlapped call's design-B workgroups read what lies before the call from the previous call's buffer, not from the carried state);
+    16 taps (the reference's RTLSDR_FIR): two launches."""
     import torch
-    h, g = pkg.default_config(64)
+    h, g = pkg.default_config(taps)
     ns, nsamp, ncalls = 256, 48000, 6
     iq, _, _, _, _ = _mixed_rows(pkg, ns, ncalls * nsamp, 5, first_id=1300)    # some rows of noise among them: the repair path runs on both sides
     dev = torch.from_numpy(iq).cuda()
@@ -85,6 +88,7 @@ def test_a_routed_streams_audio_is_bit_identical_to_what_its_kernel_gives_alone(
                 dm.process_batch_device(dev[:, 2 * k * nsamp:], out[k], nbytes=2 * nsamp, overlap=overlap)
                 if tag == "mixed" and k >= route_at:
                     assert "+" in dm.kernel_name and "(64 streams)" in dm.kernel_name, dm.kernel_name
+                    assert ("in one launch" in dm.kernel_name) == (taps == 64), dm.kernel_name
             dm.synchronize()
         outs[tag] = out.cpu().numpy().view(np.uint32)
     q, x, m = outs["q"], outs["x"], outs["mixed"]

@@ -1,10 +1,12 @@
 #!/bin/bash
-# tools/r05/mixed.sh — VERDICT r04 item 2: bench.py on batches that mix carriers and noise-only streams (per-stream routing), beside the all-carrier batch, one box
+# tools/r05/mix1.sh — the one-launch kernel of a mixed batch (k_mix): routing tests, then bench.py on mixed batches with the product library
 cd "$GRAFT_REPO_ROOT" || exit 1
-OUT=gpurun_out/r05_mixed; mkdir -p $OUT
-for rep in 1 2 3; do
-  for cls in fm mixed:5 mixed:10 mixed:25 random; do
-    timeout 90 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-steady --iq-class $cls 2>/dev/null | tail -1 > $OUT/last.json || echo "TIMEOUT $cls rep $rep"
+OUT=gpurun_out/r05_mix1; mkdir -p $OUT
+timeout 600 python -m pytest tests/test_route_gpu.py -x -q --timeout 200 2>&1 | tail -15 > $OUT/pytest.txt
+cat $OUT/pytest.txt
+for rep in 1 2; do
+  for cls in fm mixed:10 mixed:25; do
+    timeout 90 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-steady --iq-class $cls 2>$OUT/err_$cls.txt | tail -1 > $OUT/last.json || echo "TIMEOUT $cls rep $rep"
     python3 - $OUT/last.json $cls $rep <<'PY'
 import json, sys
 r = json.load(open(sys.argv[1])); rf = r["roofline"]; o = rf.get("overlapped_calls", {}); rt = r.get("routing", {})
