@@ -69,7 +69,7 @@ int sdrfm_q_blocks_per_cu(uint32_t first_chunk, uint32_t nslot, uint32_t d, uint
 hipError_t sdrfm_q_launch(const SdrfmQParams& p, uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da, hipStream_t stream, hipEvent_t done = nullptr);
 const char* sdrfm_q_kernel_symbol(uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da);
 // ---- one launch for a mixed batch (sdrfm_q.hip: k_mix): b_blocks design-B workgroups (tile R = b_R; b as k_fastb takes it, fold_state = 1) over the
-// streams of b.slist, then q.n_streams * q.runs design-Q workgroups.  An instance exists for the BASELINE shape (LDS bytes of one workgroup; 0 = none).
+// streams of b.slist, then q.n_streams * q.runs design-Q workgroups.  An instance exists for every shape both designs have one for (LDS bytes of one workgroup; 0 = none).
 struct CallParams;   // sdrfm_b.h
 uint32_t sdrfm_q_mix_lds(uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da, uint32_t T, uint32_t b_R);
 int sdrfm_q_mix_blocks_per_cu(uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da, uint32_t T, uint32_t b_R);

@@ -874,7 +874,9 @@ constexpr uint32_t b_lds() { return (uint32_t)fastb_xbytes(T, D, R) + 4u * (uint
 template <int C0, int NSLOT, int D, int DA, int T, int R>
 constexpr uint32_t mix_lds() { return q_lds<D, DA, NSLOT>() > b_lds<T, D, R, (int)SDRFM_Q_TA>() ? q_lds<D, DA, NSLOT>() : b_lds<T, D, R, (int)SDRFM_Q_TA>(); }
 #define MV(C0_, NS_, D_, DA_, T_, R_) { C0_, NS_, D_, DA_, T_, R_, mix_lds<C0_, NS_, D_, DA_, T_, R_>(), k_mix<C0_, NS_, D_, DA_, T_, R_> }
-const MixVariant kMixVariants[] = {MV(0, 5, 10, 5, 64, 4)};   // (design B's tile R = 8 — 12.9 KB of LDS — measured no faster than R = 4)
+// (design B's tile: R = 4 everywhere; R = 8 — 12.9 KB of LDS — measured no faster at the BASELINE shape)
+const MixVariant kMixVariants[] = {MV(0, 5, 10, 5, 64, 4), MV(1, 5, 10, 5, 64, 4), MV(0, 5, 10, 5, 32, 4), MV(1, 5, 10, 5, 32, 4), MV(0, 5, 10, 5, 16, 4), MV(1, 5, 10, 5, 16, 4),
+                                   MV(0, 4, 8, 8, 64, 4), MV(1, 4, 8, 8, 64, 4), MV(0, 4, 8, 8, 16, 4), MV(1, 4, 8, 8, 16, 4), MV(0, 8, 16, 5, 64, 4), MV(1, 8, 16, 5, 64, 4)};
 
 const MixVariant* mix_find(uint32_t c0, uint32_t nslot, uint32_t d, uint32_t da, uint32_t T, uint32_t R) {
   if (c0 > 1) c0 = 1;

@@ -3,8 +3,8 @@
 256 real dongles are not all tuned to a station: the reference's front end tunes one fixed frequency
 (Middlewares/ST/STM32_USB_Host_Library/Class/RTLSDR/Src/tuner_e4k.c:1097) and hands over whatever is there (usbh_rtlsdr.c:1058-1101).  A noise-only stream
 sends design Q to its repair path at almost every audio stage, and a kernel lasts as long as its slowest wave — so the streams whose windows of design-Q
-calls are mostly repair work are served by the bit-exact kernels: design-B workgroups inside design Q's launch (the BASELINE shape: csrc/sdrfm_q.hip k_mix), or
-a launch of their own ahead of design Q's (the other shapes).  Checked here: the
+calls are mostly repair work are served by the bit-exact kernels: design-B workgroups inside design Q's launch (csrc/sdrfm_q.hip k_mix: every shape both designs
+have an instance for), or a launch of their own ahead of design Q's (the others: the generic kernel).  Checked here: the
 statistics find exactly the noise-only streams, without the host ever waiting; every distinct row equals the oracle at the plain 1e-5 across the change of
 kernel; a stream's audio is bit-identical to what its kernel gives alone; calls return without blocking."""
 import time
@@ -66,12 +66,12 @@ def test_statistics_route_exactly_the_noise_only_streams_and_the_audio_stays_the
         assert np.array_equal(got[:, s].view(np.uint32), got[:, t].view(np.uint32)), (s, t)
 
 
-@pytest.mark.parametrize("taps,overlap", [(64, True), (64, False), (16, True), (16, False)])
+@pytest.mark.parametrize("taps,overlap", [(64, True), (64, False), (16, True), (16, False), (48, True), (48, False)])
 def test_a_routed_streams_audio_is_bit_identical_to_what_its_kernel_gives_alone(pkg, taps, overlap):
     """Assignment set by the test hook (every fourth stream to the bit-exact kernels, carriers or not): the design-Q streams equal an all-design-Q handle's
     audio bit for bit, the others a SDRFM_CFG_BIT_EXACT handle's — also across the call at which the assignment changes.  64 taps: both kinds of workgroup in
     one launch (an overlapped call's design-B workgroups read what lies before the call from the previous call's buffer, not from the carried state);
-    16 taps (the reference's RTLSDR_FIR): two launches."""
+    16 taps (the reference's RTLSDR_FIR): the same; 48 taps (no design-B instance: the generic kernel serves the routed streams): two launches."""
     import torch
     h, g = pkg.default_config(taps)
     ns, nsamp, ncalls = 256, 48000, 6
@@ -88,7 +88,7 @@ def test_a_routed_streams_audio_is_bit_identical_to_what_its_kernel_gives_alone(
                 dm.process_batch_device(dev[:, 2 * k * nsamp:], out[k], nbytes=2 * nsamp, overlap=overlap)
                 if tag == "mixed" and k >= route_at:
                     assert "+" in dm.kernel_name and "(64 streams)" in dm.kernel_name, dm.kernel_name
-                    assert ("in one launch" in dm.kernel_name) == (taps == 64), dm.kernel_name
+                    assert ("in one launch" in dm.kernel_name) == (taps != 48), dm.kernel_name
             dm.synchronize()
         outs[tag] = out.cpu().numpy().view(np.uint32)
     q, x, m = outs["q"], outs["x"], outs["mixed"]
@@ -166,3 +166,38 @@ def test_a_stream_is_tried_on_design_q_again_and_reset_starts_over(pkg, oracle_m
             assert dm.kernel_name.startswith("fast-q") and "+" not in dm.kernel_name, (k, dm.kernel_name)
         assert int(dm.route().sum()) == 0
         dm.synchronize()
+
+
+@pytest.mark.parametrize("T,D,Da", [(64, 8, 8), (16, 8, 8), (64, 16, 5), (32, 10, 5)])
+def test_the_one_launch_kernel_at_the_other_front_end_rates(pkg, oracle_mod, T, D, Da):
+    """k_mix has an instance for every shape both designs serve (2.048 MS/s: D = 8, audio / 8; 3.2 MS/s: D = 16; 32 taps): with every third stream
+    routed by the test hook, serial and overlapped calls give each stream the bits its kernel gives alone, and the audio is the oracle's at 1e-5."""
+    import torch
+    h, g = pkg.default_config(T, fir_decim=D, audio_taps=32, audio_decim=Da)
+    ns, nsamp, ncalls = 192, D * Da * 8 * 150, 5
+    iq, _, _, _, _ = _mixed_rows(pkg, ns, ncalls * nsamp, 7, first_id=3100 + T + D)
+    dev = torch.from_numpy(iq).cuda()
+    mask = np.array([1 if s % 3 == 1 else 0 for s in range(ns)], dtype=np.uint8)
+    na = nsamp // (D * Da)
+    outs = {}
+    for tag, cfg, ovl in (("q", {}, False), ("x", {"bit_exact": True}, False), ("serial", {}, False), ("overlapped", {}, True)):
+        out = torch.zeros((ncalls, ns, na), dtype=torch.float32, device="cuda")
+        with pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, fir_decim=D, audio_decim=Da, n_streams=ns, max_bytes_per_call=2 * nsamp, **cfg)) as dm:
+            for k in range(ncalls):
+                if tag in ("serial", "overlapped") and k == 1:
+                    assert np.array_equal(dm.route(mask), mask)
+                assert dm.process_batch_device(dev[:, 2 * k * nsamp:], out[k], nbytes=2 * nsamp, overlap=ovl) == na
+                if tag in ("serial", "overlapped") and k >= 1:
+                    assert "(64 streams) in one launch" in dm.kernel_name, dm.kernel_name
+                    assert ("overlapped" in dm.kernel_name) == ovl, dm.kernel_name
+            dm.synchronize()
+        outs[tag] = out.cpu().numpy()
+    on_q = mask == 0
+    for tag in ("serial", "overlapped"):
+        m = outs[tag].view(np.uint32)
+        assert np.array_equal(m[2:][:, ~on_q], outs["x"].view(np.uint32)[2:][:, ~on_q]), tag
+        assert np.array_equal(m[2:][:, on_q], outs["q"].view(np.uint32)[2:][:, on_q]), tag
+    for s in (0, 1, 8, 22):                                                     # carriers and noise, on either kind of workgroup
+        want = oracle_mod.Oracle(h, g, D=D, Da=Da).process(iq[s])
+        for tag in ("serial", "overlapped"):
+            assert scaled_err(np.concatenate([outs[tag][k, s] for k in range(ncalls)]), want) <= TOL, (tag, s)
