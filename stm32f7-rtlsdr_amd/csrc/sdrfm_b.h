@@ -307,7 +307,7 @@ __device__ __forceinline__ void fastb_body(const CallParams& p, const uint32_t b
 
   // taps: wave-uniform pairs; the first NVT pairs live in VGPRs, the rest in SGPRs (64 taps alone would take 64 of the
   // ~100 usable SGPRs and push kernel arguments into spills)
-  constexpr int NVT = (T >= 64) ? 12 : 0;
+  constexpr int NVT = (T >= 64) ? 12 : 0;   // (all 32 pairs in VGPRs — round 5, after an FMA with an SGPR operand was found to issue at half rate in design Q: 130 VGPRs at R = 4, no faster: profiles/r05_mixed_batches.txt)
   f2_t hp[T / 2];
 #pragma unroll
   for (int k = 0; k < T / 2; ++k) {
