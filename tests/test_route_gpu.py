@@ -7,6 +7,7 @@ calls are mostly repair work are served by the bit-exact kernels: design-B workg
 have an instance for), or a launch of their own ahead of design Q's (the others: the generic kernel).  Checked here: the
 statistics find exactly the noise-only streams, without the host ever waiting; every distinct row equals the oracle at the plain 1e-5 across the change of
 kernel; a stream's audio is bit-identical to what its kernel gives alone; calls return without blocking."""
+import os
 import time
 
 import numpy as np
@@ -201,3 +202,52 @@ def test_the_one_launch_kernel_at_the_other_front_end_rates(pkg, oracle_mod, T, 
         want = oracle_mod.Oracle(h, g, D=D, Da=Da).process(iq[s])
         for tag in ("serial", "overlapped"):
             assert scaled_err(np.concatenate([outs[tag][k, s] for k in range(ncalls)]), want) <= TOL, (tag, s)
+
+
+@pytest.mark.parametrize("seed", range(11, 11 + int(os.environ.get("SDRFM_ROUTE_SOAK", "6"))))   # (tools: SDRFM_ROUTE_SOAK=120 for a longer soak)
+def test_random_call_sequences_with_the_assignment_changing_under_them(pkg, oracle_mod, seed):
+    """Soak of the routing: random stream counts, call lengths (every one a length design Q serves), SDRFM_F_OVERLAP on or off per call, and the
+    assignment changed by the test hook at random calls (up to 45 % of the streams routed: both kinds of workgroup in one launch; sometimes more than
+    half: the bit-exact kernels take the batch).  Every distinct row is the oracle's at 1e-5 over the whole sequence; copies of a row that share an
+    assignment history give the same bits."""
+    import torch
+    rng = np.random.default_rng(seed)
+    T, D, Da = [(64, 10, 5), (16, 10, 5), (64, 8, 8), (64, 16, 5), (32, 10, 5), (64, 10, 5)][seed % 6]
+    h, g = pkg.default_config(T, fir_decim=D, audio_taps=32, audio_decim=Da)
+    ns = int(rng.choice([96, 160, 256]))
+    unit = D * Da * 8
+    lens = [int(unit * rng.integers(60, 220)) for _ in range(14)]
+    total = sum(lens)
+    fm = pkg.make_iq(6, total, mode="fm", first_id=5000 + seed)
+    rnd = pkg.make_iq(3, total, mode="random", first_id=5100 + seed)
+    kind = rng.integers(0, 9, size=ns)                                          # rows 0 - 5: carriers, 6 - 8: noise
+    group = rng.integers(0, 3, size=ns)                                         # streams of one group share their assignment history
+    iq = np.stack([fm[k] if k < 6 else rnd[k - 6] for k in kind])
+    dev = torch.from_numpy(iq).cuda()
+    bufs = [torch.zeros((ns, n // (D * Da)), dtype=torch.float32, device="cuda") for n in lens]
+    torch.cuda.synchronize()                                                    # (the fills run on torch's stream, the calls on the handle's)
+    outs = []
+    names = []
+    with pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, fir_decim=D, audio_decim=Da, n_streams=ns, max_bytes_per_call=2 * max(lens))) as dm:
+        off = 0
+        for k, n in enumerate(lens):
+            if k and rng.random() < 0.5:
+                on = rng.random(3) < [0.5, 0.35, 0.2]                            # which groups go to the bit-exact kernels from this call on
+                mask = on[group].astype(np.uint8)
+                assert np.array_equal(dm.route(mask), mask)
+            na = dm.process_batch_device(dev[:, 2 * off:], bufs[k], nbytes=2 * n, overlap=bool(rng.random() < 0.6))
+            assert na == n // (D * Da)
+            outs.append(bufs[k])
+            names.append(dm.kernel_name)
+            off += n
+        dm.synchronize()
+    got = torch.cat(outs, dim=1).cpu().numpy()
+    seen = {}
+    for s in range(ns):
+        key = (int(kind[s]), int(group[s]))
+        if key in seen:
+            assert np.array_equal(got[s].view(np.uint32), got[seen[key]].view(np.uint32)), (s, seen[key], key)
+            continue
+        seen[key] = s
+        want = oracle_mod.Oracle(h, g, D=D, Da=Da).process(iq[s])
+        assert scaled_err(got[s], want) <= TOL, (s, key, names)
