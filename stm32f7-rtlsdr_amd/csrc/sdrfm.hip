@@ -1379,7 +1379,7 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
       if (pass == 1 && v.kind != want_kind) continue;
       const uint32_t NYT = 64 * v.R, DOFF = (cfg->audio_taps - 1 + 3u) & ~3u;
       // audio flush every AB sub-tiles: AB = Da makes every flush exactly 64*R outputs (all lanes busy)
-      uint32_t AB = ab_env ? ab_env : (v.kind == 'b' ? 1u : cfg->audio_decim);
+      uint32_t AB = v.kind == 'b' ? (uint32_t)fastb_ab((int)v.R) : (ab_env ? ab_env : cfg->audio_decim);   // (design B: a compile-time property of the tile)
       if (AB > 8) AB = 8;
       while (AB > 1 && (size_t)v.xbytes + (size_t)(DOFF + AB * NYT + v.T + cfg->audio_taps) * 4 > 40 * 1024) --AB;
       if (cfg->audio_taps - 1 > AB * NYT || DOFF + AB * NYT < 2 * (cfg->audio_taps + 1)) continue;
@@ -1420,9 +1420,9 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
     for (const FastVariant& v : kFastVariants) {
       if (v.kind != 'b' || v.R != 4 || v.T != cfg->fir_taps || v.D != cfg->fir_decim || (v.Ta && (v.Ta != cfg->audio_taps || v.Da != cfg->audio_decim))) continue;
       const uint32_t NYT = 64 * v.R, DOFF = (cfg->audio_taps - 1 + 3u) & ~3u;
-      if (cfg->audio_taps - 1 > NYT || DOFF + NYT < 2 * (cfg->audio_taps + 1) || h->AB != 1) continue;
+      if (cfg->audio_taps - 1 > NYT || DOFF + NYT < 2 * (cfg->audio_taps + 1)) continue;
       h->fast_mix = &v;
-      h->fast_mix_lds = (size_t)v.xbytes + (size_t)(DOFF + NYT + v.T + cfg->audio_taps) * 4;
+      h->fast_mix_lds = (size_t)v.xbytes + (size_t)(DOFF + (uint32_t)fastb_ab((int)v.R) * NYT + v.T + cfg->audio_taps) * 4;
       // a stream costs the design-B workgroups about mix_cost times what it costs design Q's: the shares of the wave slots (measured: 2.0 / 2.7 / 3.2 ->
       // 41.2 / 38.9 / 40.3 us serial, 31.5 / 30.8 / 33.0 us overlapped with a quarter of the streams noisy: profiles/r05_mixed_batches.txt)
       h->mix_R = v.R; h->mix_cost = 2.7;

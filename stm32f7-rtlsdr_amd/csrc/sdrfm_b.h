@@ -228,6 +228,12 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 constexpr int fastb_hp(int T, int D) { return ((T - D) + 7) & ~7; }                      // halo samples (16-B granular)
 constexpr int fastb_rs(int D, int R) { return R * D * 2 + ((((R * D * 2) / 16) % 2 == 0) ? 16 : 0); }  // row stride, B
+// sub-tiles of d's buffered per audio flush: the small tile (R = 4: 256 d's = 51 audio outputs per sub-tile, which leaves the flush's three chains per lane
+// two thirds idle) flushes every third sub-tile
+#ifndef SDRFM_B_AB_SMALL
+#define SDRFM_B_AB_SMALL 3
+#endif
+constexpr int fastb_ab(int R) { return R <= 4 ? SDRFM_B_AB_SMALL : 1; }
 constexpr int fastb_xbytes(int T, int D, int R) {
   const int RD = R * D, last = fastb_hp(T, D) + 64 * RD - 1;
   return (((last / RD) * fastb_rs(D, R) + (last % RD + 1) * 2) + 15) & ~15;
@@ -268,7 +274,7 @@ __device__ __forceinline__ void fastb_body(const CallParams& p, const uint32_t b
   unsigned char* xb = smem;                                   // raw tile: position u <-> sub-tile sample s' = u - HP
   constexpr uint32_t Ta = TA, Da = DA;                         // audio stage geometry is compile-time in design B
   constexpr uint32_t DOFF = (Ta - 1 + 3u) & ~3u;
-  constexpr int DCAP = NYT;                                   // one audio flush per sub-tile (AB = 1)
+  constexpr int DCAP = fastb_ab(R) * NYT;                     // one audio flush per sub-tile (every third one at R = 4)
   float* dbuf = reinterpret_cast<float*>(smem + XBYTES);
   float* gs = dbuf + DOFF + DCAP;
   float* hs = gs + Ta;

@@ -870,7 +870,7 @@ const QVariant* q_find(uint32_t c0, uint32_t nslot, uint32_t d, uint32_t da) {
 typedef void (*MixKernel)(SdrfmQParams, CallParams, uint32_t);
 struct MixVariant { uint32_t c0, nslot, d, da, T, R, lds; MixKernel k; };
 template <int T, int D, int R, int TA>
-constexpr uint32_t b_lds() { return (uint32_t)fastb_xbytes(T, D, R) + 4u * (uint32_t)(((TA - 1 + 3) & ~3) + 64 * R + T + TA); }   // as sdrfm.hip sizes design B's workgroup
+constexpr uint32_t b_lds() { return (uint32_t)fastb_xbytes(T, D, R) + 4u * (uint32_t)(((TA - 1 + 3) & ~3) + fastb_ab(R) * 64 * R + T + TA); }   // as sdrfm.hip sizes design B's workgroup
 template <int C0, int NSLOT, int D, int DA, int T, int R>
 constexpr uint32_t mix_lds() { return q_lds<D, DA, NSLOT>() > b_lds<T, D, R, (int)SDRFM_Q_TA>() ? q_lds<D, DA, NSLOT>() : b_lds<T, D, R, (int)SDRFM_Q_TA>(); }
 #define MV(C0_, NS_, D_, DA_, T_, R_) { C0_, NS_, D_, DA_, T_, R_, mix_lds<C0_, NS_, D_, DA_, T_, R_>(), k_mix<C0_, NS_, D_, DA_, T_, R_> }
