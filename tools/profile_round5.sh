@@ -36,6 +36,7 @@ for wl in $WLS; do case $wl in
   fm256_D8)  run_wl fm256_D8 k_mfir --fir-decim 8 --no-overlap ;;      # 2.048 MS/s / 8 / 8 (round 4: design Q at the other front-end rates)
   fm256_D16) run_wl fm256_D16 k_mfir --fir-decim 16 --no-overlap ;;    # 3.2 MS/s / 16 / 5
   fm256_bitexact) run_wl fm256_bitexact k_stream --bit-exact --no-overlap ;;
+  mixed10)   run_wl mixed10 k_mix --iq-class mixed:10 --no-overlap ;;   # 10 % noise-only streams: the one-launch kernel (design-B workgroups inside design Q's grid)
   fm256_overlap|fm512_overlap)   # SDRFM_F_OVERLAP calls: the kernel trace itself (start / end of every dispatch, queue ids) and what it says
     W=$OUT/work_$wl; mkdir -p "$W"
     EXTRA=""; [ $wl = fm512_overlap ] && EXTRA="--streams-per-gpu 512"
