@@ -568,7 +568,7 @@ def main():
         if routed is not None and (args.iq_class != "fm" or int(routed.sum())):
             res["routing"] = {"streams_on_bit_exact_kernels": int(routed.sum()), "streams": ns, "kernels_timed_region": routed_kernel,
                               "note": "per-stream routing (DESIGN.md 4.Q), as the timed region ended: streams whose windows of design-Q calls were mostly repair "
-                                      "work are served by the bit-exact kernels — design B workgroups inside design Q's launch (k_mix) for the BASELINE shape, "
+                                      "work are served by the bit-exact kernels — design B workgroups inside design Q's launch (k_mix) where both designs have an instance, "
                                       "a launch of their own ahead of design Q's for the others"}
         if guard:
             res["guard"] = {"guard_r": round(guard["guard_r"], 4), "pi_minus_guard_a": round(3.141592653589793 - guard["guard_a"], 7),

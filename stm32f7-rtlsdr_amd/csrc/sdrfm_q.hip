@@ -866,7 +866,7 @@ const QVariant* q_find(uint32_t c0, uint32_t nslot, uint32_t d, uint32_t da) {
   return nullptr;
 }
 
-// ---- the one-launch kernel of a mixed batch: the BASELINE shape only (other shapes launch the two kernels one after the other) ------------------
+// ---- the one-launch kernel of a mixed batch: every shape both designs serve (where design B has no instance the host launches two kernels) ----------
 typedef void (*MixKernel)(SdrfmQParams, CallParams, uint32_t);
 struct MixVariant { uint32_t c0, nslot, d, da, T, R, lds; MixKernel k; };
 template <int T, int D, int R, int TA>

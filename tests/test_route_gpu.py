@@ -51,7 +51,7 @@ def test_statistics_route_exactly_the_noise_only_streams_and_the_audio_stays_the
     assert np.array_equal(routed, mask), (routed.sum(), mask.sum())
     first = min(k for k, n in enumerate(names) if "+" in n)
     assert 16 <= first <= 56, names                                            # a window of 16 calls, read back behind its last kernels, noticed at a later call
-    assert all(("+" in n and "(32 streams) in one launch" in n) for n in names[first:]), names[first:]   # (the BASELINE shape: k_mix)
+    assert all(("+" in n and "(32 streams) in one launch" in n) for n in names[first:]), names[first:]   # (k_mix)
     got = out.cpu().numpy()
     seen = set()
     for s in range(ns):
