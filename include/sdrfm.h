@@ -229,6 +229,9 @@ const char* sdrfm_wbfm_kernel_name(const sdrfm_wbfm_t* h);
  * middle: power[stream * power_stride + i], i = 0..nfft-1, bin i = frequency (i - nfft/2) * fs/nfft.  Stateless: each
  * call views the buffer it is given; a tail shorter than nfft is ignored (*n_frames = 0 -> all zeros).
  * Arithmetic (one fixed radix-2 DIT graph, fp32): DESIGN.md §4.6.  window = NULL selects a periodic Hann window.
+ * SDRFM_FAIL from a host-buffer call or from sdrfm_spectrum_synchronize also reports a device-side time-out: the 512 / 1024-point kernel hands
+ * a stream's running sum from wave to wave, and a wave that waited two seconds for its predecessor (a wait of ~100 us when nothing is wrong) sets
+ * an error word instead of hanging or aborting the context; the powers of that call are not valid, the handle stays usable.
  * ------------------------------------------------------------------------------------------------------------------ */
 typedef struct sdrfm_spectrum_config {
   uint32_t struct_size;           /* = sizeof(sdrfm_spectrum_config) */

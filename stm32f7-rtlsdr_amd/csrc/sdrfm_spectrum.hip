@@ -34,6 +34,7 @@ __device__ int spec_raw_load_dword(si4_t rsrc, int voffset, int soffset, int aux
 
 namespace {
 
+#define SPEC_WAIT_TICKS 200000000ull   /* k_spectrum_chain: s_memrealtime ticks (100 MHz) a wave waits for its predecessor's sum before it gives up: 2 s */
 struct SParams {
   const uint8_t* iq;
   size_t iq_stride;
@@ -44,6 +45,7 @@ struct SParams {
   const float* win;       // N window values
   uint32_t F;             // frames per stream
   float inv_frames;       // 1.0f / F
+  unsigned int* err;      // host-mapped word: k_spectrum_chain sets bit 0 when a wave gave up waiting for its predecessor's sum (the host answers SDRFM_FAIL)
 #ifdef SDRFM_DEV
   unsigned int* dbg;      // development library: per-wave cycle sums per phase of k_spectrum_chain (or null)
 #endif
@@ -501,23 +503,33 @@ __global__ void __launch_bounds__(64 * NWF) k_spectrum_chain(SParams p) {
       };
       batch();
       if ((uint32_t)__builtin_amdgcn_readfirstlane((int)tag) != r) {
-        // (a wave never waits longer than one turn of the chain, ~100 us whatever F is: 2^20 polls — tens of milliseconds — mean the hand-over
-        //  is broken, and the kernel traps rather than hang the device)
-        uint32_t polls = 0;
+        // A wave never waits longer than one turn of the chain, ~100 us whatever F is.  The wait is bounded in REAL TIME (s_memrealtime, 100 MHz:
+        // two seconds — a predecessor parked by a debugger or by wave pre-emption does not run the budget down the way a poll count did), and a wave
+        // whose budget runs out neither hangs the device nor traps (a trap takes the whole HIP context and every handle of the process with it): it
+        // sets the handle's error word, goes on with whatever the slot holds and publishes its own tag as usual, so its successors are not stuck
+        // behind it; the host answers SDRFM_FAIL at the next synchronisation (the powers of that call are not valid).
+        // (The protocol rests on two properties of the LDS: the DS operations of ONE wave execute in order — the writer stores its 64 lanes' sums,
+        // then their tags, in one instruction sequence — and a DS instruction is performed for all 64 lanes before the next one of any wave touches
+        // the same words; that is why lane 0's tag stands for all 64.)
+        const unsigned long long t_wait0 = __builtin_amdgcn_s_memrealtime();
+        bool gave_up = false;
         if (r > 1u) {                                          // far from the head of the chain: wait until the predecessor has its input
           uint32_t tp;
           for (;;) {
             asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(tp) : "v"(a_tagp) : "memory");
             if ((uint32_t)__builtin_amdgcn_readfirstlane((int)tp) >= r - 1u) break;
-            if (++polls > (1u << 20)) __builtin_trap();
+            if (__builtin_amdgcn_s_memrealtime() - t_wait0 > SPEC_WAIT_TICKS) { gave_up = true; break; }
             __builtin_amdgcn_s_sleep(2);
           }
         }
-        polls = 0;
-        do {                                                   // next in line: whole batches, one round trip after the tag lands
-          batch();
-          if (++polls > (1u << 20)) __builtin_trap();
-        } while ((uint32_t)__builtin_amdgcn_readfirstlane((int)tag) != r);
+        if (!gave_up) {
+          uint32_t polls = 0;
+          do {                                                 // next in line: whole batches, one round trip after the tag lands
+            batch();
+            if ((++polls & 1023u) == 0 && __builtin_amdgcn_s_memrealtime() - t_wait0 > SPEC_WAIT_TICKS) { gave_up = true; break; }
+          } while ((uint32_t)__builtin_amdgcn_readfirstlane((int)tag) != r);
+        }
+        if (gave_up && lane == 0 && p.err) __hip_atomic_fetch_or(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
 #pragma unroll
       for (int j = 0; j < SV / 4; ++j) { S[4 * j] = t[j].x; S[4 * j + 1] = t[j].y; S[4 * j + 2] = t[j].z; S[4 * j + 3] = t[j].w; }
@@ -615,6 +627,8 @@ struct sdrfm_spectrum {
   int chain_nwf;            // its waves per workgroup
   char name[2][48];         // kernel names as the profiler prints them: [0] k_spectrum<..>, [1] k_spectrum_chain<..>
   int last;                 // which of the two the last call launched
+  unsigned int* err_host;   // host-mapped error word (SParams.err) and its device address
+  unsigned int* err_dev;
 #ifdef SDRFM_DEV
   unsigned int* d_dbg;      // phase stamps (SDRFM_SPEC_STAMPS=1)
   int stamps;
@@ -652,6 +666,7 @@ static void sfree(sdrfm_spectrum* h) {
 #endif
   void* ptrs[] = {h->d_tw, h->d_win, h->d_iq, h->d_power};
   for (void* q : ptrs) if (q) (void)hipFree(q);
+  if (h->err_host) (void)hipHostFree(h->err_host);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }
@@ -724,6 +739,8 @@ int sdrfm_spectrum_create(const sdrfm_spectrum_config* cfg, sdrfm_spectrum_t** o
   if (e == hipSuccess) e = hipMalloc(&h->d_win, sizeof(float) * N);
   if (e == hipSuccess) e = hipMemcpy(h->d_tw, tw, sizeof(float2) * (N / 2), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(h->d_win, win, sizeof(float) * N, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&h->err_host), 64, hipHostMallocMapped);
+  if (e == hipSuccess) { *h->err_host = 0u; e = hipHostGetDevicePointer(reinterpret_cast<void**>(&h->err_dev), h->err_host, 0); }
   free(tw); free(win);
   CR(e);
 #undef CR
@@ -742,11 +759,18 @@ int sdrfm_spectrum_set_stream(sdrfm_spectrum_t* h, void* hip_stream) {
   return SDRFM_OK;
 }
 
+// the chain kernel's error word, read (and cleared) behind a synchronisation: a wave gave up waiting for its predecessor — the call's powers are not valid
+static int spec_take_error(sdrfm_spectrum* h) {
+  if (!h->err_host || !*reinterpret_cast<volatile unsigned int*>(h->err_host)) return SDRFM_OK;
+  *reinterpret_cast<volatile unsigned int*>(h->err_host) = 0u;
+  return SDRFM_FAIL;
+}
+
 int sdrfm_spectrum_synchronize(sdrfm_spectrum_t* h) {
   if (!h) return SDRFM_EINVAL;
   STRY(hipSetDevice(h->device), SDRFM_FAIL);
   STRY(hipStreamSynchronize(h->stream), SDRFM_FAIL);
-  return SDRFM_OK;
+  return spec_take_error(h);
 }
 
 static int senqueue(sdrfm_spectrum* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nbytes, float* d_power, size_t power_stride,
@@ -761,7 +785,7 @@ static int senqueue(sdrfm_spectrum* h, const uint8_t* d_iq, size_t iq_stride, ui
   (void)nbytes;
   SParams p;
   p.iq = d_iq; p.iq_stride = iq_stride; p.iq_span = (uint32_t)span; p.power = d_power; p.power_stride = power_stride;
-  p.tw = h->d_tw; p.win = h->d_win; p.F = F; p.inv_frames = 1.0f / (float)F;
+  p.tw = h->d_tw; p.win = h->d_win; p.F = F; p.inv_frames = 1.0f / (float)F; p.err = h->err_dev;
   // the raw-dword kernel needs every sample pair inside one aligned dword: iq and iq_stride even
   const bool use_chain = h->chain && !(((uintptr_t)d_iq | (uintptr_t)iq_stride) & 1u);
 #ifdef SDRFM_DEV
@@ -800,7 +824,7 @@ int sdrfm_spectrum_process_batch(sdrfm_spectrum_t* h, const uint8_t* iq, size_t 
   if (rc != SDRFM_OK) return rc;
   STRY(hipMemcpy2DAsync(power, power_stride * sizeof(float), h->d_power, N * sizeof(float), N * sizeof(float), ns, hipMemcpyDeviceToHost, h->stream), SDRFM_FAIL);
   STRY(hipStreamSynchronize(h->stream), SDRFM_FAIL);
-  return SDRFM_OK;
+  return spec_take_error(h);
 }
 
 }  // extern "C"
