@@ -585,6 +585,9 @@ def main():
                 "frac_sustained": round(alg_bytes / (kernel_ms_ovl_sus * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                 **({"frac_steady": round(alg_bytes / (float(np.median(steady_ovl[5:])) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                     "ms_per_call_regions_300": [round(x, 4) for x in steady_ovl]} if steady_ovl else {}),
+                # against the read ceiling measured in this run (roofline.peak_measured: what a read-only stream with the kernel's access pattern reaches on this box)
+                **({"frac_of_measured": round(alg_bytes / (kernel_ms_ovl * 1e-3) / 1e9 / peak_measured, 4)} if peak_measured else {}),
+                **({"frac_steady_of_measured": round(alg_bytes / (float(np.median(steady_ovl[5:])) * 1e-3) / 1e9 / peak_measured, 4)} if (peak_measured and steady_ovl) else {}),
                 "note": "bytes per call / (event span of the timed region / K); `value` is measured on these calls"}
         if args.bit_exact:
             res["handle"] = "SDRFM_CFG_BIT_EXACT (fmaf-chain kernels only: NOT the default path)"
