@@ -1007,11 +1007,9 @@ struct sdrfm {
   uint8_t* rt_noisy; uint64_t* rt_retry_at; uint32_t rt_n_noisy; uint64_t rt_calls, rt_next_retry;   // host: per stream, served by the bit-exact kernels until call rt_retry_at
   uint32_t* rt_list_dev[2]; uint32_t* rt_list_host[2]; int rt_list_cur; bool rt_dirty;   // stream lists: the clean streams first, then the noisy ones
   hipEvent_t rt_applied; bool rt_applied_pending;               // a new list version is in place (recorded on the handle's stream)
-  hipStream_t rt_bx; hipEvent_t rt_bx_done; bool rt_bx_pending;   // overlapped calls: the noisy streams' launches on a stream with a hardware queue of its own (a CU-mask stream)
   hipEvent_t rt_bx_evt[2]; uint32_t rt_bx_slot; hipStream_t rt_bx_last;   // the bit-exact sub-launches: completion events (stop events), and the stream the latest went to
                                                                 // (each takes the state the one before left: on another stream it waits for that one's event)
   bool rt_off;                                                  // (development: design Q whatever the streams hold)
-  bool rt_anyorder;                                             // the noisy streams' launch goes out behind design Q's with hipExtAnyOrderLaunch (no barrier bit)
   // SDRFM_F_OVERLAP: two internal streams taken in turn, so that consecutive calls run concurrently on the device (a call's ramp-up
   // under the previous call's tail).  ovl_in orders a call behind what the handle's stream holds when it is made; join_overlap()
   // records ovl_done[k] behind the calls put on internal stream k and makes the handle's stream wait for it.
@@ -1061,14 +1059,13 @@ static int route_create(sdrfm* h) {
   }
   HIP_TRY(hipEventCreateWithFlags(&h->rt_applied, hipEventDisableTiming), SDRFM_ENOMEM);
   for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreateWithFlags(&h->rt_bx_evt[i], hipEventDisableTiming), SDRFM_ENOMEM);
-  HIP_TRY(hipEventCreateWithFlags(&h->rt_bx_done, hipEventDisableTiming), SDRFM_ENOMEM);
-  // (rt_bx stays null: a third stream for the noisy streams' launches was tried two ways and lost both times — profiles/r05_mixed_batches.txt.  An ordinary
-  // stream shares the handle's stream's hardware queue (streams of one priority share a small pool): its kernels sat between that stream's event markers and
-  // every overlapped call waited for the previous call's launch; a CU-mask stream (a queue of its own) ran the overlapped calls at 53 us against 36 - 41 us
-  // with the launch ahead of design Q's on the call's own stream.)
+  // (No third stream for the noisy streams' launches: tried two ways, lost both times — profiles/r05_mixed_batches.txt.  An ordinary stream shares the handle's
+  // stream's hardware queue (streams of one priority share a small pool): its kernels sat between that stream's event markers and every overlapped call waited
+  // for the previous call's launch; a CU-mask stream (a queue of its own) ran the overlapped calls at 53 us against 36 - 41 us with the launch ahead of design Q's
+  // on the call's own stream.  hipExtAnyOrderLaunch — the launch behind design Q's without a barrier bit — is ignored on gfx950.  Where both designs have an
+  // instance the two kinds of workgroup share ONE launch: sdrfm_q.hip, k_mix.)
   HIP_TRY(hipStreamCreateWithFlags(&h->rt_mon, hipStreamNonBlocking), SDRFM_ENOMEM);
   h->rt_next_retry = ~0ull;
-  h->rt_anyorder = false;                                        // (measured on gfx950: the flag is ignored — hip_ext.h says as much for GFX9 — and the order design Q, design B is the slower one: profiles/r05_mixed_batches.txt)
   return SDRFM_OK;
 }
 
@@ -1079,8 +1076,6 @@ static int route_reset(sdrfm* h) {
   if (h->rt_mon) HIP_TRY(hipStreamSynchronize(h->rt_mon), SDRFM_FAIL);
   for (int k = 0; k < 2; ++k)
     if (h->ovl_stream[k]) HIP_TRY(hipStreamSynchronize(h->ovl_stream[k]), SDRFM_FAIL);
-  if (h->rt_bx) HIP_TRY(hipStreamSynchronize(h->rt_bx), SDRFM_FAIL);
-  h->rt_bx_pending = false;
   for (int i = 0; i < 2; ++i) {
     HIP_TRY(hipMemset(h->rt_pass_dev[i], 0, ns * sizeof(uint32_t)), SDRFM_FAIL);
     h->rt_rb_pending[i] = false;
@@ -1129,7 +1124,6 @@ static void free_handle(sdrfm* h) {
   for (int k = 0; k < 2; ++k)
     if (h->ovl_stream[k]) (void)hipStreamSynchronize(h->ovl_stream[k]);     // overlapped calls still use the buffers freed below
   if (h->rt_mon) (void)hipStreamSynchronize(h->rt_mon);
-  if (h->rt_bx) (void)hipStreamSynchronize(h->rt_bx);
   if (h->d_h) (void)hipFree(h->d_h);
   if (h->d_g) (void)hipFree(h->d_g);
   for (int i = 0; i < 2; ++i) {
@@ -1158,8 +1152,6 @@ static void free_handle(sdrfm* h) {
   for (int i = 0; i < 2; ++i)
     if (h->rt_bx_evt[i]) (void)hipEventDestroy(h->rt_bx_evt[i]);
   if (h->rt_mon) (void)hipStreamDestroy(h->rt_mon);
-  if (h->rt_bx) (void)hipStreamDestroy(h->rt_bx);
-  if (h->rt_bx_done) (void)hipEventDestroy(h->rt_bx_done);
   free(h->rt_noisy);
   free(h->rt_retry_at);
   if (h->d_qstat) (void)hipFree(h->d_qstat);
@@ -1494,11 +1486,6 @@ static int join_overlap(sdrfm* h) {
       HIP_TRY(hipStreamWaitEvent(h->stream, h->ovl_done[k], 0), SDRFM_FAIL);
       h->ovl_pending[k] = false;
     }
-  if (h->rt_bx_pending) {                                        // the noisy streams' launches of the overlapped calls
-    HIP_TRY(hipEventRecord(h->rt_bx_done, h->rt_bx), SDRFM_FAIL);
-    HIP_TRY(hipStreamWaitEvent(h->stream, h->rt_bx_done, 0), SDRFM_FAIL);
-    h->rt_bx_pending = false;
-  }
   return SDRFM_OK;
 }
 
@@ -1527,7 +1514,6 @@ static int route_apply(sdrfm* h) {
   h->rt_applied_pending = true;
   for (int k = 0; k < 2; ++k)
     if (h->ovl_stream[k]) HIP_TRY(hipStreamWaitEvent(h->ovl_stream[k], h->rt_applied, 0), SDRFM_FAIL);
-  if (h->rt_bx) HIP_TRY(hipStreamWaitEvent(h->rt_bx, h->rt_applied, 0), SDRFM_FAIL);
   h->rt_list_cur = v; h->rt_n_noisy = nn; h->rt_dirty = false;
   return SDRFM_OK;
 }
@@ -1736,25 +1722,21 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
   }
   CallParams pb;                                                  // fuse: design B's part of the one launch
   uint32_t pb_blocks = 0, pb_R = 0;
-  // (the bit-exact launch as a closure: it goes out ahead of design Q's launch, or — any-order launches, below — right behind it)
-  bool bx_anyorder_now = false;
+  // (the bit-exact launch as a closure)
   auto launch_bx = [&]() -> int {
-    // ---- the bit-exact kernels: every stream (on the handle's stream), or the noisy streams beside design Q's launch: on their own internal stream, in
-    // order among themselves (each takes the state the previous one left); a call made without SDRFM_F_OVERLAP forks that stream off the handle's stream
-    // and joins it again, so that the handle's stream is behind both launches when the call returns
+    // ---- the bit-exact kernels: every stream (on the handle's stream), or the noisy streams of a mixed call: inside design Q's launch where k_mix has an
+    // instance (fuse: only the parameters are prepared here), else a launch of their own ahead of design Q's on the call's stream
     const uint32_t nsub = bx_all ? ns_all : n_noisy;
     hipStream_t bs = h->stream;
     hipEvent_t bdone = nullptr;                                   // mixed: the launch's own completion event (a stop event: no marker packet)
-    const uint32_t bflags = bx_anyorder_now ? (uint32_t)hipExtAnyOrderLaunch : 0u;
     if (mixed && !fuse) {
       // The noisy streams' launch goes ahead of design Q's on the call's own stream: no third stream (streams of one priority share a small pool of
       // hardware queues — one was seen on the queue of the handle's stream, and every dependence across queues costs ~10 us of a queue's time), no
       // fork and join.  Overlapped calls run it beside the OTHER internal stream's call; it takes the state the previous such launch left, which sits
       // on that other stream then: behind its completion event (launched a whole call earlier: a wait that is over when it is reached).
-      bs = (ovl && h->rt_bx) ? h->rt_bx : qs;                      // (overlapped calls: beside both internal streams' launches, on the stream with a queue of its own)
-      if (bs == h->rt_bx) { h->rt_bx_pending = true; if (behind_in) HIP_TRY(hipStreamWaitEvent(bs, h->ovl_in, 0), SDRFM_FAIL); }
+      bs = qs;
       bdone = h->rt_bx_evt[h->rt_bx_slot]; h->rt_bx_slot ^= 1u;
-      if (!bx_anyorder_now && h->rt_bx_last && h->rt_bx_last != bs) HIP_TRY(hipStreamWaitEvent(bs, h->rt_bx_evt[h->rt_bx_slot], 0), SDRFM_FAIL);   // (the slot just left: the previous launch's event)
+      if (h->rt_bx_last && h->rt_bx_last != bs) HIP_TRY(hipStreamWaitEvent(bs, h->rt_bx_evt[h->rt_bx_slot], 0), SDRFM_FAIL);   // (the slot just left: the previous launch's event)
       h->rt_bx_last = bs;
     }
     if (mixed) p.slist = list_dev + n_clean;
@@ -1772,7 +1754,7 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
       const uint32_t segs = N / h->fast_s->seg;
       p.tiles_per_stream = (segs + 62) / 63;                      // waves per stream: 63 useful lane segments each
       p.fold_state = 1;
-      hipExtLaunchKernelGGL(h->fast_s->kernel[0], dim3(nsub * p.tiles_per_stream), dim3(64), h->fast_s->xbytes, bs, nullptr, bdone, bflags, p);
+      hipExtLaunchKernelGGL(h->fast_s->kernel[0], dim3(nsub * p.tiles_per_stream), dim3(64), h->fast_s->xbytes, bs, nullptr, bdone, 0, p);
       bname = h->fast_s_name; halo_bytes = true;
     } else if (fast_ok) {
       // split every stream into segments so that ~waves_target waves are resident; each segment >= min_subtiles sub-tiles
@@ -1803,25 +1785,20 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
         pb = p; pb_blocks = grid; pb_R = h->mix_R;
         p.iq_prev = nullptr; p.iq_prev_stride = 0; p.N_prev = 0;
       } else {
-        hipExtLaunchKernelGGL(fv->kernel[fv == h->fast ? h->fast_mode : 0], dim3(grid), dim3(64), flds, bs, nullptr, bdone, bflags, p);
+        hipExtLaunchKernelGGL(fv->kernel[fv == h->fast ? h->fast_mode : 0], dim3(grid), dim3(64), flds, bs, nullptr, bdone, 0, p);
       }
       bname = h->fast_name; halo_bytes = halo_bytes || fv->kind == 'b';
     } else {
       p.NA = h->NA;
       p.tiles_per_stream = (A + h->NA - 1) / h->NA;
       const uint32_t grid = nsub * p.tiles_per_stream + nsub;
-      hipExtLaunchKernelGGL(k_generic, dim3(grid), dim3(256), h->lds_bytes, bs, nullptr, bdone, bflags, p);
+      hipExtLaunchKernelGGL(k_generic, dim3(grid), dim3(256), h->lds_bytes, bs, nullptr, bdone, 0, p);
     }
     bx_name = bname;
     p.slist = nullptr; p.n_streams = ns_all;
     return SDRFM_OK;
   };
-  // hipExtAnyOrderLaunch: the noisy streams' launch carries no barrier bit, so it starts beside the design-Q launch that precedes it in the SAME queue (which
-  // waited for everything before it): both share the machine from the first microsecond without a second queue or a dependence between queues.
-  const bool bx_anyorder = mixed && h->rt_anyorder;
-  if ((bx_all || mixed) && !bx_anyorder) { const int brc = launch_bx(); if (brc != SDRFM_OK) return brc; }
-  // (any-order: the wait for the previous such launch — on the other internal stream — has to sit ahead of design Q's launch, whose barrier bit honours it)
-  if (bx_anyorder && h->rt_bx_last && h->rt_bx_last != qs) HIP_TRY(hipStreamWaitEvent(qs, h->rt_bx_evt[h->rt_bx_slot ^ 1u], 0), SDRFM_FAIL);
+  if (bx_all || mixed) { const int brc = launch_bx(); if (brc != SDRFM_OK) return brc; }
   if (q_ok) {
     SdrfmQParams q;
     q.iq_prev = nullptr; q.iq_prev_stride = 0; q.N_prev = 0;
@@ -1887,7 +1864,6 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
     }
     snprintf(q_name, sizeof(q_name), "%s%s", h->fast_q_name, ovl ? " overlapped" : "");
   }
-  if (bx_anyorder) { bx_anyorder_now = true; const int brc = launch_bx(); if (brc != SDRFM_OK) return brc; }
   if (mixed) {
     const char* sp = strchr(bx_name, ' ');                         // ("fast-b", "fast-s", "generic": the name's first word)
     snprintf(h->kernel_name, sizeof(h->kernel_name), "%s + %.*s (%u streams)%s", q_name, (int)(sp ? sp - bx_name : (long)strlen(bx_name)), bx_name, n_noisy,
