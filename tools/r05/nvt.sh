@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/r05/nvt.sh — design B alone (bit-exact handle, development library): channel taps in SGPRs (12 pairs in VGPRs, 20 in SGPRs: mode 0) against all 32 pairs in VGPRs
+# tools/r05/nvt.sh — design B alone (bit-exact handle, development library): channel taps in SGPRs (12 pairs in VGPRs, 20 in SGPRs: mode 0) against all 32 pairs in VGPRs (mode 1 / 2: a build with every tap pair in VGPRs — measured, not kept: the switch is no longer in csrc/sdrfm_b.h)
 cd "$GRAFT_REPO_ROOT" || exit 1
 CS=stm32f7-rtlsdr_amd/csrc; OUT=gpurun_out/r05_nvt; mkdir -p $OUT
 cp $CS/libsdrfm_dev.so $CS/libsdrfm_dev_keep.so
