@@ -48,7 +48,7 @@ int sdrfm_q_guard(const float* h, uint32_t T, const float* g, uint32_t Ta, float
 int sdrfm_debug_q_guard(sdrfm_t* h, float* guard_r, float* guard_a, unsigned long long* lanes, unsigned long long* passes);
 
 /* Per-stream routing (csrc/sdrfm.hip: the handle's comment): a stream whose windows of design-Q calls are mostly repair work is served by the bit-exact
- * kernels for a while, by a launch of their own beside design Q's launch over the other streams.  mask != NULL ([n_streams] bytes) SETS the assignment for a
+ * kernels for a while — design-B workgroups inside design Q's launch over the other streams, or a launch ahead of it.  mask != NULL ([n_streams] bytes) SETS the assignment for a
  * test (non-zero: the bit-exact kernels, for good; zero: design Q until the statistics say otherwise); mask == NULL takes in whatever statistics have arrived.
  * *n_noisy (may be NULL) = streams the bit-exact kernels serve from the next call on; noisy_out (may be NULL, [n_streams] bytes) = which.
  * SDRFM_NOT_SUPPORTED when the handle has no matrix-pipe kernel. */

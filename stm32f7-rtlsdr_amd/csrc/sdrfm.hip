@@ -911,7 +911,7 @@ const FastVariant kFastVariants[] = {
     SDRFM_STREAM(64, 10, 8, 6, 32, 5), SDRFM_STREAM(32, 10, 8, 6, 32, 5),
     // 2.4 MS/s -> 240 kS/s -> 48 kHz: the rate the firmware programs (usbh_rtlsdr.c:898) and the BASELINE configs
     SDRFM_FASTB2_ABL(64, 10, 12, 32, 5), SDRFM_FASTB2_LITE(64, 10, 8, 32, 5), SDRFM_FASTB(16, 10, 12), SDRFM_FASTB2_LITE(32, 10, 12, 32, 5),
-    // R = 4: the noisy streams' launch beside design Q's (per-stream routing): 6.8 KB of LDS per wave — a slot one of design Q's waves (10.9 KB) leaves
+    // R = 4: the noisy streams' workgroups beside design Q's (per-stream routing; inside design Q's launch: k_mix): 6.8 KB of LDS per wave — a slot one of design Q's waves (10.9 KB) leaves
     // takes one, which the 19 KB of the R = 12 instance cannot count on while design Q's waves keep coming
     SDRFM_FASTB2_LITE(64, 10, 4, 32, 5), SDRFM_FASTB2_LITE(32, 10, 4, 32, 5), SDRFM_FASTB2_LITE(16, 10, 4, 32, 5),
     // the other rates RTLSDR_set_sample_rate accepts and a dongle is commonly run at:
@@ -957,7 +957,7 @@ struct sdrfm {
   // fast kernel (when one is instantiated for this T/D)
   const FastVariant* fast;
   const FastVariant* fast_s;  // design S variant of this geometry, if one is instantiated (serves the calls it is eligible for)
-  const FastVariant* fast_mix; size_t fast_mix_lds;   // design B with the smallest tile (R = 4): the noisy streams' launch beside design Q's
+  const FastVariant* fast_mix; size_t fast_mix_lds;   // design B with the smallest tile (R = 4): the noisy streams' workgroups beside design Q's
   uint32_t mix_lds, mix_waves_per_cu, mix_R; double mix_cost;                 // ... or INSIDE design Q's launch (sdrfm_q.hip: k_mix) where an instance exists: LDS bytes of a workgroup (0 = none), workgroups a CU holds
   uint32_t n_cu;              // compute units of the device
   char fast_s_name[64];
@@ -994,8 +994,8 @@ struct sdrfm {
   // stream (device memory); a window of SDRFM_Q_ADAPT_WINDOW design-Q calls is read back on a side stream behind the completion events of
   // the window's last kernels (hipExtLaunchKernelGGL stop events: no marker packets in the compute queues, no host wait anywhere: a
   // finished read-back is noticed by hipEventQuery at a later call).  A stream more than a quarter of whose audio stages needed a repair
-  // pass is served by the bit-exact kernels for SDRFM_Q_ADAPT_BACKOFF calls (a launch of their own over the list of such streams, on an
-  // internal stream of its own beside design Q's launch over the others), then tried on design Q again.  Which kernel serves a stream at
+  // pass is served by the bit-exact kernels for SDRFM_Q_ADAPT_BACKOFF calls (design-B workgroups over the list of such streams INSIDE design
+  // Q's launch over the others — sdrfm_q.hip: k_mix — or, where design B has no instance, a launch ahead of it), then tried on design Q again.  Which kernel serves a stream at
   // a given call therefore depends on WHEN the device's report is noticed; every choice is within the tolerance, a stream's audio is
   // bit-identical to what its kernel gives alone, and SDRFM_CFG_BIT_EXACT pins the kernels.
   uint32_t* rt_pass_dev[2]; uint32_t* rt_pass_host[2]; uint32_t* rt_pass_host_dev[2];         // repair passes per stream: the set the open window adds into / pinned read-back; two in turn
@@ -1638,7 +1638,7 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
   const bool q_ok = q_fit && n_clean > 0 && 2 * n_noisy < ns_all; // design Q serves n_clean streams (all of them when no stream is noisy); with half of the streams
                                                                  // noisy the bit-exact kernels take the whole batch (design S fills the machine then)
   const bool bx_all = !q_ok;                                     // the bit-exact kernels serve every stream, on the handle's stream (as every call design Q cannot take)
-  const bool mixed = q_ok && n_noisy > 0;                        // ... or the noisy ones beside design Q, on their own internal stream
+  const bool mixed = q_ok && n_noisy > 0;                        // ... or the noisy ones beside design Q: in its launch (k_mix) or ahead of it
   ++h->rt_calls;
   // SDRFM_F_OVERLAP: the call goes to one of two internal streams and warms every stream up from the previous call's buffer instead
   // of reading the carried state, so that it depends on nothing the previous call computes (the state sets are still written, for
