@@ -428,7 +428,7 @@ def main():
         ovl_calls["n"] += 1
 
     if args.iq_class != "fm":
-        # a capture that has been running for a while: the library's per-stream statistics (windows of 8 calls, read back asynchronously) have settled
+        # a capture that has been running for a while: the library's per-stream statistics (windows of 16 calls, read back asynchronously) have settled
         for i in range(96):
             (step_ovl if overlap else step_rot)(i)
             if i % 8 == 7:
