@@ -1,4 +1,4 @@
-"""tools/r05/soak_dbg.py <seed> — the routing soak of tests/test_route_gpu.py, call by call: which streams of which call miss the oracle."""
+"""tools/r05/soak_dbg.py <seed> — test infrastructure (the oracle is the checker here, as in tests/): the routing soak of tests/test_route_gpu.py, call by call: which streams of which call miss the oracle."""
 import sys, os
 import numpy as np
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
