@@ -285,12 +285,6 @@ def timed(torch, dist, use_dist, stream, step, steps, finish=None, rest=0.0):
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(stream)
-    if finish is not None:
-        # (overlapped calls go to the library's internal streams, ordered behind whatever the launch stream still holds: with this marker still pending the first
-        #  call would wait for it across hardware queues — 10 - 18 us that belong to the instrumentation, not to the K steps; the wall clock above keeps running)
-        t_poll = time.perf_counter()
-        while not ev0.query() and time.perf_counter() - t_poll < 1.0:
-            pass
     for i in range(steps):
         step(i)
     if finish is not None:
