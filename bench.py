@@ -31,6 +31,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The HIP runtime maps a process's streams onto a small pool of hardware queues (4 by default).  With RCCL initialised in the process its streams take some of them,
+# and the library's two internal streams of the overlapped calls then share queues with the launch stream: every call waits for the one before it across queues —
+# 49 us per call instead of 23 on one GPU with world size 1 (tools/r05/dist_probe.sh, profiles/r05_q_experiments.txt item 16).  Eight queues restore it.  Set before
+# anything initialises the runtime; a caller's own setting is respected.  (INTEGRATION.md says the same to hosts that run RCCL beside the library.)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 REST_S = float(os.environ.get("BENCH_REST_S", "0.05"))   # idle time before every secondary timed region (see timed())
@@ -267,6 +272,9 @@ def pick_batches(args, bytes_per_batch):
     return max(3, -(-int(1.5 * L3_BYTES) // int(bytes_per_batch)) + 1)   # (nb - 1) batches between two uses of one > 1.5 x L3
 
 
+TIMED_WITH_BARRIER = {"s": None}   # (N > 1: the last timed region's wall clock with the closing barrier inside the bracket, MAX over ranks)
+
+
 def timed(torch, dist, use_dist, stream, step, steps, finish=None, rest=0.0):
     """K back-to-back steps between ONE pair of HIP events on the launch stream, bracketed by barrier + synchronize on both
     sides; returns (max-over-ranks wall seconds, event span / K in ms).  `finish` (overlapped calls: sdrfm_flush) is called after the
@@ -293,12 +301,18 @@ def timed(torch, dist, use_dist, stream, step, steps, finish=None, rest=0.0):
     t_poll = time.perf_counter()
     while not ev1.query() and time.perf_counter() - t_poll < 30.0:   # (the closing synchronize then returns at once: a blocking wait's wake-up latency is not part of K steps)
         pass
-    fence()
+    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        # Every rank's clock stops at its OWN closing synchronize; the closing barrier follows, and the figure is the MAX over ranks — the time until the slowest
+        # rank was done, which is what a barrier inside the bracket measures plus the barrier's own latency (through RCCL: ~0.6 ms, more than the 20 steps of the
+        # driver's run take: it would halve `value` at every N > 1 and say nothing about the K steps).  TIMED_WITH_BARRIER keeps the other figure for the line.
+        dist.barrier()
+        torch.cuda.synchronize()
+        TIMED_WITH_BARRIER["s"] = time.perf_counter() - t0
+        t = torch.tensor([elapsed, TIMED_WITH_BARRIER["s"]], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, TIMED_WITH_BARRIER["s"] = float(t[0].item()), float(t[1].item())
     return elapsed, ev0.elapsed_time(ev1) / steps
 
 
@@ -441,6 +455,7 @@ def main():
     serial_regions = None
     if overlap:
         elapsed, kernel_ms_ovl = timed(torch, dist, use_dist, stream, step_ovl, args.steps, finish=dm.flush)
+        elapsed_with_barrier = TIMED_WITH_BARRIER["s"]
         served_by = dm.kernel_name
         routed_timed, routed_kernel = dm.route(), served_by      # (the assignment the timed region ran with: a stream is tried on design Q again every 1024 calls)
         if "overlapped" not in served_by:                        # a handle the matrix-pipe kernel does not serve (--bit-exact, other taps): the
@@ -460,6 +475,7 @@ def main():
         kernel_ms_avg = sorted(serial_regions)[len(serial_regions) // 2]
     else:
         elapsed, kernel_ms_avg = timed(torch, dist, use_dist, stream, step_rot, args.steps)
+        elapsed_with_barrier = TIMED_WITH_BARRIER["s"]
         routed_timed, routed_kernel = dm.route(), dm.kernel_name
     n_audio = last["n"]
     kernel_ms = per_launch_events(torch, stream, step_rot, min(args.steps, 20))
@@ -522,6 +538,9 @@ def main():
             "value": round(value, 1), "unit": "MSamples/s",
             "n_gpus": world, "rccl_world": rccl_world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            **({"timing": "N ranks through RCCL: the K steps from the opening barrier + synchronize to each rank's own closing synchronize, MAX over ranks; the closing barrier "
+                          "follows the clock — its own latency is in ms_per_step_with_closing_barrier, not in value",
+                "ms_per_step_with_closing_barrier": round(elapsed_with_barrier / args.steps * 1e3, 4)} if (use_dist and elapsed_with_barrier) else {}),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32 audio; K2 = u8 x 24-bit fixed-point taps on the i8 matrix pipe, exact i32 sums, one f32 recombination (design Q); K3 / K4 f32; "
                       "ill-conditioned phases recomputed with the f32 fmaf chain" if dm.kernel_name.startswith("fast-q") else "f32 (fmaf chains throughout)"),

@@ -17,7 +17,7 @@
  * k's block arrives in buffer k & 1 while repetition k - 1 is still being demodulated, the calls of consecutive repetitions run concurrently
  * on the device, and the fan-in of repetition k - 1 goes out behind sdrfm_flush_previous while call k runs; sdrfm_flush before the last one.
  */
-#define _POSIX_C_SOURCE 199309L   /* clock_gettime */
+#define _POSIX_C_SOURCE 200112L   /* clock_gettime, setenv */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -67,6 +67,9 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--reps") && i + 1 < argc) reps = atoi(argv[++i]);
   }
   if ((size_t)n_streams * nbytes != niq || (nbytes & 1u) || !n_streams) { fprintf(stderr, "iq.u8 must hold n_streams x nbytes_per_stream bytes (even)\n"); return 2; }
+  /* RCCL's streams take hardware queues out of the runtime's pool of 4; the library's overlapped calls need two of their own beside the caller's stream
+     (INTEGRATION.md): ask for 8 before the runtime starts, unless the environment already says otherwise */
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);
   int ndev = 0;
   HIPC(hipGetDeviceCount(&ndev));
   if (world <= 0 || world > ndev) world = ndev;
