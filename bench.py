@@ -35,7 +35,8 @@ sys.path.insert(0, ROOT)
 # and the library's two internal streams of the overlapped calls then share queues with the launch stream: every call waits for the one before it across queues —
 # 49 us per call instead of 23 on one GPU with world size 1 (tools/r05/dist_probe.sh, profiles/r05_q_experiments.txt item 16).  Eight queues restore it.  Set before
 # anything initialises the runtime; a caller's own setting is respected.  (INTEGRATION.md says the same to hosts that run RCCL beside the library.)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+if "WORLD_SIZE" in os.environ or "TORCHELASTIC_RUN_ID" in os.environ:   # (a rank of a distributed run; the plain N = 1 run keeps the runtime's default: 4 and 8 queues measure the same there)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 REST_S = float(os.environ.get("BENCH_REST_S", "0.05"))   # idle time before every secondary timed region (see timed())

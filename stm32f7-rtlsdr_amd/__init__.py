@@ -13,7 +13,8 @@ import os as _os
 # Overlapped calls (SDRFM_F_OVERLAP) need two hardware queues of their own beside the caller's stream; the HIP runtime maps a process's streams onto a pool of 4
 # by default and RCCL's streams take some of them.  Effective only when this package is imported before anything loads the runtime (torch);
 # a host that imports torch first sets the variable itself — bench.py does.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+if "WORLD_SIZE" in _os.environ or "TORCHELASTIC_RUN_ID" in _os.environ:   # (a rank of a torch.distributed run: RCCL will be in the process)
+    _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 from .lib import SdrfmError, load_library, library_path, STATUS, ABI_SYMBOLS
 from .demod import FmDemod, FmConfig
