@@ -1015,7 +1015,7 @@ struct sdrfm {
   // records ovl_done[k] behind the calls put on internal stream k and makes the handle's stream wait for it.
   hipStream_t ovl_stream[2];
   hipEvent_t ovl_in, ovl_done[2];
-  bool ovl_pending[2], ovl_bound[2];   // (bound: ovl_done[k] has been attached to a kernel of stream k at least once)
+  bool ovl_pending[2], ovl_bound[2], ovl_join_style;   // (bound: the latest kernel of stream k carries ovl_done[k] as its stop event; join_style: the caller joins after every call)
   uint32_t ovl_next;
   // the previous call's device buffer (valid after a SDRFM_F_DEVICE_PTRS call): what an overlapped call warms its streams up from
   const uint8_t* prev_iq; size_t prev_stride; uint32_t prev_nbytes;
@@ -1482,7 +1482,8 @@ int sdrfm_audio_count(const sdrfm_t* h, uint32_t nbytes, uint32_t* n_audio) {
 static int join_overlap(sdrfm* h) {
   for (int k = 0; k < 2; ++k)
     if (h->ovl_pending[k]) {
-      HIP_TRY(hipStreamWaitEvent(h->stream, h->ovl_done[k], 0), SDRFM_FAIL);   // (the completion event of the stream's latest kernel: enqueue())
+      if (!h->ovl_bound[k]) HIP_TRY(hipEventRecord(h->ovl_done[k], h->ovl_stream[k]), SDRFM_FAIL);   // (else: the stream's latest kernel carries the event — enqueue())
+      HIP_TRY(hipStreamWaitEvent(h->stream, h->ovl_done[k], 0), SDRFM_FAIL);
       h->ovl_pending[k] = false;
     }
   return SDRFM_OK;
@@ -1528,7 +1529,9 @@ int sdrfm_flush_previous(sdrfm_t* h) {
   if (!h) return SDRFM_EINVAL;
   HIP_TRY(hipSetDevice(h->device), SDRFM_FAIL);
   const uint32_t k = h->ovl_next;                                // the stream the NEXT call takes = the one the call before the last took
+  h->ovl_join_style = true;                                     // (a join after every call: from now on the kernels carry their stream's completion event)
   if (h->ovl_pending[k]) {
+    if (!h->ovl_bound[k]) HIP_TRY(hipEventRecord(h->ovl_done[k], h->ovl_stream[k]), SDRFM_FAIL);
     HIP_TRY(hipStreamWaitEvent(h->stream, h->ovl_done[k], 0), SDRFM_FAIL);
     h->ovl_pending[k] = false;
   }
@@ -1834,14 +1837,17 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
         else h->rt_win_need[k] = true;
       }
     }
-    // An overlapped call's kernel carries its internal stream's completion event itself (a stop event: the dispatch's own completion signal), so that
-    // sdrfm_flush / sdrfm_flush_previous / any call without the flag order the handle's stream behind it WITHOUT a marker packet in that queue — the consumer
-    // loop of INTEGRATION.md (flush_previous after every call) paid two hops across hardware queues per call for the markers: 31 us per call against 23.
-    // The kernel is the last thing the call puts on that stream, and a stream completes in order: the event also stands for the window's kernels on it.
-    if (ovl) { done = h->ovl_done[k]; if (h->rt_win_used[k]) h->rt_win_need[k] = false; }
+    // For a caller that joins after every call (sdrfm_flush_previous: the consumer loop of INTEGRATION.md) an overlapped call's kernel carries its internal
+    // stream's completion event itself (a stop event: the dispatch's own completion signal), so that the join orders the handle's stream behind it WITHOUT a marker
+    // packet in that queue: 31 -> 29.4 us per call of that loop.  The kernel is the last thing the call puts on that stream, and a stream completes in order: the
+    // event also stands for the window's kernels on it.  A caller that joins once in a while (sdrfm_flush at the end of a burst: bench.py) keeps kernels without a
+    // stop event and pays one marker per join: under the kernel tracer a stop event on every kernel shortens the time two kernels are resident (0.96 -> 0.75 of a
+    // 100-call burst, +3 % per call; un-profiled within the noise): profiles/r05_q_experiments.txt item 15.
+    const bool carry = ovl && h->ovl_join_style;
+    if (carry) { done = h->ovl_done[k]; if (h->rt_win_used[k]) h->rt_win_need[k] = false; }
     if (fuse && pb_blocks) HIP_TRY(sdrfm_q_launch_mix(q, h->q_c0, h->q_nslot, c.fir_decim, c.audio_decim, pb, pb_blocks, pb_R, qs, done), SDRFM_FAIL);
     else HIP_TRY(sdrfm_q_launch(q, h->q_c0, h->q_nslot, c.fir_decim, c.audio_decim, qs, done), SDRFM_FAIL);
-    if (ovl) { h->ovl_pending[k] = true; h->ovl_bound[k] = true; }
+    if (ovl) { h->ovl_pending[k] = true; h->ovl_bound[k] = carry; }
     h->prev_ovl_audio = ovl ? d_audio : nullptr; h->prev_ovl_audio_stride = audio_stride; h->prev_ovl_audio_n = A;
     h->yprev_exact = false; h->hist_q_valid = true;
     if (h->rt_noisy && !h->rt_off && h->rt_win_stats) {
