@@ -63,6 +63,7 @@ def parse():
                     "comparison figures, labelled as such")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-steady", action="store_true", help="skip the steady-state series (ten regions of 300 calls; fm workload)")
+    ap.add_argument("--no-bit-exact-leg", action="store_true", help="skip the SDRFM_CFG_BIT_EXACT comparison leg of the default line (bit_exact_kernel)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--check", action="store_true", help="also verify a few streams against the oracle (not timed)")
     ap.add_argument("--workload", choices=["fm", "wbfm", "spectrum"], default="fm",
@@ -160,6 +161,12 @@ def bound_block(kind, kname, ms, alg, traffic):
         if c.get("SQ_LDS_IDX_ACTIVE") and c.get("SQ_BUSY_CYCLES"):
             blk["lds_active_cycles_per_cu_over_kernel_cycles"] = round(c["SQ_LDS_IDX_ACTIVE"] / 256.0 / (c["SQ_BUSY_CYCLES"] / 32.0), 3)
         blk["instruction_floor_ms"] = round(ms * blk["valu_issue_busy_fraction"], 4) if kind == "valu" else None
+        if kind == "valu":
+            # the kernel's OWN roofline: the vector pipe issues one wave-instruction per SIMD and issue cycle; valu_frac = issue cycles the kernel's vector
+            # instructions need (counted: SQ_ACTIVE_INST_VALU) / issue cycles the launch had (SQ_BUSY_CYCLES x SIMDs), both from ONE counter pass
+            blk["valu_frac"] = blk["valu_issue_busy_fraction"]
+            blk["valu_frac_note"] = ("fraction of the vector pipe's issue cycles this kernel's instructions occupy (4 SQ_ACTIVE_INST_VALU / 1024 SIMDs / kernel cycles, one counter "
+                                     "pass): the roofline that binds it; the HBM fraction above is what BASELINE's metric is quoted against")
         blk["pipe_figures_source"] = "profiles/%s (separate rocprofv3 --pmc passes at commit %s)" % (d["file"], d.get("commit", "?"))
     return blk
 
@@ -273,12 +280,16 @@ def pick_batches(args, bytes_per_batch):
     return max(3, -(-int(1.5 * L3_BYTES) // int(bytes_per_batch)) + 1)   # (nb - 1) batches between two uses of one > 1.5 x L3
 
 
+DIST_DEVICE = {"d": "cuda"}         # where the ranks' bookkeeping tensors live (the CPU test of that bookkeeping, under gloo, sets "cpu")
 TIMED_WITH_BARRIER = {"s": None}   # (N > 1: the last timed region's wall clock with the closing barrier inside the bracket, MAX over ranks)
 
 
 def timed(torch, dist, use_dist, stream, step, steps, finish=None, rest=0.0):
-    """K back-to-back steps between ONE pair of HIP events on the launch stream, bracketed by barrier + synchronize on both
-    sides; returns (max-over-ranks wall seconds, event span / K in ms).  `finish` (overlapped calls: sdrfm_flush) is called after the
+    """K back-to-back steps between ONE pair of HIP events on the launch stream; returns (max-over-ranks wall seconds, event span / K in ms).
+    N = 1: the wall clock runs from behind the opening synchronize to behind the closing one.  N > 1: barrier + synchronize open the bracket on
+    every rank; a rank's clock stops at its OWN closing synchronize, the closing barrier follows, and the figure is the MAX over ranks (the skew
+    between ranks leaving the opening barrier is therefore not in it; `ms_per_step_with_closing_barrier` in the line is the common-end reading).
+    `finish` (overlapped calls: sdrfm_flush) is called after the
     last step, before the closing event: it puts the launch stream behind every call.  `rest` seconds of idle GPU first (the secondary
     regions: each starts from the same rested state instead of inheriting the previous region's power / clock state — a serial region run
     right behind 100 overlapped calls measured 37 us per call against 27 - 29 us a few milliseconds later)."""
@@ -311,10 +322,34 @@ def timed(torch, dist, use_dist, stream, step, steps, finish=None, rest=0.0):
         dist.barrier()
         torch.cuda.synchronize()
         TIMED_WITH_BARRIER["s"] = time.perf_counter() - t0
-        t = torch.tensor([elapsed, TIMED_WITH_BARRIER["s"]], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, TIMED_WITH_BARRIER["s"]], dtype=torch.float64, device=DIST_DEVICE["d"])
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, TIMED_WITH_BARRIER["s"] = float(t[0].item()), float(t[1].item())
     return elapsed, ev0.elapsed_time(ev1) / steps
+
+
+def gather_per_rank(torch, dist, world, x, device="cuda"):
+    """every rank's figure on every rank (N > 1: `roofline.per_rank_kernel_ms`)"""
+    t = torch.tensor([x], dtype=torch.float64, device=device)
+    gathered = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(gathered, t)
+    return [round(float(v.item()), 4) for v in gathered]
+
+
+def scaling_fields(world, rccl_world, ns, nsamp, steps, elapsed, elapsed_with_barrier, use_dist):
+    """the fields of the JSON line that depend on the number of ranks: whole-job throughput over ALL ranks' streams / the max-over-ranks time"""
+    out = {"value": round(float(world) * ns * nsamp * steps / elapsed / 1e6, 1), "unit": "MSamples/s", "n_gpus": world, "rccl_world": rccl_world,
+           "ms_per_step": round(elapsed / steps * 1e3, 4), "scaling": "weak"}
+    if use_dist and elapsed_with_barrier:
+        out["timing"] = ("N ranks through RCCL: the K steps from the opening barrier + synchronize to each rank's own closing synchronize, MAX over ranks; the closing barrier "
+                         "follows the clock — its own latency is in ms_per_step_with_closing_barrier, not in value")
+        out["ms_per_step_with_closing_barrier"] = round(elapsed_with_barrier / steps * 1e3, 4)
+    return out
+
+
+def read_basis(samples_per_launch, ms):
+    """fraction of the 8 TB/s HBM-READ roofline: samples x 2 B / time — the basis BASELINE.md section 2 defines the >= 70 % target on (the audio writes are not counted)"""
+    return round(samples_per_launch * 2.0 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if ms else None
 
 
 def steady_regions(torch, stream, step, finish=None, regions=10, steps=300):
@@ -496,6 +531,32 @@ def main():
         if overlap:
             time.sleep(REST_S)
             steady_ovl = steady_regions(torch, stream, step_ovl, finish=dm.flush)
+    # the north-star's literal design beside the default one: a SDRFM_CFG_BIT_EXACT handle — fp32 fmaf chains on the vector pipe, no matrix
+    # instruction, bit-identical to the definition's chains — over the same rotated batches: K serial calls from rest (median of five regions when K is short) and
+    # the steady series.  A second handle; nothing of the default handle's figures depends on it.
+    bit_exact_leg = None
+    if e2e is None and not use_dist and not args.bit_exact and not args.dev_library and not args.no_bit_exact_leg and args.iq_class == "fm":
+        time.sleep(REST_S)
+        dx = pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, fir_decim=D, audio_decim=Da, n_streams=ns, device=local_rank, bit_exact=True))
+        dx.set_stream(stream.cuda_stream)
+
+        def step_bx(i):
+            dx.process_batch_device(batches[i % nb], audio)
+        regs = []
+        for _ in range(5 if args.steps < 100 else 1):
+            time.sleep(REST_S)
+            for i in range(args.warmup):
+                step_bx(i)
+            regs.append(timed(torch, dist, False, stream, step_bx, args.steps)[1])
+        bx_ms = sorted(regs)[len(regs) // 2]
+        bx_steady = None
+        if not args.no_steady:
+            time.sleep(REST_S)
+            bx_steady = steady_regions(torch, stream, step_bx)
+        bit_exact_leg = {"kernel": dx.kernel_name, "ms": bx_ms, "regions": regs, "steady": bx_steady}
+        dx.synchronize()
+        dx.set_stream(None)
+        dx.close()
     # second, labelled figure: ONE resident input batch (fits the 256 MiB Infinity Cache) — what round 1 reported as `value`
     res_steps = min(args.steps, 100)
     for i in range(min(args.warmup, 10)):
@@ -507,12 +568,7 @@ def main():
     time.sleep(REST_S)
     peak_measured = read_ceiling(pkg, batches, local_rank) if e2e is None else None
     guard = dm.q_guard()
-    per_rank = None
-    if use_dist:
-        t = torch.tensor([kernel_ms_avg], dtype=torch.float64, device="cuda")
-        gathered = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(gathered, t)
-        per_rank = [round(float(x.item()), 4) for x in gathered]
+    per_rank = gather_per_rank(torch, dist, world, kernel_ms_avg) if use_dist else None
 
     ok = None
     if args.check and rank == 0:
@@ -528,21 +584,17 @@ def main():
             ok = ok and bool(err <= 1e-5)
 
     if rank == 0:
-        total_samples = float(world) * ns * nsamp * args.steps
-        value = total_samples / elapsed / 1e6
+        sf = scaling_fields(world, rccl_world, ns, nsamp, args.steps, elapsed, elapsed_with_barrier, use_dist)
+        value = sf["value"]
         samples_per_launch = ns * nsamp
         alg_bytes = samples_per_launch * 2.0 + ns * n_audio * 4.0        # 2 B in + 4/(D*Da) B out per IQ sample
         achieved = alg_bytes / (kernel_ms_avg * 1e-3) / 1e9
         traffic = latest_traffic(dm.kernel_name, alg_bytes)
         res = {
             "metric": "IQ MSamples/s through FIR+FM-demod+resample",
-            "value": round(value, 1), "unit": "MSamples/s",
-            "n_gpus": world, "rccl_world": rccl_world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            **({"timing": "N ranks through RCCL: the K steps from the opening barrier + synchronize to each rank's own closing synchronize, MAX over ranks; the closing barrier "
-                          "follows the clock — its own latency is in ms_per_step_with_closing_barrier, not in value",
-                "ms_per_step_with_closing_barrier": round(elapsed_with_barrier / args.steps * 1e3, 4)} if (use_dist and elapsed_with_barrier) else {}),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            **{k: sf[k] for k in ("value", "unit", "n_gpus", "rccl_world")}, "steps": args.steps, "warmup": args.warmup,
+            **{k: sf[k] for k in ("ms_per_step", "timing", "ms_per_step_with_closing_barrier") if k in sf},
+            "higher_is_better": True, "scaling": sf["scaling"], "vs_baseline": None,
             "dtype": ("f32 audio; K2 = u8 x 24-bit fixed-point taps on the i8 matrix pipe, exact i32 sums, one f32 recombination (design Q); K3 / K4 f32; "
                       "ill-conditioned phases recomputed with the f32 fmaf chain" if dm.kernel_name.startswith("fast-q") else "f32 (fmaf chains throughout)"),
             "data": ("synthetic" if args.iq_class == "fm" else
@@ -584,6 +636,34 @@ def main():
                             if serial_regions and len(serial_regions) > 1 else {})},
             "gen_seconds": round(t_gen, 2),
         }
+        # The >= 70 % target of BASELINE.md section 2 is defined on the HBM-READ basis (2 B per IQ sample; the audio writes are not counted): every
+        # fraction above again on that basis, and whether the target is met — judged on the steady overlapped calls (what a consumer that runs for
+        # seconds gets through the API's fastest way), or on the timed region's overlapped calls when the steady series was not taken.
+        rl = res["roofline"]
+        rb = {"bytes_per_launch": samples_per_launch * 2.0, "frac": read_basis(samples_per_launch, kernel_ms_avg),
+              "frac_sustained": read_basis(samples_per_launch, kernel_ms_sus),
+              "frac_steady": read_basis(samples_per_launch, float(np.median(steady_ser[5:]))) if steady_ser else None,
+              "note": "samples x 2 B / time / 8 TB/s — the basis the >= 70 % target is defined on; `frac` etc. above count the audio writes too (2.08 B per sample)"}
+        if overlap:
+            rb["overlapped_calls"] = {"frac": read_basis(samples_per_launch, kernel_ms_ovl), "frac_sustained": read_basis(samples_per_launch, kernel_ms_ovl_sus),
+                                      "frac_steady": read_basis(samples_per_launch, float(np.median(steady_ovl[5:]))) if steady_ovl else None}
+        rl["read_basis"] = rb
+        rl["frac_read_basis"] = rb["frac"]
+        judged = (rb.get("overlapped_calls", {}).get("frac_steady") or rb.get("overlapped_calls", {}).get("frac") or rb["frac_steady"] or rb["frac"])
+        rl["target_70pct_read_roofline_met"] = bool(judged is not None and judged >= 0.70) if (D == 10 and args.iq_class == "fm" and not args.bit_exact) else None
+        rl["target_judged_on"] = {"frac_read_basis": judged, "which": ("overlapped calls, steady state" if rb.get("overlapped_calls", {}).get("frac_steady") else
+                                                                      "overlapped calls, the timed region" if rb.get("overlapped_calls", {}).get("frac") else
+                                                                      "serial calls, steady state" if rb["frac_steady"] else "serial calls, the timed region")}
+        if bit_exact_leg:
+            bx = bit_exact_leg
+            res["bit_exact_kernel"] = {
+                "handle": "SDRFM_CFG_BIT_EXACT: the north-star's literal design (fp32 fmaf chains on the vector pipe, no matrix instruction), bit-identical to the definition's chains; NOT the default path",
+                "kernel": bx["kernel"], "kernel_ms_avg": round(bx["ms"], 4), "kernel_ms_avg_regions": [round(x, 4) for x in bx["regions"]],
+                "value": round(samples_per_launch / (bx["ms"] * 1e-3) / 1e6, 1), "unit": "MSamples/s (serial calls, event span / K)",
+                "frac": round(alg_bytes / (bx["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "frac_read_basis": read_basis(samples_per_launch, bx["ms"]),
+                **({"frac_steady": round(alg_bytes / (float(np.median(bx["steady"][5:])) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                    "frac_steady_read_basis": read_basis(samples_per_launch, float(np.median(bx["steady"][5:]))),
+                    "kernel_ms_regions_300": [round(x, 4) for x in bx["steady"]]} if bx["steady"] else {})}
         routed = routed_timed
         if routed is not None and (args.iq_class != "fm" or int(routed.sum())):
             res["routing"] = {"streams_on_bit_exact_kernels": int(routed.sum()), "streams": ns, "kernels_timed_region": routed_kernel,

@@ -1657,8 +1657,14 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
   if (bx_all) {
     // A bit-exact kernel takes over from design Q: the y[-1] it is handed must be the definition's (design Q's own is within 1e-4 of it,
     // which a small |y| would turn into a wrong d[0]): recomputed from the 64 raw samples design Q left.
-    if (!h->yprev_exact && h->hist_q_valid)
-      HIP_TRY(sdrfm_q_fix_yprev(h->d_hist_q[h->cur], h->d_hpad, h->d_yprev[h->cur], c.n_streams, nullptr, h->stream), SDRFM_FAIL);
+    // Only the streams design Q served at the previous call (the clean part of the list in use, as in route_apply): a routed stream's y[-1] IS
+    // the definition's — its bit-exact kernel wrote it — and design Q left no raw samples for it (a call design Q cannot take behind
+    // a mixed call overwrote it from stale rows; tests/test_route_gpu.py::test_a_call_design_q_cannot_take_behind_mixed_calls).
+    if (!h->yprev_exact && h->hist_q_valid) {
+      const uint32_t nn = h->rt_noisy ? h->rt_n_noisy : 0u;
+      HIP_TRY(sdrfm_q_fix_yprev(h->d_hist_q[h->cur], h->d_hpad, h->d_yprev[h->cur], c.n_streams - nn, nn ? h->rt_list_dev[h->rt_list_cur] : nullptr, h->stream),
+              SDRFM_FAIL);
+    }
     h->yprev_exact = true; h->hist_q_valid = false;
     h->prev_ovl_audio = nullptr;
   }

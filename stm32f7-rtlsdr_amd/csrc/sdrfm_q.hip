@@ -88,6 +88,18 @@ struct QGeo {
   static_assert(QTP + 2 * D <= 96, "the tap table of the repair path sits below the d history");
   static_assert(D % 2 == 0 && D <= 16 && (ALIGNED || D == 10), "geometries the ring logic is written for");
 };
+#ifndef SDRFM_Q_K3
+#define SDRFM_Q_K3 1    // 1 (round 6): K3 as a difference of angles, the guard's norms taken from the arctangent (q_angle); 0: the conjugate-product form of rounds 3 - 5
+#endif
+#ifndef SDRFM_Q_XORSKIP
+#define SDRFM_Q_XORSKIP 1   // 1 (round 6): D = 10, T <= 64: window bytes 0 .. 51 meet no tap (qtaps.c: tap k = 89 + 10 o - w < 64), so the first dword of a lane's first piece
+#endif                      // (bytes 16 g .. 16 g + 3 <= 51) needs no byte - 128: one v_xor less per step
+#ifndef SDRFM_Q_MICRO
+#define SDRFM_Q_MICRO 1     // 1 (round 6): the carried angle enters lane 0 through v_writelane (one instruction instead of a move and a select); the d write's address
+#endif                      // is one shift-add on a pointer kept in a VGPR (the compiler re-added the buffer's offset every step)
+#ifndef SDRFM_Q_MAGIC
+#define SDRFM_Q_MAGIC 0     // experiment (round 6): the digits' sums leave the matrix pipe as floats — accumulators start at the bit pattern of 1.5 * 2^23, so that
+#endif                      // as_float(acc) - 1.5 * 2^23 = S exactly (|S| <= 2^20): a full-rate subtraction instead of v_cvt_f32_i32 and the shift-add; 2: the factors in VGPRs
 #ifndef SDRFM_Q_AUX
 #define SDRFM_Q_AUX 2   // cache policy of the ring's fetches: 2 = nt (streamed once; measured 0.4-1 us per launch better than the default policy)
 #endif
@@ -119,6 +131,37 @@ __device__ __forceinline__ float q_discriminate(float yr, float yi, float pr, fl
   if (ay > ax) a = 0x1.921fb6p+0f - a;
   if (re < 0.0f) a = 0x1.921fb6p+1f - a;
   return __builtin_copysignf(a, im);
+}
+
+// K3 as a DIFFERENCE OF ANGLES (round 6, SDRFM_Q_K3 = 1): theta[m] = atan2(yi, yr) once per output, d[m] = theta[m] - theta[m-1] wrapped into
+// [-pi, pi].  Against the conjugate-product form above this drops the five instructions of the product per output and halves the
+// neighbour exchange (one angle instead of a complex number); the arctangent's larger magnitude max(|yr|, |yi|) IS the norm the
+// conditioning guard tests, so the guard's three v_max and its v_min3 go too (sdrfm_q.hip: "the conditioning guard").  The price is
+// one more rounding of the arctangent in every d (both angles carry the polynomial's 3.9e-7) and the wrap: |d - definition's d| <= 1.1e-6
+// worst case where the phase is well conditioned (the guard's business where it is not), measured 7e-7 (tools/q_emulate.py k3="diff").
+__device__ __forceinline__ float q_angle(float yr, float yi, float& mx_out) {
+  const float ax = __builtin_fabsf(yr), ay = __builtin_fabsf(yi);
+  const float mx = __builtin_fmaxf(__builtin_fmaxf(ax, ay), 0x1p-120f), mn = __builtin_fminf(ax, ay);   // v_max3_f32, v_min_f32
+  mx_out = mx;
+  const float v = mn * __builtin_amdgcn_rcpf(mx);
+  const float s2 = v * v;
+  float q = 0x1.e34882p-8f;
+  q = __builtin_fmaf(q, s2, -0x1.22fc74p-5f);
+  q = __builtin_fmaf(q, s2, 0x1.509024p-4f);
+  q = __builtin_fmaf(q, s2, -0x1.12688cp-3f);
+  q = __builtin_fmaf(q, s2, 0x1.96c562p-3f);
+  q = __builtin_fmaf(q, s2, -0x1.554086p-2f);
+  float a = __builtin_fmaf(v, s2 * q, v);
+  if (ay > ax) a = 0x1.921fb6p+0f - a;
+  if (yr < 0.0f) a = 0x1.921fb6p+1f - a;
+  return __builtin_copysignf(a, yi);
+}
+// x in (-2 pi, 2 pi) -> x - 2 pi rint(x / 2 pi): three full-rate instructions (the rounding through the 1.5 * 2^23 constant; v_rndne_f32 is a quarter-rate one)
+__device__ __forceinline__ float q_wrap(float x) {
+  float t = __builtin_fmaf(x, 0x1.45f306p-3f, 0x1.8p+23f);
+  asm volatile("" : "+v"(t));                                   // (keeps the two roundings apart)
+  const float k = t - 0x1.8p+23f;
+  return __builtin_fmaf(k, -0x1.921fb6p+2f, x);
 }
 
 template <int N>
@@ -306,6 +349,17 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
     if (lane + 64 < HT) *reinterpret_cast<unsigned short*>(smem + ((PRE - 2 * HT + 2 * (lane + 64)) ^ HSW)) = hb1;
     if (lane < QTA - 1) db[DB0 + sigma - (QTA - 1) + lane] = hd0;
   }
+#if SDRFM_Q_K3
+  // the angle of y[m-1] of the step's first output and whether its norm is inside the guard's radius (a warm-up: neither matters, see above)
+  float cth = 0.0f;
+  unsigned long long cfl = 0ull;
+  if (!warm) {
+    float mxp;
+    const float tp = q_angle(cr, ci, mxp);
+    cth = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tp)));
+    cfl = __builtin_amdgcn_ballot_w64(mxp < p.guard_r) & 1ull;
+  }
+#endif
   db[lane] = hz0;
   if (lane < 2 * QD) db[64 + lane] = hz1;
 #if SDRFM_Q_GTAB
@@ -550,8 +604,34 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
 #ifdef SDRFM_Q_SCALE_VGPR   // experiment (round 5): the recombination's factors in VGPRs (an FMA with an SGPR operand issues at half rate) — measured 0.2 us
   float q0v = p.q0, q2v = p.q2, cstv = p.cst;                  // per call SLOWER than leaving them in SGPRs (the kernel sits at its 128 VGPRs): profiles/r05_q_experiments.txt
   asm volatile("" : "+v"(q0v), "+v"(q2v), "+v"(cstv));
+#elif SDRFM_Q_MAGIC == 2
+  float q0v = p.q0, q2v = p.q2;
+  const float cstv = p.cst;
+  asm volatile("" : "+v"(q0v), "+v"(q2v));
 #else
   const float q0v = p.q0, q2v = p.q2, cstv = p.cst;
+#endif
+#ifdef SDRFM_Q_ZMFMA
+  qi4_t qz4 = {0, 0, 0, 0};
+  asm volatile("" : "+v"(qz4));
+#endif
+  [[maybe_unused]] constexpr int QMB = 0x4B400000;               // the bit pattern of 1.5 * 2^23: + S (|S| < 2^22) is the float 1.5 * 2^23 + S
+#if defined(SDRFM_Q_ZMFMA) && SDRFM_Q_MAGIC
+  qi4_t qmb4 = {QMB, QMB, QMB, QMB};
+  asm volatile("" : "+v"(qmb4));
+#else
+  [[maybe_unused]] const qi4_t qmb4 = {0, 0, 0, 0};
+#endif
+#if SDRFM_Q_MAGIC == 2
+  float q1v = 256.0f * p.q0, qmf = 0x1.8p+23f;
+  asm volatile("" : "+v"(q1v), "+v"(qmf));
+#elif SDRFM_Q_MAGIC
+  const float q1v = 256.0f * p.q0;
+  constexpr float qmf = 0x1.8p+23f;
+#endif
+#if SDRFM_Q_MICRO && SDRFM_Q_K3
+  int doff = (PRE + RINGB) + 4 * (DB0 + sigma + dlane);          // LDS byte offset of the lane's two d's of the stage's first step (opaque: an offset, not a
+  asm volatile("" : "+v"(doff));                                // pointer — an opaque POINTER loses its address space and the write becomes a flat store)
 #endif
   const int wrank = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 4) & 15u);
   const int prio_at = p.prio_by_age ? nsteps / 2 : -1;
@@ -574,11 +654,19 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
     // ---- K2 on the matrix pipe ------------------------------------------------------------------------------------------------
     qi4_t acc[SDRFM_Q_DIGITS];
 #pragma unroll
-    for (int t = 0; t < SDRFM_Q_DIGITS; ++t) acc[t] = qi4_t{0, 0, 0, 0};
+    for (int t = 0; t < SDRFM_Q_DIGITS; ++t) {
+#ifdef SDRFM_Q_ZMFMA   // experiment (round 6): the accumulators zeroed by the matrix pipe (one dense issue with a zero A operand: 0 * B + 0) instead of two v_mov_b64 each
+      asm volatile("" : "+v"(qz4));                               // (opaque: three issues, not one and two copies)
+      acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(qz4, qz4, SDRFM_Q_MAGIC ? qmb4 : qi4_t{0, 0, 0, 0}, 0, 0, 0);
+#else
+      acc[t] = SDRFM_Q_MAGIC ? qi4_t{QMB, QMB, QMB, QMB} : qi4_t{0, 0, 0, 0};
+#endif
+    }
     [[maybe_unused]] constexpr int XM = (int)0x80808080;
 #ifndef SDRFM_Q_LDSXOR
 #pragma unroll
-    for (int c = 0; c < NB - 1 + (NCH & 1 ? 0 : 1); ++c) B[c] = B[c] ^ qi4_t{XM, XM, XM, XM};   // byte - 128 as i8 (not the piece beyond the window)
+    for (int c = 0; c < NB - 1 + (NCH & 1 ? 0 : 1); ++c)                                      // byte - 128 as i8 (not the piece beyond the window)
+      B[c] = B[c] ^ ((SDRFM_Q_XORSKIP && QD == 10 && C0 == 0 && c == 0) ? qi4_t{0, XM, XM, XM} : qi4_t{XM, XM, XM, XM});
 #endif
 #pragma unroll
     for (int c = C0; c < NSC; ++c) {
@@ -598,14 +686,39 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
     float y[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
+#if SDRFM_Q_MAGIC
+      const int i0 = acc[0][r], i1 = acc[1][r], i2 = acc[2][r];   // (copies: __builtin_bit_cast of a vector ELEMENT reads element 0 whatever the index — clang 22)
+      const float f0 = __builtin_bit_cast(float, i0) - qmf, f1 = __builtin_bit_cast(float, i1) - qmf, f2 = __builtin_bit_cast(float, i2) - qmf;   // exact
+      y[r] = __builtin_fmaf(f0, q0v, __builtin_fmaf(f1, q1v, __builtin_fmaf(f2, q2v, cstv)));
+#else
       const int s01 = acc[0][r] + acc[1][r] * 256;              // exact: |S0| <= 2^20, |S1 << 8| <= 2^28
       y[r] = __builtin_fmaf((float)s01, q0v, __builtin_fmaf((float)acc[2][r], q2v, cstv));
+#endif
     }
 #ifdef SDRFM_Q_PHASES
     asm volatile("" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
 #endif
     Q_PHASE(3);                                                 // xor, MFMAs, recombination
     // ---- K3: y[m-1] of the lane's first output sits in lane - 16 (or is the previous step's last output) -------------------------
+#if SDRFM_Q_K3
+    // (round 6) angles, not products: the lane's second angle first — it is what the neighbour needs —, the exchange in flight under the first one's chain
+    float mx0, mx1;
+    const float th1 = q_angle(y[2], y[3], mx1);
+    float thp = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(srcaddr, __builtin_bit_cast(int, th1)));
+    const float th0 = q_angle(y[0], y[1], mx0);
+#if SDRFM_Q_MICRO
+    asm("v_writelane_b32 %0, %1, 0" : "+v"(thp) : "s"(cth));    // lane 0: the carried angle
+#else
+    if (lane == 0) thp = cth;
+#endif
+#ifdef SDRFM_Q_PHASES
+    asm volatile("" : "+v"(thp));
+#endif
+    Q_PHASE(4);                                                 // neighbour exchange
+    cth = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, th1), 63));
+    const float d1 = q_wrap(th1 - th0);
+    const float d0 = q_wrap(th0 - thp);
+#else
     float pr = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(srcaddr, __builtin_bit_cast(int, y[2])));
     float pi = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(srcaddr, __builtin_bit_cast(int, y[3])));
     if (lane == 0) { pr = cr; pi = ci; }
@@ -621,8 +734,13 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
     const float d1 = q_discriminate(y[2], y[3], y[0], y[1]);   // (the pair that needs no neighbour first: its chain runs while the exchange is in flight)
     const float d0 = q_discriminate(y[0], y[1], pr, pi);
 #endif
+#endif
     {
+#if SDRFM_Q_MICRO && SDRFM_Q_K3
+      float* dst = reinterpret_cast<float*>(smem + (doff + 512 * osm));
+#else
       float* dst = db + DB0 + sigma + 128 * osm + dlane;
+#endif
       dst[0] = d0;
       dst[1] = d1;
     }
@@ -634,6 +752,21 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
     // within reach of the cut (above guard_a) is put on a list; its two d's are recomputed by the definition's own chain before anything
     // reads them (repair_flagged).  An FM carrier never gets here; noise-only input does, a few lanes per step.
     {
+#if SDRFM_Q_K3
+      // (round 6) the norms are the arctangents' own larger magnitudes: two compares; the neighbour's y[m-1] is small exactly when the lane it came
+      // from found its second norm small — a shift of that lane mask in scalar registers (lane l > 15 took it from lane l - 16, lane n in 1 .. 15 from
+      // lane 47 + n, lane 0 from the previous step's lane 63) instead of a third norm and a v_min3
+      float t1;
+      unsigned long long fm, m0, m1;
+      asm("v_cmp_lt_f32_e64 %[m0], %[x0], %[gr]\n\t"
+          "v_cmp_lt_f32_e64 %[m1], %[x1], %[gr]\n\t"
+          "v_max_f32_e64 %[t1], |%[d0]|, |%[d1]|\n\t"
+          "v_cmp_gt_f32_e64 %[fm], %[t1], %[ga]"
+          : [t1] "=&v"(t1), [fm] "=&s"(fm), [m0] "=&s"(m0), [m1] "=&s"(m1)
+          : [x0] "v"(mx0), [x1] "v"(mx1), [d0] "v"(d0), [d1] "v"(d1), [gr] "v"(guard_r), [ga] "v"(guard_a));
+      fm |= m0 | m1 | (m1 << 16) | ((m1 >> 47) & 0xFFFEull) | cfl;
+      cfl = m1 >> 63;
+#else
       float t0, t1, t2;
       unsigned long long fm, fm2;
 #ifdef SDRFM_Q_GUARD_L1   // experiment (round 5): |re| + |im| (a full-rate add) instead of max(|re|, |im|) against twice the radius: flags a superset
@@ -655,6 +788,7 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
           : [y0] "v"(y[0]), [y1] "v"(y[1]), [y2] "v"(y[2]), [y3] "v"(y[3]), [pr] "v"(pr), [pi] "v"(pi), [d0] "v"(d0), [d1] "v"(d1),
             [gr] "v"(guard_r), [ga] "v"(guard_a)
           : "scc");
+#endif
       if (fm) {                                                                                // wave-uniform, rare
         if (kk == nsteps - 1 && nlast < 16) fm &= 0x0001000100010001ull * ((1ull << nlast) - 1ull);   // the run's last step: only its first nlast blocks exist
         if (fm) {

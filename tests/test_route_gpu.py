@@ -251,3 +251,47 @@ def test_random_call_sequences_with_the_assignment_changing_under_them(pkg, orac
         seen[key] = s
         want = oracle_mod.Oracle(h, g, D=D, Da=Da).process(iq[s])
         assert scaled_err(got[s], want) <= TOL, (s, key, names)
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_a_call_design_q_cannot_take_behind_mixed_calls(pkg, oracle_mod, overlap):
+    """a mixed call leaves design Q's own y[-1] for the clean streams only; a following call design Q cannot serve (here: a length that
+    is no whole number of audio periods, so the bit-exact kernels take the whole batch) must turn exactly THOSE into the definition's y[-1] — the routed
+    streams' are the definition's already, and design Q left no raw samples for them.  (The bug: all streams were 'fixed' from stale rows; d[0] of the
+    routed streams, hence ~Ta / Da audio outputs each, left the tolerance.)  Carriers and noise on both sides of the assignment, every distinct row
+    against the oracle over the whole sequence."""
+    import torch
+    h, g = pkg.default_config(64)
+    D, Da = 10, 5
+    unit = D * Da * 8
+    ns = 256
+    lens = [unit * 120, unit * 120, unit * 120, unit * 97 + D * Da, unit * 120 - D * Da, unit * 120, unit * 60 + 2 * D, unit * 120]
+    total = sum(lens)
+    iq, _, src, fm, rnd = _mixed_rows(pkg, ns, total, 5, first_id=7300)
+    dev = torch.from_numpy(iq).cuda()
+    mask = np.array([1 if s % 4 == 2 else 0 for s in range(ns)], dtype=np.uint8)     # routed by the test hook: carriers and noise alike
+    bufs = [torch.zeros((ns, n // (D * Da) + 2), dtype=torch.float32, device="cuda") for n in lens]
+    torch.cuda.synchronize()
+    names, counts = [], []
+    with pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=ns, max_bytes_per_call=2 * max(lens))) as dm:
+        off = 0
+        for k, n in enumerate(lens):
+            if k == 1:
+                assert np.array_equal(dm.route(mask), mask)
+            counts.append(dm.process_batch_device(dev[:, 2 * off:], bufs[k], nbytes=2 * n, overlap=overlap))
+            names.append(dm.kernel_name)
+            off += n
+        dm.synchronize()
+    assert "+" in names[1] and "+" in names[2] and "+" in names[5], names          # mixed calls ...
+    assert not names[3].startswith("fast-q") and not names[6].startswith("fast-q"), names   # ... and calls design Q cannot take right behind them
+    got = np.concatenate([b.cpu().numpy()[:, :c] for b, c in zip(bufs, counts)], axis=1)
+    seen = {}
+    for s in range(ns):
+        key = (src[s], int(mask[s]))
+        if key in seen:
+            assert np.array_equal(got[s].view(np.uint32), got[seen[key]].view(np.uint32)), (s, seen[key], key)
+            continue
+        seen[key] = s
+        row = rnd[src[s][1]] if src[s][0] == "r" else fm[src[s][1]]
+        want = oracle_mod.Oracle(h, g).process(row[:2 * total])
+        assert scaled_err(got[s], want) <= TOL, (s, key, names)

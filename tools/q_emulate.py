@@ -69,6 +69,14 @@ def q_atan2_dev(im, re):
     return np.copysign(a, im).astype(np.float32)
 
 
+def q_wrap_dev(x):
+    """x in (-2 pi, 2 pi) -> x - 2 pi rint(x / 2 pi) as the kernel evaluates it (csrc/sdrfm_q.hip q_wrap): the rounding through 1.5 * 2^23, three fp32 operations"""
+    big = np.float32(12582912.0)
+    t = fma32(x, np.float32(float.fromhex("0x1.45f306p-3")), big)
+    k = f32(t - big)
+    return fma32(k, np.float32(float.fromhex("-0x1.921fb6p+2")), x)
+
+
 def chain_y(iq, h, D, m):
     """the DEFINITION's y[m] for the output indices m (all windows inside the stream): acc = fmaf(h[k], x, acc), oldest sample first, x = byte - 127.5 —
     the repair path's arithmetic (csrc/sdrfm_q.hip repair_flagged), which is the oracle's (oracle/sdrfm_oracle.c) written out here independently"""
@@ -87,14 +95,17 @@ def host_discriminate(lib, yr, yi, pr, pi):
     return np.array([lib.sdrfm_host_discriminate(float(a), float(b), float(c), float(d)) for a, b, c, d in zip(yr, yi, pr, pi)], dtype=np.float32)
 
 
-def design_q_audio(iq, h, g, ndig=3, D=10, Da=5, guard=None, stats=None, device_atan=True):
+def design_q_audio(iq, h, g, ndig=3, D=10, Da=5, guard=None, stats=None, device_atan=True, k3="diff", recomb="cvt"):
     """One stream from reset, zero history handled like the product does: the first outputs come from the exact spec (the
     generic kernel patches them), so only steady-state arithmetic is judged here.
     guard = (guard_r, guard_a) emulates the kernel's conditioning guard (csrc/sdrfm_q.hip): outputs are held in pairs (2 i, 2 i + 1) by one
     lane; a pair one of whose three y's (y[2 i - 1], y[2 i], y[2 i + 1]) has max(|re|, |im|) < guard_r, or one of whose |d|'s exceeds
     guard_a, gets both d's from the definition's chain recomputed HERE from the raw bytes (chain_y) and the definition's discriminator (round 5;
     round 4 took them from the oracle, which checked the flagging rule but not the repair arithmetic).  device_atan: the unflagged d's use design Q's
-    own 6-coefficient arctangent (q_atan2_dev), not libm's.  stats (a dict) receives the number of repaired pairs."""
+    own 6-coefficient arctangent (q_atan2_dev), not libm's.  stats (a dict) receives the number of repaired pairs.
+    k3: "diff" (round 6, the kernel's default) — d[m] = wrap(theta[m] - theta[m-1]), theta = the device's arctangent of y itself (q_angle / q_wrap) —
+    or "product" (rounds 3 - 5: the arctangent of the conjugate product).  recomb: "cvt" (S0 + 256 S1 in i32, two conversions, two fmas) or "magic"
+    (each digit sum as an exact float, three fmas: the SDRFM_Q_MAGIC experiment)."""
     T, Ta = len(h), len(g)
     b = iq.astype(np.int64)
     xi8 = np.stack([b[0::2] - 128, b[1::2] - 128], axis=1)          # [N, 2]
@@ -110,7 +121,10 @@ def design_q_audio(iq, h, g, ndig=3, D=10, Da=5, guard=None, stats=None, device_
     assert np.abs(S).max() < 2 ** 31
     qf = np.float32(q)
     cst = np.float32(0.5 * np.sum(np.asarray(h, dtype=np.float64)))
-    if ndig == 3:
+    if ndig == 3 and recomb == "magic":
+        assert np.abs(S).max() < 2 ** 22
+        y = fma32(f32(S[0]), qf, fma32(f32(S[1]), np.float32(256.0) * qf, fma32(f32(S[2]), np.float32(65536.0) * qf, cst)))
+    elif ndig == 3:
         s01 = S[0] + 256 * S[1]
         assert np.abs(s01).max() < 2 ** 31
         y = fma32(f32(s01), qf, fma32(f32(S[2]), np.float32(65536.0) * qf, cst))
@@ -132,7 +146,12 @@ def design_q_audio(iq, h, g, ndig=3, D=10, Da=5, guard=None, stats=None, device_
     yr, yi, pr, pi = y[:, 0], y[:, 1], prev[:, 0], prev[:, 1]
     re = fma32(yr, pr, f32(yi * pi))
     im = f32(f32(yi * pr) - f32(yr * pi))
-    d = q_atan2_dev(im, re) if device_atan else np.where((re == 0) & (im == 0), np.float32(0), np.arctan2(im, re).astype(np.float32))
+    if device_atan and k3 == "diff":
+        th = q_atan2_dev(yi, yr)
+        thp = np.concatenate([np.zeros(1, np.float32), th[:-1]])
+        d = q_wrap_dev(f32(th - thp))
+    else:
+        d = q_atan2_dev(im, re) if device_atan else np.where((re == 0) & (im == 0), np.float32(0), np.arctan2(im, re).astype(np.float32))
     if guard is not None:
         gr_, ga_ = np.float32(guard[0]), np.float32(guard[1])
         linf = np.maximum(np.abs(y[:, 0]), np.abs(y[:, 1]))
