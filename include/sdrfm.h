@@ -29,16 +29,23 @@
  * definition's fp32 chain, i.e. within 1e-6 of the definition's AUDIO wherever the phase of y[m] conj(y[m-1]) is well conditioned; where
  * it is not — |y| small (a deep fade: noise-only input gets there, a carrier does not) or d within reach of +-pi (the branch cut) — its
  * conditioning guard recomputes the affected d's with the definition's own chain from the raw bytes, so that they are the bit-identical
- * kernels' d's.  How far "within reach" goes rests on a bound E on |y_fast-q - y_definition| that is STATISTICAL: E = 1.25 sqrt(T) 127.5 sum|h| 2^-24
- * (csrc/qtaps.c; 28 standard deviations of what uniform random bytes produce, 9 of a full-scale carrier's), where the chain's worst case —
- * every one of its T roundings falling the same way — is T 127.5 sum|h| 2^-24, 6.4 times as much at T = 64.  So "fast-q" within the 1e-5
- * tolerance (|a - b| <= 1e-5 max(|b|, 1), for audio taps of about unit absolute sum) is a measured statement, not a proven one: no
- * violation, worst 8.4e-7, in the device soak over every input class — uniform random bytes, constant and counter bytes, carriers, and
- * the classes built to probe the bound (strong out-of-band carriers at one to three guard radii, 2 - 8 LSB carriers, periodic byte
- * patterns: tools/q_classes.py, profiles/r05_fuzz_q.txt).  SDRFM_CFG_BIT_EXACT is the guarantee: the bit-identical kernels only.
+ * kernels' d's.  How far "within reach" goes rests on a bound E on |y_fast-q - y_definition|.  By default it is STATISTICAL:
+ * E = 1.25 sqrt(T) 127.5 sum|h| 2^-24 (csrc/qtaps.c; 28 standard deviations of what uniform random bytes produce, 9 of a full-scale
+ * carrier's).  So "fast-q" within the 1e-5 tolerance (|a - b| <= 1e-5 max(|b|, 1), for audio taps of about unit absolute sum) is by
+ * default a MEASURED statement, not a proven one: no violation, worst 9.8e-7, in the device soaks over every input class — uniform random
+ * bytes, constant and counter bytes, carriers, and the classes built to probe the bound (strong out-of-band carriers at one to three guard
+ * radii, 2 - 8 LSB carriers, periodic byte patterns: tools/q_classes.py, profiles/r06_fuzz_q.txt).  What can be had beyond that, and its price:
+ *   SDRFM_CFG_GUARD_WORST_CASE  the radius from the PROVEN worst case of E (every rounding the same way: 6.9 x at 64 taps).  Proves every
+ *                               unrepaired d within 5e-6 / max|g| + 1.1e-6 of the definition's; the AUDIO bound that follows for arbitrary bytes is
+ *                               sum|g| times that (4.6e-5 for the BASELINE audio taps: all 32 d's of a window at the radius, errors aligned), 1e-5
+ *                               when at most one pair of a window is marginal.  Costs a carrier nothing measurable (profiles/r06_guard_worst_case.txt).
+ *   SDRFM_CFG_BIT_EXACT         the guarantee: the bit-identical kernels only — 0.42 of the HBM roofline against 0.60 / 0.72 (bench.py: bit_exact_kernel).
+ *                               A worst-case radius that PROVED 1e-5 for arbitrary bytes would be 2 sum|g| E_wc / 8e-6 = 180 of 127.5 full scale:
+ *                               every output repaired, i.e. this flag at a higher price.
  * A stream whose windows of calls are mostly repair work (noise only) is moved to the bit-identical kernels for a while, per stream
- * (DESIGN.md 4.Q "routing"); which kernel serves a stream at a given call depends on when the device's statistics are noticed — every
- * choice is within the tolerance, none waits for the device.
+ * (DESIGN.md 4.Q "routing").  Which kernel serves a stream at which call is a function of the bytes and the sequence of calls alone (round 6): a
+ * window of 16 calls takes effect at the first call of the window four windows later, never "when noticed" — two runs of one capture give
+ * the same bits.  Every choice is within the tolerance.
  *
  * There is NO CPU fallback in this library: every entry point that computes runs hand-written HIP kernels
  * on a gfx950 device and fails with SDRFM_NO_DEVICE when none is usable.
@@ -83,12 +90,21 @@ enum {
                                        noise only, which the bit-identical kernels serve faster: those are routed to them per stream;
                                        every other configuration runs the bit-identical kernels anyway */
 #define SDRFM_CFG_NO_ZEROCOPY   2u  /* URB-sized host calls use the staged H2D/D2H path instead of mapped host memory (tests) */
+#define SDRFM_CFG_GUARD_WORST_CASE 8u  /* "fast-q": the conditioning guard's radius from the PROVEN worst case of |y_fast-q - y_definition| — every rounding of
+                                       the definition's chain and of the recombination falling the same way at the largest partial sum, every tap's
+                                       quantisation error against a full-scale byte: (T + 4) 127.5 sum|h| 2^-24 + 64 T q (csrc/qtaps.c) — instead of the
+                                       statistical bound; 6.9 times the radius at 64 taps (|y| < 32 of 127.5 is recomputed by the definition's chain).
+                                       With it every unrepaired discriminator output is PROVABLY within 5e-6 / max|g| + 1.1e-6 of the definition's;
+                                       a carrier above a quarter of full scale never meets the guard and costs the same (profiles/r06_guard_worst_case.txt),
+                                       weaker streams are repaired more often and then routed to the bit-identical kernels.  See the note above. */
 
 /* flags for sdrfm_process_batch */
 #define SDRFM_F_DEVICE_PTRS 1u    /* iq and audio are device pointers on cfg.device; call is enqueued on the
-                                     handle's stream and returns without synchronising or waiting for the device in any way
-                                     (rounds 3 - 4 could wait on an event of an earlier window of calls here; since round 5 the
-                                     per-stream statistics are read back on a side stream and looked at with hipEventQuery:
+                                     handle's stream and returns without synchronising; it does not wait for the device either while the
+                                     caller is less than 48 calls ahead of it ("fast-q" handles: the per-stream statistics of a window of 16
+                                     calls are read back on a side stream and take effect at a fixed call three windows after the window
+                                     closed — a caller further ahead than that waits there for the read-back, which is what makes the kernel
+                                     assignment a function of the bytes and the calls and not of timing;
                                      tests/test_route_gpu.py test_calls_return_without_waiting_for_the_device).  The handle's own stream is
                                      created non-blocking: it does NOT order itself against the null stream or any
                                      other stream, so work that produces iq or touches audio elsewhere must be

@@ -40,6 +40,7 @@ int sdrfm_q_build(const float* h, uint32_t T, uint32_t D, int8_t* A, float* q, f
 
 /* Design Q (csrc/qtaps.c): the conditioning guard's thresholds for channel taps h[0..T) and audio taps g[0..Ta).  0 on success. */
 int sdrfm_q_guard(const float* h, uint32_t T, const float* g, uint32_t Ta, float* guard_r, float* guard_a);
+int sdrfm_q_guard2(const float* h, uint32_t T, const float* g, uint32_t Ta, int worst_case, float* guard_r, float* guard_a);   /* worst_case = 1: SDRFM_CFG_GUARD_WORST_CASE's radius */
 
 /* Design Q's conditioning guard on this handle (csrc/sdrfm_q.hip): a lane is repaired — its two discriminator outputs recomputed with the
  * definition's own fmaf chain — when one of its y's has max(|re|, |im|) < *guard_r or one of its |d|'s exceeds *guard_a; *lanes / *passes =

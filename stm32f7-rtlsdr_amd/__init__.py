@@ -8,14 +8,8 @@ call raises.
 The directory name contains a hyphen (it is fixed by the build contract), so import it with
 ``importlib.import_module("stm32f7-rtlsdr_amd")``.
 """
-import os as _os
-
-# Overlapped calls (SDRFM_F_OVERLAP) need two hardware queues of their own beside the caller's stream; the HIP runtime maps a process's streams onto a pool of 4
-# by default and RCCL's streams take some of them (INTEGRATION.md).  Effective only when this package is imported before anything loads the runtime (torch);
-# a host that imports torch first sets the variable itself — bench.py does.
-if "WORLD_SIZE" in _os.environ or "TORCHELASTIC_RUN_ID" in _os.environ:   # (a rank of a torch.distributed run: RCCL will be in the process)
-    _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
+# (Importing this package does not touch the process environment.  A host that runs RCCL beside overlapped calls wants GPU_MAX_HW_QUEUES=8 set BEFORE the HIP
+# runtime loads — INTEGRATION.md section 3 says why; bench.py and examples/multi_gpu_main.c set it themselves.)
 from .lib import SdrfmError, load_library, library_path, STATUS, ABI_SYMBOLS
 from .demod import FmDemod, FmConfig
 from .wbfm import WbfmDemod, WbfmConfig

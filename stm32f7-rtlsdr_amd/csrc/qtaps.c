@@ -78,21 +78,37 @@ int sdrfm_q_build(const float* h, uint32_t T, uint32_t D, int8_t* A, float* q_ou
 
 /* The conditioning guard's thresholds (kernel: sdrfm_q.hip; derivation: DESIGN.md 4.Q "guard").
  * Design Q's y and the definition's fmaf chain differ by the chain's own rounding — T roundings at partial sums of up to P = 127.5 sum|h| —
- * plus the 24-bit taps: |dy| <= E = 1.25 sqrt(T) P 2^-24 (9.5e-5 for the BASELINE 64 taps: 28 standard deviations of what uniform random
- * bytes produce, 9 of a full-scale carrier's; the chain's worst case T P 2^-24 would need every rounding to fall the same way).  A
- * discriminator output then moves by at most E / |y| + E / |p| and the audio by max|g| times that.  Outputs with a y below
+ * plus the 24-bit taps and the three roundings of the recombination.  Two bounds E on |dy|:
+ *   statistical (the default):  E = 1.25 sqrt(T) P 2^-24 (9.5e-5 for the BASELINE 64 taps: 28 standard deviations of what uniform random bytes
+ *                               produce, 9 of a full-scale carrier's);
+ *   worst case (SDRFM_CFG_GUARD_WORST_CASE, round 6):  E = (T + 4) P 2^-24 + 64 T q — every one of the chain's T roundings at the largest partial
+ *                               sum and falling the same way ((T) P 2^-24 (1 + T 2^-24)), the recombination's conversion and two fused
+ *                               multiply-adds (3 x 1.01 P 2^-24), every tap's quantisation error q / 2 against a byte of magnitude 128, the rounding
+ *                               of the constant 0.5 sum h (< P 2^-24).  A PROVEN bound on |y_fast-q - y_definition| for any bytes; 6.9 times the
+ *                               statistical one at T = 64.
+ * A discriminator output then moves by at most asin(E / |y|) + asin(E / |p|) and the audio by max|g| times that per tap.  Outputs with a y below
  * R = 2 max|g| E / 5e-6 are recomputed by the definition's own chain (ONE ill-conditioned pair may use half of the 1e-5 tolerance; everything
  * else together is measured below 1e-6), and so are d's within 2 * 5e-6 / max|g| of +-pi, where an unrepaired pair could still land on the
- * other side of the branch cut.  Returns 0, or -1 for taps the guard cannot serve (all-zero audio taps are served: nothing to guard). */
-int sdrfm_q_guard(const float* h, uint32_t T, const float* g, uint32_t Ta, float* guard_r, float* guard_a) {
+ * other side of the branch cut.  What the worst-case radius PROVES: every unrepaired d is within 5e-6 / max|g| + 1.1e-6 of the definition's
+ * (1.1e-6: two arctangents, the wrap), hence every audio sample within sum|g| (5e-6 / max|g| + 1.1e-6) of the oracle's — 4.6e-5 for the
+ * BASELINE audio taps, reached only if all 32 d's of a window sat at the radius with aligned errors; within 1e-5 whenever at most one
+ * pair of a window is that close to the radius.  The fully proven 1e-5 is SDRFM_CFG_BIT_EXACT (include/sdrfm.h).
+ * Returns 0, or -1 for taps the guard cannot serve (all-zero audio taps are served: nothing to guard). */
+int sdrfm_q_guard2(const float* h, uint32_t T, const float* g, uint32_t Ta, int worst_case, float* guard_r, float* guard_a) {
   if (!h || !g || !guard_r || !guard_a || T < 1 || Ta < 1) return -1;
-  double habs = 0.0, gmax = 0.0;
-  for (uint32_t k = 0; k < T; ++k) habs += fabs((double)h[k]);
+  double habs = 0.0, hmax = 0.0, gmax = 0.0;
+  for (uint32_t k = 0; k < T; ++k) { habs += fabs((double)h[k]); if (fabs((double)h[k]) > hmax) hmax = fabs((double)h[k]); }
   for (uint32_t k = 0; k < Ta; ++k) if (fabs((double)g[k]) > gmax) gmax = fabs((double)g[k]);
   if (!isfinite(habs) || !isfinite(gmax)) return -1;
   if (gmax == 0.0) { *guard_r = 0.0f; *guard_a = 4.0f; return 0; }
-  const double E = 1.25 * sqrt((double)T) * 127.5 * habs * ldexp(1.0, -24);
+  const double P = 127.5 * habs, u = ldexp(1.0, -24);
+  const double E = worst_case ? ((double)T + 4.0) * P * u + 64.0 * (double)T * (hmax / (double)SDRFM_Q_HMAX)
+                              : 1.25 * sqrt((double)T) * P * u;
   *guard_r = (float)(2.0 * gmax * E / 5e-6);
   *guard_a = (float)(3.14159265358979323846 - 2.0 * 5e-6 / gmax);
   return 0;
+}
+
+int sdrfm_q_guard(const float* h, uint32_t T, const float* g, uint32_t Ta, float* guard_r, float* guard_a) {
+  return sdrfm_q_guard2(h, T, g, Ta, 0, guard_r, guard_a);
 }

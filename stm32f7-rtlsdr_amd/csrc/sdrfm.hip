@@ -929,6 +929,10 @@ const FastVariant kFastVariants[] = {
 // =================================================================================================================
 //  Host side (C-ABI)
 // =================================================================================================================
+#define SDRFM_Q_ADAPT_WINDOW 16u     /* design-Q calls per window of per-stream repair statistics */
+#define SDRFM_Q_ADAPT_SETS 4u        /* counter sets taken in turn: a window's statistics take effect when its set comes round again — at the first design-Q call of the
+                                        window SETS windows later, a FIXED call: the host waits there if the device has not delivered them (a host > (SETS - 1) windows ahead) */
+#define SDRFM_Q_ADAPT_BACKOFF 1024u  /* eligible calls served by the bit-exact kernels after a window of noise-like input */
 struct sdrfm {
   sdrfm_config cfg;
   int device;
@@ -995,18 +999,21 @@ struct sdrfm {
   // the window's last kernels (hipExtLaunchKernelGGL stop events: no marker packets in the compute queues, no host wait anywhere: a
   // finished read-back is noticed by hipEventQuery at a later call).  A stream more than a quarter of whose audio stages needed a repair
   // pass is served by the bit-exact kernels for SDRFM_Q_ADAPT_BACKOFF calls (design-B workgroups over the list of such streams INSIDE design
-  // Q's launch over the others — sdrfm_q.hip: k_mix — or, where design B has no instance, a launch ahead of it), then tried on design Q again.  Which kernel serves a stream at
-  // a given call therefore depends on WHEN the device's report is noticed; every choice is within the tolerance, a stream's audio is
-  // bit-identical to what its kernel gives alone, and SDRFM_CFG_BIT_EXACT pins the kernels.
-  uint32_t* rt_pass_dev[2]; uint32_t* rt_pass_host[2]; uint32_t* rt_pass_host_dev[2];         // repair passes per stream: the set the open window adds into / pinned read-back; two in turn
+  // Q's launch over the others — sdrfm_q.hip: k_mix — or, where design B has no instance, a launch ahead of it), then tried on design Q again.
+  // DETERMINISTIC since round 6: a window's statistics take effect at a FIXED call — the first design-Q call of the window
+  // SDRFM_Q_ADAPT_SETS windows later, when the window's counter set comes round again — whenever the read-back arrived; should it not have arrived by then
+  // (a host more than SETS - 1 windows of calls ahead of its device) that call waits for it.  Which kernel serves a stream at which call is therefore a
+  // function of the bytes and the call sequence alone: two runs of one capture give the same bits (tests/test_route_gpu.py).  Every choice is within the
+  // tolerance, a stream's audio is bit-identical to what its kernel gives alone, and SDRFM_CFG_BIT_EXACT pins the kernels.
+  uint32_t* rt_pass_dev[SDRFM_Q_ADAPT_SETS]; uint32_t* rt_pass_host[SDRFM_Q_ADAPT_SETS]; uint32_t* rt_pass_host_dev[SDRFM_Q_ADAPT_SETS];   // repair passes per stream: the set the open window adds into / pinned read-back
   hipStream_t rt_mon;                                           // side stream of the read-backs
-  hipEvent_t rt_rb_done[2]; bool rt_rb_pending[2]; uint64_t rt_rb_stages[2];   // read-back of set i: its event; audio stages per stream its window covered
-  hipEvent_t rt_win_evt[2][3];                                  // completion events of a window's last kernels: [set][internal stream 0, 1, the handle's stream]
-  bool rt_win_need[3], rt_win_used[3], rt_win_stats;            // open window: stream holds kernels no event covers / holds kernels at all; the window counts
+  hipEvent_t rt_rb_done[SDRFM_Q_ADAPT_SETS]; bool rt_rb_pending[SDRFM_Q_ADAPT_SETS]; uint64_t rt_rb_stages[SDRFM_Q_ADAPT_SETS];   // read-back of set i: its event; audio stages per stream its window covered
+  hipEvent_t rt_win_evt[SDRFM_Q_ADAPT_SETS][3];                 // completion events of a window's last kernels: [set][internal stream 0, 1, the handle's stream]
+  bool rt_win_need[3], rt_win_used[3];                          // open window: stream holds kernels no event covers / holds kernels at all
   uint32_t rt_win_calls, rt_set; uint64_t rt_win_stages;
   uint8_t* rt_noisy; uint64_t* rt_retry_at; uint32_t rt_n_noisy; uint64_t rt_calls, rt_next_retry;   // host: per stream, served by the bit-exact kernels until call rt_retry_at
   uint32_t* rt_list_dev[2]; uint32_t* rt_list_host[2]; int rt_list_cur; bool rt_dirty;   // stream lists: the clean streams first, then the noisy ones
-  hipEvent_t rt_applied; bool rt_applied_pending;               // a new list version is in place (recorded on the handle's stream)
+  hipEvent_t rt_applied[2]; bool rt_applied_pending[2];         // list version v is in place (recorded on the handle's stream behind its copy: its host buffer may be rewritten after it)
   hipEvent_t rt_bx_evt[2]; uint32_t rt_bx_slot; hipStream_t rt_bx_last;   // the bit-exact sub-launches: completion events (stop events), and the stream the latest went to
                                                                 // (each takes the state the one before left: on another stream it waits for that one's event)
   bool rt_off;                                                  // (development: design Q whatever the streams hold)
@@ -1025,8 +1032,6 @@ struct sdrfm {
 
 static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nbytes, float* d_audio, size_t audio_stride,
                    uint32_t* n_audio, uint32_t call_flags = 0);
-#define SDRFM_Q_ADAPT_WINDOW 16u     /* design-Q calls per window of per-stream repair statistics (8 in rounds 3 - 4: a window that closes at the third call of a burst from rest meets a host that is barely ahead of the device) */
-#define SDRFM_Q_ADAPT_BACKOFF 1024u  /* eligible calls served by the bit-exact kernels after a window of noise-like input */
 static int join_overlap(sdrfm* h);
 static int route_create(sdrfm* h);
 static int route_reset(sdrfm* h);
@@ -1047,18 +1052,20 @@ static int route_create(sdrfm* h) {
   h->rt_noisy = static_cast<uint8_t*>(calloc(ns, 1));
   h->rt_retry_at = static_cast<uint64_t*>(calloc(ns, sizeof(uint64_t)));
   if (!h->rt_noisy || !h->rt_retry_at) return SDRFM_ENOMEM;
-  for (int i = 0; i < 2; ++i) {
+  for (uint32_t i = 0; i < SDRFM_Q_ADAPT_SETS; ++i) {
     HIP_TRY(hipMalloc(&h->rt_pass_dev[i], ns * sizeof(uint32_t)), SDRFM_ENOMEM);
     HIP_TRY(hipMemset(h->rt_pass_dev[i], 0, ns * sizeof(uint32_t)), SDRFM_FAIL);
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->rt_pass_host[i]), ns * sizeof(uint32_t), hipHostMallocMapped), SDRFM_ENOMEM);
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->rt_pass_host_dev[i]), h->rt_pass_host[i], 0), SDRFM_FAIL);
-    HIP_TRY(hipMalloc(&h->rt_list_dev[i], ns * sizeof(uint32_t)), SDRFM_ENOMEM);
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->rt_list_host[i]), ns * sizeof(uint32_t), hipHostMallocDefault), SDRFM_ENOMEM);
     HIP_TRY(hipEventCreateWithFlags(&h->rt_rb_done[i], hipEventDisableTiming), SDRFM_ENOMEM);
     for (int k = 0; k < 3; ++k) HIP_TRY(hipEventCreateWithFlags(&h->rt_win_evt[i][k], hipEventDisableTiming), SDRFM_ENOMEM);
   }
-  HIP_TRY(hipEventCreateWithFlags(&h->rt_applied, hipEventDisableTiming), SDRFM_ENOMEM);
-  for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreateWithFlags(&h->rt_bx_evt[i], hipEventDisableTiming), SDRFM_ENOMEM);
+  for (int i = 0; i < 2; ++i) {
+    HIP_TRY(hipMalloc(&h->rt_list_dev[i], ns * sizeof(uint32_t)), SDRFM_ENOMEM);
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->rt_list_host[i]), ns * sizeof(uint32_t), hipHostMallocDefault), SDRFM_ENOMEM);
+    HIP_TRY(hipEventCreateWithFlags(&h->rt_applied[i], hipEventDisableTiming), SDRFM_ENOMEM);
+    HIP_TRY(hipEventCreateWithFlags(&h->rt_bx_evt[i], hipEventDisableTiming), SDRFM_ENOMEM);
+  }
   // (No third stream for the noisy streams' launches: tried two ways, lost both times — profiles/r05_mixed_batches.txt.  An ordinary stream shares the handle's
   // stream's hardware queue (streams of one priority share a small pool): its kernels sat between that stream's event markers and every overlapped call waited
   // for the previous call's launch; a CU-mask stream (a queue of its own) ran the overlapped calls at 53 us against 36 - 41 us with the launch ahead of design Q's
@@ -1076,39 +1083,44 @@ static int route_reset(sdrfm* h) {
   if (h->rt_mon) HIP_TRY(hipStreamSynchronize(h->rt_mon), SDRFM_FAIL);
   for (int k = 0; k < 2; ++k)
     if (h->ovl_stream[k]) HIP_TRY(hipStreamSynchronize(h->ovl_stream[k]), SDRFM_FAIL);
-  for (int i = 0; i < 2; ++i) {
+  for (uint32_t i = 0; i < SDRFM_Q_ADAPT_SETS; ++i) {
     HIP_TRY(hipMemset(h->rt_pass_dev[i], 0, ns * sizeof(uint32_t)), SDRFM_FAIL);
     h->rt_rb_pending[i] = false;
   }
   memset(h->rt_noisy, 0, ns);
-  h->rt_n_noisy = 0; h->rt_next_retry = ~0ull; h->rt_dirty = false; h->rt_applied_pending = false; h->rt_bx_last = nullptr; h->rt_calls = 0;
-  h->rt_win_calls = 0; h->rt_win_stages = 0; h->rt_win_stats = false;
+  h->rt_n_noisy = 0; h->rt_next_retry = ~0ull; h->rt_dirty = false; h->rt_applied_pending[0] = h->rt_applied_pending[1] = false; h->rt_bx_last = nullptr; h->rt_calls = 0;
+  h->rt_win_calls = 0; h->rt_win_stages = 0; h->rt_set = 0;
   for (int k = 0; k < 3; ++k) { h->rt_win_need[k] = false; h->rt_win_used[k] = false; }
   return SDRFM_OK;
 }
 
-// Read-backs that have finished: a stream more than a quarter of whose audio stages needed a repair pass leaves design Q for a while.
-static void route_poll(sdrfm* h) {
-  for (int i = 0; i < 2; ++i) {
-    if (!h->rt_rb_pending[i] || hipEventQuery(h->rt_rb_done[i]) != hipSuccess) continue;
-    h->rt_rb_pending[i] = false;
-    const uint32_t* pass = h->rt_pass_host[i];
-    for (uint32_t s = 0; s < h->cfg.n_streams; ++s)
-      if (!h->rt_noisy[s] && (uint64_t)pass[s] * 4u > h->rt_rb_stages[i]) {
-        h->rt_noisy[s] = 1;
-        h->rt_retry_at[s] = h->rt_calls + SDRFM_Q_ADAPT_BACKOFF;
-        if (h->rt_retry_at[s] < h->rt_next_retry) h->rt_next_retry = h->rt_retry_at[s];
-        h->rt_dirty = true;
-      }
-  }
-  (void)hipGetLastError();                                       // (hipErrorNotReady of a pending query is not an error)
-  if (h->rt_calls >= h->rt_next_retry) {                         // streams whose time on the bit-exact kernels is over: design Q is tried again
-    h->rt_next_retry = ~0ull;
-    for (uint32_t s = 0; s < h->cfg.n_streams; ++s) {
-      if (!h->rt_noisy[s]) continue;
-      if (h->rt_retry_at[s] <= h->rt_calls) { h->rt_noisy[s] = 0; h->rt_dirty = true; }
-      else if (h->rt_retry_at[s] < h->rt_next_retry) h->rt_next_retry = h->rt_retry_at[s];
+// The read-back of counter set i is taken in — at a FIXED call: enqueue() calls this at the first design-Q call of the window that will count into set i
+// again, SDRFM_Q_ADAPT_SETS windows after the one the read-back covers.  A stream more than a quarter of whose audio stages needed a repair pass leaves
+// design Q for a while.  The read-back was enqueued (SETS - 1) windows of calls ago; a host that far ahead of its device waits here (the one place a
+// SDRFM_F_DEVICE_PTRS call can wait: include/sdrfm.h) — the price of a kernel assignment that is a function of the bytes and the call sequence alone.
+static int route_take(sdrfm* h, uint32_t i) {
+  if (!h->rt_rb_pending[i]) return SDRFM_OK;
+  HIP_TRY(hipEventSynchronize(h->rt_rb_done[i]), SDRFM_FAIL);
+  h->rt_rb_pending[i] = false;
+  const uint32_t* pass = h->rt_pass_host[i];
+  for (uint32_t s = 0; s < h->cfg.n_streams; ++s)
+    if (!h->rt_noisy[s] && (uint64_t)pass[s] * 4u > h->rt_rb_stages[i]) {
+      h->rt_noisy[s] = 1;
+      h->rt_retry_at[s] = h->rt_calls + SDRFM_Q_ADAPT_BACKOFF;
+      if (h->rt_retry_at[s] < h->rt_next_retry) h->rt_next_retry = h->rt_retry_at[s];
+      h->rt_dirty = true;
     }
+  return SDRFM_OK;
+}
+
+// streams whose time on the bit-exact kernels is over (counted in calls): design Q is tried again
+static void route_retry(sdrfm* h) {
+  if (h->rt_calls < h->rt_next_retry) return;
+  h->rt_next_retry = ~0ull;
+  for (uint32_t s = 0; s < h->cfg.n_streams; ++s) {
+    if (!h->rt_noisy[s]) continue;
+    if (h->rt_retry_at[s] <= h->rt_calls) { h->rt_noisy[s] = 0; h->rt_dirty = true; }
+    else if (h->rt_retry_at[s] < h->rt_next_retry) h->rt_next_retry = h->rt_retry_at[s];
   }
 }
 
@@ -1116,6 +1128,42 @@ static uint32_t max_audio_for(const sdrfm_config& c, uint32_t nbytes) {
   const uint64_t n = nbytes / 2;
   const uint64_t m = (n + c.fir_decim - 1) / c.fir_decim + 1;
   return (uint32_t)((m + c.audio_decim - 1) / c.audio_decim + 1);
+}
+
+// Everything design Q and its per-stream routing own (free_handle; and sdrfm_create when any of it could not be had: the handle then runs the bit-exact
+// kernels, with nothing half-allocated left behind — ADVICE r05).  Every member is null or valid; all are null afterwards.
+static void q_free(sdrfm* h) {
+  if (h->d_qA) (void)hipFree(h->d_qA);
+  if (h->d_hpad) (void)hipFree(h->d_hpad);
+  h->d_qA = nullptr; h->d_hpad = nullptr;
+  for (uint32_t i = 0; i < SDRFM_Q_ADAPT_SETS; ++i) {
+    if (h->rt_pass_dev[i]) (void)hipFree(h->rt_pass_dev[i]);
+    if (h->rt_pass_host[i]) (void)hipHostFree(h->rt_pass_host[i]);
+    if (h->rt_rb_done[i]) (void)hipEventDestroy(h->rt_rb_done[i]);
+    h->rt_pass_dev[i] = nullptr; h->rt_pass_host[i] = nullptr; h->rt_pass_host_dev[i] = nullptr; h->rt_rb_done[i] = nullptr;
+    for (int k = 0; k < 3; ++k) {
+      if (h->rt_win_evt[i][k]) (void)hipEventDestroy(h->rt_win_evt[i][k]);
+      h->rt_win_evt[i][k] = nullptr;
+    }
+  }
+  for (int i = 0; i < 2; ++i) {
+    if (h->rt_list_dev[i]) (void)hipFree(h->rt_list_dev[i]);
+    if (h->rt_list_host[i]) (void)hipHostFree(h->rt_list_host[i]);
+    if (h->rt_applied[i]) (void)hipEventDestroy(h->rt_applied[i]);
+    if (h->rt_bx_evt[i]) (void)hipEventDestroy(h->rt_bx_evt[i]);
+    h->rt_list_dev[i] = nullptr; h->rt_list_host[i] = nullptr; h->rt_applied[i] = nullptr; h->rt_bx_evt[i] = nullptr;
+  }
+  if (h->rt_mon) (void)hipStreamDestroy(h->rt_mon);
+  h->rt_mon = nullptr;
+  free(h->rt_noisy);
+  free(h->rt_retry_at);
+  h->rt_noisy = nullptr; h->rt_retry_at = nullptr;
+  if (h->d_qstat) (void)hipFree(h->d_qstat);
+  h->d_qstat = nullptr;
+  for (int i = 0; i < 2; ++i) {
+    if (h->d_hist_q[i]) (void)hipFree(h->d_hist_q[i]);
+    h->d_hist_q[i] = nullptr;
+  }
 }
 
 static void free_handle(sdrfm* h) {
@@ -1137,26 +1185,7 @@ static void free_handle(sdrfm* h) {
   if (h->zc_audio) (void)hipHostFree(h->zc_audio);
   if (h->d_audio) (void)hipFree(h->d_audio);
   if (h->d_dbg) (void)hipFree(h->d_dbg);
-  if (h->d_qA) (void)hipFree(h->d_qA);
-  if (h->d_hpad) (void)hipFree(h->d_hpad);
-  for (int i = 0; i < 2; ++i) {
-    if (h->rt_pass_dev[i]) (void)hipFree(h->rt_pass_dev[i]);
-    if (h->rt_pass_host[i]) (void)hipHostFree(h->rt_pass_host[i]);
-    if (h->rt_list_dev[i]) (void)hipFree(h->rt_list_dev[i]);
-    if (h->rt_list_host[i]) (void)hipHostFree(h->rt_list_host[i]);
-    if (h->rt_rb_done[i]) (void)hipEventDestroy(h->rt_rb_done[i]);
-    for (int k = 0; k < 3; ++k)
-      if (h->rt_win_evt[i][k]) (void)hipEventDestroy(h->rt_win_evt[i][k]);
-  }
-  if (h->rt_applied) (void)hipEventDestroy(h->rt_applied);
-  for (int i = 0; i < 2; ++i)
-    if (h->rt_bx_evt[i]) (void)hipEventDestroy(h->rt_bx_evt[i]);
-  if (h->rt_mon) (void)hipStreamDestroy(h->rt_mon);
-  free(h->rt_noisy);
-  free(h->rt_retry_at);
-  if (h->d_qstat) (void)hipFree(h->d_qstat);
-  for (int i = 0; i < 2; ++i)
-    if (h->d_hist_q[i]) (void)hipFree(h->d_hist_q[i]);
+  q_free(h);
   for (int k = 0; k < 2; ++k) {
     if (h->ovl_stream[k]) (void)hipStreamDestroy(h->ovl_stream[k]);
     if (h->ovl_done[k]) (void)hipEventDestroy(h->ovl_done[k]);
@@ -1216,7 +1245,7 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
   if (!out) return SDRFM_EINVAL;
   *out = nullptr;
   if (!cfg || cfg->struct_size != sizeof(sdrfm_config)) return SDRFM_EINVAL;
-  if (!cfg->n_streams || !cfg->fir_coeffs || !cfg->audio_coeffs || (cfg->flags & ~(SDRFM_CFG_FORCE_GENERIC | SDRFM_CFG_NO_ZEROCOPY | SDRFM_CFG_BIT_EXACT))) return SDRFM_EINVAL;
+  if (!cfg->n_streams || !cfg->fir_coeffs || !cfg->audio_coeffs || (cfg->flags & ~(SDRFM_CFG_FORCE_GENERIC | SDRFM_CFG_NO_ZEROCOPY | SDRFM_CFG_BIT_EXACT | SDRFM_CFG_GUARD_WORST_CASE))) return SDRFM_EINVAL;
   if (!cfg->fir_taps || cfg->fir_taps > SDRFM_MAX_TAPS || !cfg->audio_taps || cfg->audio_taps > SDRFM_MAX_TAPS)
     return SDRFM_EINVAL;
   if (!cfg->fir_decim || cfg->fir_decim > SDRFM_MAX_DECIM || !cfg->audio_decim || cfg->audio_decim > SDRFM_MAX_DECIM)
@@ -1326,8 +1355,10 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
     // The conditioning guard's thresholds (qtaps.c: sdrfm_q_guard).  A guard that would send a carrier at an eighth of full scale to the
     // repair path makes design Q pointless for these taps: the bit-exact kernels serve them.
     float q_R = 0.0f, q_A = 4.0f;
-    const bool q_guard_ok = sdrfm_q_guard(hc, cfg->fir_taps, gc, cfg->audio_taps, &q_R, &q_A) == 0 &&
-                            (double)q_R <= 0.125 * 127.5 * std::fabs(q_sum) && q_A > 3.0f;
+    // (SDRFM_CFG_GUARD_WORST_CASE: the radius from the proven worst-case bound — 6.9 x at 64 taps; a carrier at a third of full scale must still clear it)
+    const bool q_wc = (cfg->flags & SDRFM_CFG_GUARD_WORST_CASE) != 0;
+    const bool q_guard_ok = sdrfm_q_guard2(hc, cfg->fir_taps, gc, cfg->audio_taps, q_wc ? 1 : 0, &q_R, &q_A) == 0 &&
+                            (double)q_R <= (q_wc ? 0.33 : 0.125) * 127.5 * std::fabs(q_sum) && q_A > 3.0f;
     // instances: (D, Da) = (10, 5) — the 2.4 MS/s front end of BASELINE —, (8, 8) and (16, 5): the 2.048 and 3.2 MS/s rates
     // RTLSDR_set_sample_rate accepts (usbh_rtlsdr.c:676-678); 32 audio taps each
     const size_t q_tab_bytes = (size_t)SDRFM_Q_SPARSE_CHUNKS(cfg->fir_decim) * SDRFM_Q_DIGITS * 64 * 16;
@@ -1337,7 +1368,8 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
       float qs = 0.f, qc = 0.f, hpad[SDRFM_Q_TP];
       uint32_t c0 = 0;
       for (uint32_t k = 0; k < SDRFM_Q_TP; ++k) hpad[k] = k < cfg->fir_taps ? hc[k] : 0.0f;
-      if (tab && sdrfm_q_build(hc, cfg->fir_taps, cfg->fir_decim, tab, &qs, &qc, &c0) == 0 &&
+      const bool q_built = tab && sdrfm_q_build(hc, cfg->fir_taps, cfg->fir_decim, tab, &qs, &qc, &c0) == 0;   // (false: taps the tables cannot hold)
+      if (q_built &&
           hipMalloc(&h->d_qA, q_tab_bytes) == hipSuccess &&
           hipMemcpy(h->d_qA, tab, q_tab_bytes, hipMemcpyHostToDevice) == hipSuccess &&
           hipMalloc(&h->d_hpad, sizeof(hpad)) == hipSuccess && hipMemcpy(h->d_hpad, hpad, sizeof(hpad), hipMemcpyHostToDevice) == hipSuccess &&
@@ -1359,7 +1391,12 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
         h->n_cu = (uint32_t)prop.multiProcessorCount;
         snprintf(h->fast_q_name, sizeof(h->fast_q_name), "fast-q T%u D%u Ta%u Da%u %s", cfg->fir_taps, cfg->fir_decim, cfg->audio_taps,
                  cfg->audio_decim, sdrfm_q_kernel_symbol(h->q_c0, h->q_nslot, cfg->fir_decim, cfg->audio_decim));
-      } else if (h->d_qA) { (void)hipFree(h->d_qA); h->d_qA = nullptr; }
+      } else {
+        // (the handle serves every call with the bit-exact kernels; said once, so that the slower path is not silent)
+        if (q_built) fprintf(stderr, "[sdrfm] the matrix-pipe kernel's tables or routing state could not be allocated: this handle runs the bit-exact kernels only\n");
+        (void)hipGetLastError();
+        q_free(h);
+      }
       free(tab);
     }
     for (int pass = 0; pass < 3 && !h->fast; ++pass)
@@ -1498,6 +1535,10 @@ static int route_apply(sdrfm* h) {
   const uint32_t ns = c.n_streams;
   { const int jrc = join_overlap(h); if (jrc != SDRFM_OK) return jrc; }
   const int v = h->rt_list_cur ^ 1;
+  if (h->rt_applied_pending[v]) {                                // (this version's host buffer feeds a copy enqueued two assignments ago: over, but for a host that far ahead)
+    HIP_TRY(hipEventSynchronize(h->rt_applied[v]), SDRFM_FAIL);
+    h->rt_applied_pending[v] = false;
+  }
   uint32_t* L = h->rt_list_host[v];
   uint32_t nc = 0, nn = 0;
   for (uint32_t s = 0; s < ns; ++s) if (!h->rt_noisy[s]) L[nc++] = s;
@@ -1510,10 +1551,10 @@ static int route_apply(sdrfm* h) {
                              2 * (size_t)(c.fir_taps - 1), ns, hipMemcpyDeviceToDevice, h->stream), SDRFM_FAIL);
   h->yprev_exact = true; h->hist_q_valid = true;
   HIP_TRY(hipMemcpyAsync(h->rt_list_dev[v], L, (size_t)ns * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream), SDRFM_FAIL);
-  HIP_TRY(hipEventRecord(h->rt_applied, h->stream), SDRFM_FAIL);
-  h->rt_applied_pending = true;
+  HIP_TRY(hipEventRecord(h->rt_applied[v], h->stream), SDRFM_FAIL);
+  h->rt_applied_pending[v] = true;
   for (int k = 0; k < 2; ++k)
-    if (h->ovl_stream[k]) HIP_TRY(hipStreamWaitEvent(h->ovl_stream[k], h->rt_applied, 0), SDRFM_FAIL);
+    if (h->ovl_stream[k]) HIP_TRY(hipStreamWaitEvent(h->ovl_stream[k], h->rt_applied[v], 0), SDRFM_FAIL);
   h->rt_list_cur = v; h->rt_n_noisy = nn; h->rt_dirty = false;
   return SDRFM_OK;
 }
@@ -1628,12 +1669,14 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
   // ---- which streams design Q serves at this call (the handle's comment: per-stream routing) -----------------------------------------------
   const uint32_t ns_all = c.n_streams;
   if (q_fit && h->rt_noisy && !h->rt_off) {
-    route_poll(h);
-    if (h->rt_dirty && !(h->rt_applied_pending && hipEventQuery(h->rt_applied) != hipSuccess)) {
+    // the first design-Q call of a window: the statistics of the window that last counted into this window's set take effect HERE, at a call the call
+    // sequence fixes (route_take waits for a read-back that has not arrived: a host more than SETS - 1 windows ahead of its device)
+    if (h->rt_win_calls == 0) { const int trc = route_take(h, h->rt_set); if (trc != SDRFM_OK) return trc; }
+    route_retry(h);
+    if (h->rt_dirty) {
       const int arc = route_apply(h);
       if (arc != SDRFM_OK) return arc;
     }
-    (void)hipGetLastError();
   }
   const uint32_t n_noisy = (q_fit && h->rt_noisy) ? h->rt_n_noisy : 0u, n_clean = ns_all - n_noisy;
   const bool q_ok = q_fit && n_clean > 0 && 2 * n_noisy < ns_all; // design Q serves n_clean streams (all of them when no stream is noisy); with half of the streams
@@ -1834,14 +1877,11 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
     // whether its kernel's completion carries one of the window's events (the window's last two calls: both internal streams are covered)
     hipEvent_t done = nullptr;
     q.stream_pass = nullptr;
-    if (h->rt_noisy && !h->rt_off) {
-      if (h->rt_win_calls == 0) h->rt_win_stats = !h->rt_rb_pending[h->rt_set];
-      if (h->rt_win_stats) {
-        q.stream_pass = h->rt_pass_dev[h->rt_set];
-        h->rt_win_used[k] = true;
-        if (h->rt_win_calls + 2 >= SDRFM_Q_ADAPT_WINDOW) { done = h->rt_win_evt[h->rt_set][k]; h->rt_win_need[k] = false; }
-        else h->rt_win_need[k] = true;
-      }
+    if (h->rt_noisy && !h->rt_off) {                              // (every window counts: its set was taken in at the window's first call)
+      q.stream_pass = h->rt_pass_dev[h->rt_set];
+      h->rt_win_used[k] = true;
+      if (h->rt_win_calls + 2 >= SDRFM_Q_ADAPT_WINDOW) { done = h->rt_win_evt[h->rt_set][k]; h->rt_win_need[k] = false; }
+      else h->rt_win_need[k] = true;
     }
     // For a caller that joins after every call (sdrfm_flush_previous: the consumer loop of INTEGRATION.md) an overlapped call's kernel carries its internal
     // stream's completion event itself (a stop event: the dispatch's own completion signal), so that the join orders the handle's stream behind it WITHOUT a marker
@@ -1856,7 +1896,7 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
     if (ovl) { h->ovl_pending[k] = true; h->ovl_bound[k] = carry; }
     h->prev_ovl_audio = ovl ? d_audio : nullptr; h->prev_ovl_audio_stride = audio_stride; h->prev_ovl_audio_n = A;
     h->yprev_exact = false; h->hist_q_valid = true;
-    if (h->rt_noisy && !h->rt_off && h->rt_win_stats) {
+    if (h->rt_noisy && !h->rt_off) {
       h->rt_win_stages += (uint64_t)runs * ((q_steps / runs + c.audio_decim - 1) / c.audio_decim);   // audio stages of ONE stream's waves in this call
       if (++h->rt_win_calls >= SDRFM_Q_ADAPT_WINDOW) {
         // the window closes: read its statistics back behind its last kernels, on the side stream (nothing here waits, no packet enters a compute queue
@@ -1875,7 +1915,7 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
         hipLaunchKernelGGL(k_route_collect, dim3((ns_all + 255) / 256), dim3(256), 0, h->rt_mon, h->rt_pass_dev[i], h->rt_pass_host_dev[i], ns_all);
         HIP_TRY(hipEventRecord(h->rt_rb_done[i], h->rt_mon), SDRFM_FAIL);
         h->rt_rb_pending[i] = true; h->rt_rb_stages[i] = h->rt_win_stages;
-        h->rt_set ^= 1u; h->rt_win_calls = 0; h->rt_win_stages = 0;
+        h->rt_set = (h->rt_set + 1u) % SDRFM_Q_ADAPT_SETS; h->rt_win_calls = 0; h->rt_win_stages = 0;
       }
     }
     snprintf(q_name, sizeof(q_name), "%s%s", h->fast_q_name, ovl ? " overlapped" : "");
@@ -2150,15 +2190,10 @@ int sdrfm_debug_route(sdrfm_t* h, const uint8_t* mask, uint32_t* n_noisy, uint8_
       h->rt_retry_at[s] = ~0ull;
     }
     if (h->rt_dirty) {
-      if (h->rt_applied_pending) HIP_TRY(hipEventSynchronize(h->rt_applied), SDRFM_FAIL);   // (a test hook may wait)
       const int arc = route_apply(h);
       if (arc != SDRFM_OK) return arc;
     }
-  } else {
-    route_poll(h);
-    if (h->rt_dirty && !(h->rt_applied_pending && hipEventQuery(h->rt_applied) != hipSuccess)) { const int arc = route_apply(h); if (arc != SDRFM_OK) return arc; }
-    (void)hipGetLastError();
-  }
+  }                                                              // (no mask: the assignment as the last call left it — statistics are taken in by calls only, at fixed ones)
   if (n_noisy) *n_noisy = h->rt_n_noisy;
   if (noisy_out) memcpy(noisy_out, h->rt_noisy, ns);
   return SDRFM_OK;

@@ -7,8 +7,10 @@
  * chain of the oracle (designs S / B / generic are): K2 is evaluated exactly in integers from taps rounded to 24-bit fixed
  * point, which lands within 1e-4 (absolute) of the chain's y: within 1e-6 of the oracle's audio wherever the phase of
  * y[m] conj(y[m-1]) is well conditioned, and where it is not (a deep fade; a d next to +-pi) the CONDITIONING GUARD lists the
- * output pair and the repair path recomputes it with the definition's own chain from the raw bytes (repair_flagged below) —
- * the 1e-5 tolerance holds for any input bytes (tests/test_q_guard_gpu.py, tools/fuzz_q.py at the plain criterion).
+ * output pair and the repair path recomputes it with the definition's own chain from the raw bytes (repair_flagged below).
+ * With the default (statistical) radius the 1e-5 tolerance is a MEASURED statement (tests/test_q_guard_gpu.py, tools/fuzz_q.py at the plain
+ * criterion: no violation); SDRFM_CFG_GUARD_WORST_CASE derives the radius from the proven worst case of |dy|; the guarantee is
+ * SDRFM_CFG_BIT_EXACT (include/sdrfm.h has the three statements side by side).
  * Instances: (D, Da) = (10, 5) — 2.4 MS/s, BASELINE —, (8, 8) — 2.048 MS/s — and (16, 5) — 3.2 MS/s; the step sizes below
  * are the (10, 5) ones (QGeo has the others: steps of 2 / 4 whole KiB chunks, a swizzled ring).
  *
@@ -58,7 +60,7 @@ namespace {
 
 constexpr int QTA = (int)SDRFM_Q_TA;            // audio taps (every instance)
 constexpr int DB0 = 128;                        // d buffer: word DB0 + sigma = first d of the current audio stage
-constexpr int ABS = 4;                          // audio stages (128 outputs each) parked in LDS before they are stored
+constexpr int ABS = 4;                          // audio stages (128 outputs each) parked in LDS before they are stored (2, which lets 16 waves fit a CU: no faster, r06_q_experiments.txt item 5)
 constexpr int ABW = 128 * ABS;                  // words, after the d buffer
 constexpr int FLW = 64 + 2;                     // words, after the parked audio: up to 128 two-byte entries of lanes waiting for the repair path, two counters
 #ifndef SDRFM_Q_GTAB
@@ -97,9 +99,6 @@ struct QGeo {
 #ifndef SDRFM_Q_MICRO
 #define SDRFM_Q_MICRO 1     // 1 (round 6): the carried angle enters lane 0 through v_writelane (one instruction instead of a move and a select); the d write's address
 #endif                      // is one shift-add on a pointer kept in a VGPR (the compiler re-added the buffer's offset every step)
-#ifndef SDRFM_Q_MAGIC
-#define SDRFM_Q_MAGIC 0     // experiment (round 6): the digits' sums leave the matrix pipe as floats — accumulators start at the bit pattern of 1.5 * 2^23, so that
-#endif                      // as_float(acc) - 1.5 * 2^23 = S exactly (|S| <= 2^20): a full-rate subtraction instead of v_cvt_f32_i32 and the shift-add; 2: the factors in VGPRs
 #ifndef SDRFM_Q_AUX
 #define SDRFM_Q_AUX 2   // cache policy of the ring's fetches: 2 = nt (streamed once; measured 0.4-1 us per launch better than the default policy)
 #endif
@@ -154,8 +153,8 @@ __device__ __forceinline__ float q_angle(float yr, float yi, float& mx_out) {
   float a = __builtin_fmaf(v, s2 * q, v);
   if (ay > ax) a = 0x1.921fb6p+0f - a;
   if (yr < 0.0f) a = 0x1.921fb6p+1f - a;
-  return __builtin_copysignf(a, yi);
-}
+  return __builtin_copysignf(a, yi);                            // (the two reflections as sign transfers — v_bfi around pi / 4 and pi / 2, no compare + select — measured
+}                                                               // 0.8 % slower and cost two more roundings: profiles/r06_q_experiments.txt item 4)
 // x in (-2 pi, 2 pi) -> x - 2 pi rint(x / 2 pi): three full-rate instructions (the rounding through the 1.5 * 2^23 constant; v_rndne_f32 is a quarter-rate one)
 __device__ __forceinline__ float q_wrap(float x) {
   float t = __builtin_fmaf(x, 0x1.45f306p-3f, 0x1.8p+23f);
@@ -604,30 +603,8 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
 #ifdef SDRFM_Q_SCALE_VGPR   // experiment (round 5): the recombination's factors in VGPRs (an FMA with an SGPR operand issues at half rate) — measured 0.2 us
   float q0v = p.q0, q2v = p.q2, cstv = p.cst;                  // per call SLOWER than leaving them in SGPRs (the kernel sits at its 128 VGPRs): profiles/r05_q_experiments.txt
   asm volatile("" : "+v"(q0v), "+v"(q2v), "+v"(cstv));
-#elif SDRFM_Q_MAGIC == 2
-  float q0v = p.q0, q2v = p.q2;
-  const float cstv = p.cst;
-  asm volatile("" : "+v"(q0v), "+v"(q2v));
 #else
   const float q0v = p.q0, q2v = p.q2, cstv = p.cst;
-#endif
-#ifdef SDRFM_Q_ZMFMA
-  qi4_t qz4 = {0, 0, 0, 0};
-  asm volatile("" : "+v"(qz4));
-#endif
-  [[maybe_unused]] constexpr int QMB = 0x4B400000;               // the bit pattern of 1.5 * 2^23: + S (|S| < 2^22) is the float 1.5 * 2^23 + S
-#if defined(SDRFM_Q_ZMFMA) && SDRFM_Q_MAGIC
-  qi4_t qmb4 = {QMB, QMB, QMB, QMB};
-  asm volatile("" : "+v"(qmb4));
-#else
-  [[maybe_unused]] const qi4_t qmb4 = {0, 0, 0, 0};
-#endif
-#if SDRFM_Q_MAGIC == 2
-  float q1v = 256.0f * p.q0, qmf = 0x1.8p+23f;
-  asm volatile("" : "+v"(q1v), "+v"(qmf));
-#elif SDRFM_Q_MAGIC
-  const float q1v = 256.0f * p.q0;
-  constexpr float qmf = 0x1.8p+23f;
 #endif
 #if SDRFM_Q_MICRO && SDRFM_Q_K3
   int doff = (PRE + RINGB) + 4 * (DB0 + sigma + dlane);          // LDS byte offset of the lane's two d's of the stage's first step (opaque: an offset, not a
@@ -654,14 +631,7 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
     // ---- K2 on the matrix pipe ------------------------------------------------------------------------------------------------
     qi4_t acc[SDRFM_Q_DIGITS];
 #pragma unroll
-    for (int t = 0; t < SDRFM_Q_DIGITS; ++t) {
-#ifdef SDRFM_Q_ZMFMA   // experiment (round 6): the accumulators zeroed by the matrix pipe (one dense issue with a zero A operand: 0 * B + 0) instead of two v_mov_b64 each
-      asm volatile("" : "+v"(qz4));                               // (opaque: three issues, not one and two copies)
-      acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(qz4, qz4, SDRFM_Q_MAGIC ? qmb4 : qi4_t{0, 0, 0, 0}, 0, 0, 0);
-#else
-      acc[t] = SDRFM_Q_MAGIC ? qi4_t{QMB, QMB, QMB, QMB} : qi4_t{0, 0, 0, 0};
-#endif
-    }
+    for (int t = 0; t < SDRFM_Q_DIGITS; ++t) acc[t] = qi4_t{0, 0, 0, 0};   // (zeroed by the matrix pipe itself — a dense issue with a zero A operand — measured slower: r06_q_experiments.txt item 3)
     [[maybe_unused]] constexpr int XM = (int)0x80808080;
 #ifndef SDRFM_Q_LDSXOR
 #pragma unroll
@@ -686,14 +656,10 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
     float y[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-#if SDRFM_Q_MAGIC
-      const int i0 = acc[0][r], i1 = acc[1][r], i2 = acc[2][r];   // (copies: __builtin_bit_cast of a vector ELEMENT reads element 0 whatever the index — clang 22)
-      const float f0 = __builtin_bit_cast(float, i0) - qmf, f1 = __builtin_bit_cast(float, i1) - qmf, f2 = __builtin_bit_cast(float, i2) - qmf;   // exact
-      y[r] = __builtin_fmaf(f0, q0v, __builtin_fmaf(f1, q1v, __builtin_fmaf(f2, q2v, cstv)));
-#else
+      // (The digit sums as exact floats — accumulators started at the bit pattern of 1.5 * 2^23, a full-rate subtraction instead of the conversions and the
+      // shift-add, three fused multiply-adds — measured no faster with the factors in SGPRs and slower with them in VGPRs: r06_q_experiments.txt item 2.)
       const int s01 = acc[0][r] + acc[1][r] * 256;              // exact: |S0| <= 2^20, |S1 << 8| <= 2^28
       y[r] = __builtin_fmaf((float)s01, q0v, __builtin_fmaf((float)acc[2][r], q2v, cstv));
-#endif
     }
 #ifdef SDRFM_Q_PHASES
     asm volatile("" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));

@@ -26,6 +26,9 @@ int sdrfm_q_build(const float* h, uint32_t T, uint32_t D, int8_t* A, float* q, f
 /* The conditioning guard's thresholds for channel taps h[0..T) and audio taps g[0..Ta) (see qtaps.c): a lane is repaired when one of its y's
  * has max(|re|, |im|) < *guard_r or one of its |d|'s exceeds *guard_a.  Returns 0 or -1. */
 int sdrfm_q_guard(const float* h, uint32_t T, const float* g, uint32_t Ta, float* guard_r, float* guard_a);
+/* ... with the bound on |y_fast-q - y_definition| the radius rests on chosen: worst_case = 0 the statistical one (sdrfm_q_guard), 1 the PROVEN
+ * worst case of the chain's and the recombination's roundings and the taps' quantisation (SDRFM_CFG_GUARD_WORST_CASE; qtaps.c has the terms). */
+int sdrfm_q_guard2(const float* h, uint32_t T, const float* g, uint32_t Ta, int worst_case, float* guard_r, float* guard_a);
 
 #ifdef __cplusplus
 }

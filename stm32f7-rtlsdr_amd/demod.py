@@ -23,6 +23,7 @@ class FmConfig:
     force_generic: bool = False     # SDRFM_CFG_FORCE_GENERIC: never use a (T,D)-specialised kernel (tests)
     bit_exact: bool = False         # SDRFM_CFG_BIT_EXACT: only kernels bit-identical to the fmaf-chain definition (never "fast-q")
     no_zerocopy: bool = False       # SDRFM_CFG_NO_ZEROCOPY: URB-sized host calls take the staged copy path (tests)
+    guard_worst_case: bool = False  # SDRFM_CFG_GUARD_WORST_CASE: "fast-q"'s conditioning guard from the proven worst-case bound on |dy| (6.9 x the radius at 64 taps)
     dev_library: bool = False       # load csrc/libsdrfm_dev.so (instrumented / ablation kernels, SDRFM_* environment knobs)
 
 
@@ -43,7 +44,7 @@ class FmDemod:
         c.audio_coeffs = g.ctypes.data_as(C.POINTER(C.c_float))
         c.max_bytes_per_call = cfg.max_bytes_per_call
         c.device = cfg.device
-        c.flags = (1 if cfg.force_generic else 0) | (2 if cfg.no_zerocopy else 0) | (4 if cfg.bit_exact else 0)
+        c.flags = (1 if cfg.force_generic else 0) | (2 if cfg.no_zerocopy else 0) | (4 if cfg.bit_exact else 0) | (8 if cfg.guard_worst_case else 0)
         self._h = C.c_void_p()
         st = self._lib.sdrfm_create(C.byref(c), C.byref(self._h))
         if st != _l.OK:

@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
 
 
 # include/sdrfm_dev.h: test hooks the product library also exports / development-library-only aids (not the drop-in boundary)
-TEST_HOOK_SYMBOLS = ["sdrfm_host_atan2f", "sdrfm_host_discriminate", "sdrfm_debug_discriminate", "sdrfm_q_build", "sdrfm_q_guard", "sdrfm_debug_q_guard", "sdrfm_debug_read_ceiling", "sdrfm_debug_route"]
+TEST_HOOK_SYMBOLS = ["sdrfm_host_atan2f", "sdrfm_host_discriminate", "sdrfm_debug_discriminate", "sdrfm_q_build", "sdrfm_q_guard", "sdrfm_q_guard2", "sdrfm_debug_q_guard", "sdrfm_debug_read_ceiling", "sdrfm_debug_route"]
 DEV_ONLY_SYMBOLS = ["sdrfm_debug_phase_cycles", "sdrfm_debug_raw", "sdrfm_dev_read_debug"]
 
 
@@ -131,6 +131,8 @@ def load_library(dev=False):
     lib.sdrfm_debug_discriminate.restype = C.c_int
     lib.sdrfm_q_guard.argtypes = [vp, u32, vp, u32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.sdrfm_q_guard.restype = C.c_int
+    lib.sdrfm_q_guard2.argtypes = [vp, u32, vp, u32, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.sdrfm_q_guard2.restype = C.c_int
     lib.sdrfm_debug_read_ceiling.argtypes = [C.c_int, C.POINTER(vp), u32, C.c_size_t, u32, C.POINTER(C.c_double)]
     lib.sdrfm_debug_read_ceiling.restype = C.c_int
     lib.sdrfm_debug_q_guard.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
