@@ -174,6 +174,12 @@ int  sdrfm_flush(sdrfm_t* h);
 /* The same for every overlapped call but the most recent one: a consumer of call k-1's audio that runs on the handle's stream is put behind
  * call k-1 only, so call k keeps running beside it (and call k+1, ordered behind the consumer, may reuse call k-1's audio buffer). */
 int  sdrfm_flush_previous(sdrfm_t* h);
+/* The same ordering given to ANOTHER stream of the caller's (hipStream_t): `hip_stream` is put behind every overlapped call but the most recent one, and the
+ * handle's own stream is left alone — so a consumer of call k-1's audio on a stream of its own (the device PCM sink, a copy engine) runs beside call k, and call
+ * k+1 is ordered behind nothing but its own inputs: the consumer loop of INTEGRATION.md at the demodulator's own rate (23 us per BASELINE configs[2] call with the
+ * device PCM sink as the consumer; a consumer on the handle's stream holds every second call back: 43 us).  The caller orders its reuse of an audio buffer against
+ * that consumer itself (three audio buffers and an event).  Non-blocking. */
+int  sdrfm_wait_previous(sdrfm_t* h, void* hip_stream);
 
 /* Introspection used by bench/tests: the kernel variant that served the LAST call (before any call: the one the
  * configuration selects), e.g. "fast T64 D10 R4 Ta32 Da5" or "generic T7 D3 Ta5 Da4 NA64". */
@@ -305,10 +311,17 @@ int   sdrfm_pcm_deemph_s16(const float* audio, uint32_t n, float alpha, float ga
 float sdrfm_pcm_alpha(float fs_hz, float tau_s);   /* 1 - exp(-1/(fs*tau)); tau = 75e-6 (US) / 50e-6 (EU) */
 
 /* The same sink ON THE DEVICE for the batched path: audio[stream * audio_stride + i] (f32, as sdrfm_process_batch leaves it) ->
- * pcm[stream * pcm_stride + 2*i + {0,1}] (int16, L = R), de-emphasis state carried per stream in the handle.  Bit-identical
- * to sdrfm_pcm_deemph_s16 run per stream (same operations in the same order; csrc/sdrfm_sink.hip).  pcm_stride is in int16
+ * pcm[stream * pcm_stride + 2*i + {0,1}] (int16, L = R), de-emphasis state carried per stream in the handle.  pcm_stride is in int16
  * elements, even, >= 2*n.  With SDRFM_F_DEVICE_PTRS both buffers are device memory (pcm 4-byte aligned) and the call only
- * enqueues on the sink's stream; give it the demodulator's stream (or synchronise) so that it runs after the audio exists. */
+ * enqueues on the sink's stream; give it the demodulator's stream (or synchronise) so that it runs after the audio exists.
+ * Two forms of the same recursion (csrc/sdrfm_sink.hip):
+ *   default            a blocked scan — 256 lanes per stream walk chunks of the call, the carries between chunks by a scan, every chunk then
+ *                      re-walked from its true carry-in with the exact form's own operations: PCM within 1 LSB of the exact form's (different only
+ *                      where y * gain sits on a rounding boundary), carried state within 1e-6 relative; microseconds per 256 x 4800 call
+ *                      (profiles/r06_sink.txt);
+ *   SDRFM_PCM_F_EXACT  one lane per stream, the operations of sdrfm_pcm_deemph_s16 in its order: BIT-IDENTICAL to it (and to an exact-rational
+ *                      restatement: tests/test_pcm_sink_gpu.py); latency-bound: 1.35 ms per 256 x 4800 call. */
+#define SDRFM_PCM_F_EXACT 4u      /* flag for sdrfm_pcm_sink_process_batch (beside SDRFM_F_DEVICE_PTRS) */
 typedef struct sdrfm_pcm_sink sdrfm_pcm_sink_t;
 int  sdrfm_pcm_sink_create(uint32_t n_streams, float alpha, float gain, int32_t device, sdrfm_pcm_sink_t** out);
 void sdrfm_pcm_sink_destroy(sdrfm_pcm_sink_t* k);

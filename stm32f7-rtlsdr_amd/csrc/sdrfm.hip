@@ -1579,6 +1579,19 @@ int sdrfm_flush_previous(sdrfm_t* h) {
   return SDRFM_OK;
 }
 
+// A stream of the caller's behind all overlapped calls but the most recent one; the handle's own stream is not touched (it keeps its pending joins).
+int sdrfm_wait_previous(sdrfm_t* h, void* hip_stream) {
+  if (!h || !hip_stream) return SDRFM_EINVAL;
+  HIP_TRY(hipSetDevice(h->device), SDRFM_FAIL);
+  const uint32_t k = h->ovl_next;                                // the stream the NEXT call takes = the one the call before the last took
+  h->ovl_join_style = true;                                     // (a join after every call: from now on the kernels carry their stream's completion event)
+  if (h->ovl_pending[k]) {
+    if (!h->ovl_bound[k]) { HIP_TRY(hipEventRecord(h->ovl_done[k], h->ovl_stream[k]), SDRFM_FAIL); h->ovl_bound[k] = true; }   // (recorded once: it covers the stream's latest call)
+    HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(hip_stream), h->ovl_done[k], 0), SDRFM_FAIL);
+  }
+  return SDRFM_OK;
+}
+
 int sdrfm_set_stream(sdrfm_t* h, void* hip_stream) {
   if (!h) return SDRFM_EINVAL;
   HIP_TRY(hipSetDevice(h->device), SDRFM_FAIL);

@@ -96,6 +96,9 @@ struct QGeo {
 #ifndef SDRFM_Q_XORSKIP
 #define SDRFM_Q_XORSKIP 1   // 1 (round 6): D = 10, T <= 64: window bytes 0 .. 51 meet no tap (qtaps.c: tap k = 89 + 10 o - w < 64), so the first dword of a lane's first piece
 #endif                      // (bytes 16 g .. 16 g + 3 <= 51) needs no byte - 128: one v_xor less per step
+#ifndef SDRFM_Q_PEEL
+#define SDRFM_Q_PEEL 1      // 1 (round 6): the run's last step peeled out of the step loop (what only the last step does is compiled out of the others)
+#endif
 #ifndef SDRFM_Q_MICRO
 #define SDRFM_Q_MICRO 1     // 1 (round 6): the carried angle enters lane 0 through v_writelane (one instruction instead of a move and a select); the d write's address
 #endif                      // is one shift-add on a pointer kept in a VGPR (the compiler re-added the buffer's offset every step)
@@ -385,7 +388,7 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
   const int srcaddr = 4 * (g > 0 ? lane - 16 : ((lane + 47) & 63));   // lane holding y[m-1] of this lane's first output
   const int dlane = 8 * n + 2 * g;
   const int ylast = (int)p.M - 1 - o0;                          // the call's last output, relative to the grid
-  const int ylast_step = ylast >> 7, ylast_lane = ((ylast & 127) >> 3) + 16 * ((ylast & 7) >> 1);
+  const int ylast_lane = ((ylast & 127) >> 3) + 16 * ((ylast & 7) >> 1);   // (its step is the last run's last one: blocks [bs, Bt) end with the block that holds output M - 1)
 
   // (A version software-pipelined by one stage — the window of step kk + 1 read, and the ring refilled, while the discriminators of
   // step kk run — measured 33.4 us against 30.5 us for this straight order on the same box: the earlier wait for the next step's bytes
@@ -612,7 +615,17 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
 #endif
   const int wrank = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 4) & 15u);
   const int prio_at = p.prio_by_age ? nsteps / 2 : -1;
+  // One step.  LAST (a compile-time flag): the run's last step, peeled out of the loop (round 6) — everything that only the last step does (the call's y[-1] and d
+  // history handed over, the partly filled step's lanes kept off the guard's list, the repair pass and the audio stage that must not wait for a full stage) then costs
+  // the other steps nothing: ~20 scalar instructions and four exec-mask round trips per step, a tenth of a wave's own instruction stream (profiles/r06_q_experiments.txt
+  // item 6).  The last step also refills nothing: no step is left to read the ring.
+#if SDRFM_Q_PEEL
+  auto step = [&](auto LAST_, const int kk) {
+    constexpr bool LAST = decltype(LAST_)::value;
+#else
   for (int kk = 0; kk < nsteps; ++kk) {
+    const bool LAST = kk == nsteps - 1;
+#endif
     if (kk == prio_at) {
       if (wrank == 0) __builtin_amdgcn_s_setprio(0);
       else if (wrank == 1) __builtin_amdgcn_s_setprio(1);
@@ -623,9 +636,9 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
 #endif
     read_step(B, kk == 0);
     Q_PHASE(1);                                                 // wait for the step's bytes, window reads issued
-    refill_step(kk);
+    if (!(SDRFM_Q_PEEL && LAST)) refill_step(kk);
 #ifdef SDRFM_Q_EARLYSTORE   // experiment (round 5): the stages parked so far are stored BEFORE the run's last step computes (their acknowledgements then come
-    if (kk == nsteps - 1 && npend > 0) flush_audio();   // back during it: a wave ends only when its stores are acknowledged), the last stage alone after it
+    if (LAST && npend > 0) flush_audio();   // back during it: a wave ends only when its stores are acknowledged), the last stage alone after it
 #endif
     Q_PHASE(2);                                                 // LDS round trip of the window, refill issue
     // ---- K2 on the matrix pipe ------------------------------------------------------------------------------------------------
@@ -710,7 +723,7 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
       dst[0] = d0;
       dst[1] = d1;
     }
-    if (last_run && kk == ylast_step && lane == ylast_lane) kargs()->yprev_out[stream] = make_float2(y[2], y[3]);
+    if (LAST && last_run && lane == ylast_lane) kargs()->yprev_out[stream] = make_float2(y[2], y[3]);   // (the call's last output lies in the last run's last step)
 #if !(defined(SDRFM_Q_ABLATE) && (SDRFM_Q_ABLATE & 512))
     // ---- the conditioning guard: design Q's y is within E ~ 1e-4 (absolute) of the definition's fmaf chain, so its d is within
     // E / |y| + E / |p| of the definition's — fine while both magnitudes are large, not at a deep fade, and near d = +-pi the two may land
@@ -756,7 +769,7 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
           : "scc");
 #endif
       if (fm) {                                                                                // wave-uniform, rare
-        if (kk == nsteps - 1 && nlast < 16) fm &= 0x0001000100010001ull * ((1ull << nlast) - 1ull);   // the run's last step: only its first nlast blocks exist
+        if (LAST && nlast < 16) fm &= 0x0001000100010001ull * ((1ull << nlast) - 1ull);   // the run's last step: only its first nlast blocks exist
         if (fm) {
           const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(fm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fm, 0u));
           if ((fm >> lane) & 1ull) fl16[nflag + rank] = (unsigned short)(((osm + 1) << 6) | lane);
@@ -768,7 +781,7 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
     ++osm;
     // everything the list holds is repaired before the d's are read: at every audio stage, at the run's last step (the d history below), and
     // whenever another step's worth of lanes might not fit
-    if (nflag > 0 && (osm == QDA || kk == nsteps - 1 || nflag > 64)) {
+    if (nflag > 0 && (osm == QDA || LAST || nflag > 64)) {
       __builtin_amdgcn_s_setprio(3);                            // a wave in the repair path is behind its SIMD's others: first in line until it is through
       repair_flagged();
       if (prio_at >= 0 && kk >= prio_at) {
@@ -781,7 +794,7 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
     }
     __builtin_amdgcn_wave_barrier();                            // (the d's are read by other lanes from here on)
     // the stream's last 31 d's, taken before the audio stage below may move the buffer on (the call's last step need not be full)
-    if (last_run && kk == nsteps - 1 && lane < QTA - 1) {
+    if (LAST && last_run && lane < QTA - 1) {
       const KargPtr pp = kargs();
       pp->hist_d_out[(size_t)stream * (QTA - 1) + lane] = db[DB0 + sigma + ((int)pp->M - (QTA - 1) + lane - mbase)];
     }
@@ -791,7 +804,7 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
     Q_PHASE(5);                                                 // discriminators, d write
 
     // ---- K4: 128 audio outputs per five owned steps, two consecutive outputs per lane -------------------------------------------
-    if (osm == QDA || (kk == nsteps - 1 && osm > 0)) {
+    if (osm == QDA || (LAST && osm > 0)) {
       const float* w = db + DB0 + sigma + phi + 2 * QDA * lane - (QTA - 1);   // oldest d of the stage's output 2 lane: an even word
       // The whole 40-word window is read up front (one LDS round trip), then four independent chains: each output's 32 taps as two
       // halves of 16, oldest d first within a half, summed at the end.  (Reading the window eight words at a time in two chains took 340
@@ -842,7 +855,13 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
       if (npend == ABS) flush_audio();                          // (long runs only: configs[2]'s runs hold 3.4 stages)
       Q_PHASE(6);                                               // audio stage
     }
+#if SDRFM_Q_PEEL
+  };
+  for (int kk = 0; kk < nsteps - 1; ++kk) step(std::false_type{}, kk);
+  step(std::true_type{}, nsteps - 1);
+#else
   }
+#endif
 #ifdef SDRFM_Q_STAMPS
   const unsigned long long t_loop = __builtin_amdgcn_s_memrealtime();
 #endif

@@ -16,11 +16,23 @@
  *   lane = stream: 64 dependent steps from LDS, packed (L | R << 16) back into the tile in place
  *   LDS --row r--> HBM 256 B coalesced stores of the interleaved int16 pairs
  *
- * The chain is latency-bound (sub -> fma per sample): ~4800 samples x ~10 cycles ~ 25 us per launch at any stream count
- * up to 64 per CU-resident wave; it runs on its own stream beside the next batch's demodulation.
+ * The chain is latency-bound (one lane per stream, and every 64 samples a tile of 64 dependent row loads): measured 1.35 ms per 256 x 4800
+ * launch (profiles/r06_sink.txt; rounds 2 - 5 quoted an estimate of 25 us that had never been timed) — sixty demodulator calls.  It is kept
+ * as the EXACT form (SDRFM_PCM_F_EXACT): bit-identical to the host routine.
+ *
+ * The default since round 6 is a BLOCKED SCAN (k_pcm_sink_scan): the recursion is linear — y[n] = (1 - alpha) y[n-1] + alpha x[n] —,
+ * so a stream's call is cut into segments of 64 chunks of 75 samples, one lane per chunk, ONE WAVE per stream, the chunk in registers, no LDS:
+ *   1. lane t walks its chunk from state 0 (lane 0: from the carried state) -> e[t], the chunk's own contribution to its last sample;
+ *   2. the carries s[t] = (1 - alpha)^c s[t-1] + e[t] by a Hillis-Steele scan over the wave's 64 lanes (6 shuffles, the powers squared on the way);
+ *   3. lane t walks its chunk AGAIN, now from its true carry-in s[t-1], with exactly the exact form's operations, and packs the PCM.
+ * What differs from the exact chain is therefore only the carry-in of a chunk (re-associated: ~1e-7 relative), and that difference decays with
+ * (1 - alpha)^k inside the chunk: the PCM is within 1 LSB of the exact form's (equal but where y * gain sits within 1e-3 of a rounding boundary),
+ * the carried state within 2.5e-7 (tests/test_pcm_sink_gpu.py).  A lane reads and writes its own 300 consecutive bytes; the chunk sits in registers for both
+ * walks; no LDS allocation and one wave per stream, so that the kernel finds room BESIDE the demodulator's waves (profiles/r06_sink.txt has the timings).
  */
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -71,6 +83,59 @@ __global__ void __launch_bounds__(64) k_pcm_sink(SinkParams p) {
     __syncthreads();
   }
   if (lane < rows) p.state[mine] = y;
+}
+
+// ---- the blocked scan (the default): ONE WAVE per stream, no LDS allocation, segments of 64 x SINK_C samples in registers --------------------------------------
+// (A first version — 256 lanes per stream, the row staged through 19 KiB of LDS — took 7.3 us alone and 33 us per call in the consumer loop: beside the
+// demodulator, whose 15 waves per CU hold all but 0.9 KiB of a CU's LDS, its workgroups had to wait for a CU to drain.  This one needs no LDS and one wave slot.)
+constexpr uint32_t SINK_C = 75, SINK_SEG = 64 * SINK_C;         // 4800 samples per segment: BASELINE's call in one
+
+__global__ void __launch_bounds__(64) k_pcm_sink_scan(SinkParams p, float pc) {
+  const uint32_t s = blockIdx.x, t = threadIdx.x;
+  const float* const row = p.audio + (size_t)s * p.audio_stride;
+  unsigned* const out = reinterpret_cast<unsigned*>(p.pcm + (size_t)s * p.pcm_stride);
+  float y0 = p.state[s];                                        // the state before the segment (every lane holds it)
+  for (uint32_t base = 0; base < p.n; base += SINK_SEG) {
+    const uint32_t m = (p.n - base < SINK_SEG) ? p.n - base : SINK_SEG;   // samples of this segment
+    // the lane's chunk [i0, i0 + cnt) straight into registers: a lane reads 300 consecutive bytes, the wave 19 200 — every line is used whole, from the L1 after
+    // its first touch
+    const uint32_t i0 = t * SINK_C < m ? t * SINK_C : m, cnt = (m - i0 < SINK_C) ? m - i0 : SINK_C;
+    const float* const src = row + base + i0;
+    float xr[SINK_C];
+#pragma unroll
+    for (uint32_t q = 0; q < SINK_C; ++q) xr[q] = q < cnt ? src[q] : 0.0f;
+    // 1. the chunk's own contribution to its last sample (lane 0 starts from the real state: its chain is the exact one already)
+    float y = t == 0 ? y0 : 0.0f;
+#pragma unroll
+    for (uint32_t q = 0; q < SINK_C; ++q)
+      if (q < cnt) y = __builtin_fmaf(p.alpha, xr[q] - y, y);
+    // 2. s[t] = pc s[t-1] + e[t], pc = (1 - alpha)^SINK_C: Hillis-Steele over the wave's 64 lanes (only the last non-empty chunk may be short, and nothing follows it)
+    float sc = y, pw = pc;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+      const float up = __shfl_up(sc, d, 64);
+      if (t >= d) sc = __builtin_fmaf(pw, up, sc);
+      pw *= pw;
+    }
+    // 3. the exact form's chain from the true carry-in
+    const float cin = __shfl_up(sc, 1, 64);
+    y = t == 0 ? y0 : cin;
+    unsigned* const dst = out + base + i0;
+#pragma unroll
+    for (uint32_t q = 0; q < SINK_C; ++q)
+      if (q < cnt) {
+        y = __builtin_fmaf(p.alpha, xr[q] - y, y);
+        float v = y * p.gain;
+        if (v > 32767.0f) v = 32767.0f;
+        if (v < -32768.0f) v = -32768.0f;
+        const unsigned w = (unsigned)(int)__builtin_rintf(v) & 0xffffu;
+        dst[q] = w | (w << 16);
+      }
+    // the state behind the segment: the last sample's lane has it
+    const uint32_t tl = (m - 1) / SINK_C;
+    y0 = __shfl(y, (int)tl, 64);
+  }
+  if (t == 0) p.state[s] = y0;
 }
 
 }  // namespace
@@ -162,7 +227,7 @@ int sdrfm_pcm_sink_synchronize(sdrfm_pcm_sink_t* k) {
 int sdrfm_pcm_sink_process_batch(sdrfm_pcm_sink_t* k, const float* audio, size_t audio_stride, uint32_t n, int16_t* pcm,
                                  size_t pcm_stride, uint32_t flags) {
   if (!k) return SDRFM_EINVAL;
-  if (flags & ~SDRFM_F_DEVICE_PTRS) return SDRFM_EINVAL;
+  if (flags & ~(SDRFM_F_DEVICE_PTRS | SDRFM_PCM_F_EXACT)) return SDRFM_EINVAL;
   if (n == 0) return SDRFM_OK;
   if (!audio || !pcm) return SDRFM_EINVAL;
   if (k->n_streams > 1 && (audio_stride < n || pcm_stride < 2 * (size_t)n)) return SDRFM_ECAPACITY;
@@ -171,10 +236,16 @@ int sdrfm_pcm_sink_process_batch(sdrfm_pcm_sink_t* k, const float* audio, size_t
   SinkParams p;
   p.state = k->d_state; p.n_streams = k->n_streams; p.n = n; p.alpha = k->alpha; p.gain = k->gain;
   const dim3 grid((k->n_streams + 63) / 64);
+  const float pc = (float)pow(1.0 - (double)k->alpha, (double)SINK_C);   // the blocked scan's carry factor: (1 - alpha)^(samples per chunk)
+  const bool exact = (flags & SDRFM_PCM_F_EXACT) != 0;
+  auto launch = [&]() {
+    if (exact) hipLaunchKernelGGL(k_pcm_sink, grid, dim3(64), 0, k->stream, p);
+    else hipLaunchKernelGGL(k_pcm_sink_scan, dim3(k->n_streams), dim3(64), 0, k->stream, p, pc);
+  };
   if (flags & SDRFM_F_DEVICE_PTRS) {
     if ((uintptr_t)pcm % 4 != 0) return SDRFM_EINVAL;
     p.audio = audio; p.audio_stride = audio_stride; p.pcm = pcm; p.pcm_stride = pcm_stride;
-    hipLaunchKernelGGL(k_pcm_sink, grid, dim3(64), 0, k->stream, p);
+    launch();
     STRY(hipGetLastError(), SDRFM_FAIL);
     return SDRFM_OK;
   }
@@ -192,7 +263,7 @@ int sdrfm_pcm_sink_process_batch(sdrfm_pcm_sink_t* k, const float* audio, size_t
   STRY(hipMemcpy2DAsync(k->d_audio, sizeof(float) * k->cap, audio, sizeof(float) * as, sizeof(float) * n, k->n_streams,
                         hipMemcpyHostToDevice, k->stream), SDRFM_FAIL);
   p.audio = k->d_audio; p.audio_stride = k->cap; p.pcm = k->d_pcm; p.pcm_stride = 2 * (size_t)k->cap;
-  hipLaunchKernelGGL(k_pcm_sink, grid, dim3(64), 0, k->stream, p);
+  launch();
   STRY(hipGetLastError(), SDRFM_FAIL);
   STRY(hipMemcpy2DAsync(pcm, sizeof(int16_t) * ps, k->d_pcm, sizeof(int16_t) * 2 * k->cap, sizeof(int16_t) * 2 * n, k->n_streams,
                         hipMemcpyDeviceToHost, k->stream), SDRFM_FAIL);

@@ -168,6 +168,11 @@ class FmDemod:
                                                _l.F_DEVICE_PTRS | (_l.F_OVERLAP if overlap else 0)), "sdrfm_process_batch(device)")
         return n.value
 
+    def wait_previous(self, hip_stream_ptr):
+        """sdrfm_wait_previous: the caller's stream `hip_stream_ptr` is ordered behind every overlapped call but the most recent one; the handle's own stream is
+        left alone (a consumer of call k-1's audio on its own stream, beside call k)."""
+        self._ck(self._lib.sdrfm_wait_previous(self._h, C.c_void_p(int(hip_stream_ptr))), "sdrfm_wait_previous")
+
     def flush(self, keep_last=False):
         """Order the handle's stream behind every overlapped call made so far (sdrfm_flush) — or, with keep_last, behind all but the most
         recent one (sdrfm_flush_previous); does not block the host."""

@@ -19,9 +19,16 @@ def pcm_deemph_s16_host(audio, alpha, gain, state=0.0):
     return pcm, st.value
 
 
+PCM_F_EXACT = 4   # SDRFM_PCM_F_EXACT (include/sdrfm.h)
+
+
 class PcmSink:
-    def __init__(self, n_streams, alpha, gain, device=0):
+    """exact=False (default): the blocked-scan kernel (PCM within 1 LSB of the exact form); exact=True: SDRFM_PCM_F_EXACT, one lane per stream,
+    bit-identical to the host routine sdrfm_pcm_deemph_s16."""
+
+    def __init__(self, n_streams, alpha, gain, device=0, exact=False):
         self._lib = _l.load_library()
+        self._xf = PCM_F_EXACT if exact else 0
         self.n_streams = int(n_streams)
         self._h = C.c_void_p()
         st = self._lib.sdrfm_pcm_sink_create(self.n_streams, alpha, gain, device, C.byref(self._h))
@@ -72,7 +79,7 @@ class PcmSink:
         assert a.shape[0] == self.n_streams
         n = a.shape[1]
         pcm = np.zeros((self.n_streams, 2 * n), np.int16)
-        self._ck(self._lib.sdrfm_pcm_sink_process_batch(self._h, a.ctypes.data, n, n, pcm.ctypes.data, 2 * n, 0),
+        self._ck(self._lib.sdrfm_pcm_sink_process_batch(self._h, a.ctypes.data, n, n, pcm.ctypes.data, 2 * n, self._xf),
                  "sdrfm_pcm_sink_process_batch")
         return pcm
 
@@ -81,5 +88,5 @@ class PcmSink:
         assert audio.is_cuda and pcm.is_cuda and audio.stride(1) == 1 and pcm.stride(1) == 1
         n = audio.shape[1] if n is None else int(n)
         self._ck(self._lib.sdrfm_pcm_sink_process_batch(self._h, C.c_void_p(audio.data_ptr()), audio.stride(0), n,
-                                                        C.c_void_p(pcm.data_ptr()), pcm.stride(0), _l.F_DEVICE_PTRS),
+                                                        C.c_void_p(pcm.data_ptr()), pcm.stride(0), _l.F_DEVICE_PTRS | self._xf),
                  "sdrfm_pcm_sink_process_batch(device)")

@@ -115,7 +115,7 @@ def test_c_multi_gpu_host_on_the_devices_present(pkg, oracle_mod, tmp_path, tran
 def test_c_pipeline_host_overlapped_equals_serial_and_the_host_sink(pkg, tmp_path):
     """examples/pipeline_main.c: a capture ring of three device buffers filled on the stream, SDRFM_F_OVERLAP calls, the device PCM sink
     as the consumer of call k-1 behind sdrfm_flush_previous while call k runs.  The PCM must equal the same program's --serial output
-    bit for bit, and the host sink run over the Python wrapper's serial audio."""
+    bit for bit, and — within the 1 LSB the device sink's blocked scan is held to — the host sink run over the Python wrapper's serial audio."""
     import json
     exe = os.path.join(ROOT, "examples", "pipeline_main")
     if not os.path.exists(exe):
@@ -150,4 +150,5 @@ def test_c_pipeline_host_overlapped_equals_serial_and_the_host_sink(pkg, tmp_pat
         st = 0.0
         for k in range(n_calls):
             want, st = pkg.pcm_deemph_s16_host(audio[k][s_], alpha, gain, st)
-            assert np.array_equal(outs["overlapped"][k, s_], want), (s_, k)
+            # (the program uses the device sink's default form, the blocked scan: within 1 LSB of the host routine's exact chain)
+            assert np.abs(outs["overlapped"][k, s_].astype(np.int32) - want.astype(np.int32)).max() <= 1, (s_, k)

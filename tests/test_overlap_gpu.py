@@ -121,7 +121,7 @@ def test_overlap_flag_on_a_bit_exact_handle_and_flag_errors(pkg):
 
 def test_pipeline_with_the_pcm_sink_on_the_handles_stream(pkg):
     """The loop INTEGRATION.md shows: call k overlapped, then the consumer of call k-1 (the device PCM sink, on the handle's stream) behind
-    sdrfm_flush_previous; two audio buffers in turn.  PCM equal to the host sink over the serial calls' audio."""
+    sdrfm_flush_previous; two audio buffers in turn.  PCM within 1 LSB of the host sink over the serial calls' audio."""
     import torch
     lib = pkg.load_library()
     alpha, gain = lib.sdrfm_pcm_alpha(48000.0, 75e-6), np.float32(32767.0 / (2 * np.pi * 75e3 / 240e3))
@@ -146,7 +146,7 @@ def test_pipeline_with_the_pcm_sink_on_the_handles_stream(pkg):
         state = 0.0
         for k in range(nb):
             want, state = pkg.pcm_deemph_s16_host(want_audio[k][s], alpha, gain, state)
-            assert np.array_equal(pcm[k].cpu().numpy()[s], want), (s, k)
+            assert np.abs(pcm[k].cpu().numpy()[s].astype(np.int32) - want.astype(np.int32)).max() <= 1, (s, k)   # (the sink's default form: a blocked scan, 1 LSB)
 
 
 def test_broken_promises_fall_back_to_serial_calls(pkg, oracle_mod, tol):
