@@ -21,14 +21,15 @@
  * as the EXACT form (SDRFM_PCM_F_EXACT): bit-identical to the host routine.
  *
  * The default since round 6 is a BLOCKED SCAN (k_pcm_sink_scan): the recursion is linear — y[n] = (1 - alpha) y[n-1] + alpha x[n] —,
- * so a stream's call is cut into segments of 64 chunks of 75 samples, one lane per chunk, ONE WAVE per stream, the chunk in registers, no LDS:
+ * so a stream's call is cut into segments of 256 chunks of 19 samples, one lane per chunk, one workgroup of 256 lanes per stream:
  *   1. lane t walks its chunk from state 0 (lane 0: from the carried state) -> e[t], the chunk's own contribution to its last sample;
- *   2. the carries s[t] = (1 - alpha)^c s[t-1] + e[t] by a Hillis-Steele scan over the wave's 64 lanes (6 shuffles, the powers squared on the way);
+ *   2. the carries s[t] = (1 - alpha)^c s[t-1] + e[t] by a Hillis-Steele scan over the 256 lanes in LDS (8 steps, the powers squared on the way);
  *   3. lane t walks its chunk AGAIN, now from its true carry-in s[t-1], with exactly the exact form's operations, and packs the PCM.
  * What differs from the exact chain is therefore only the carry-in of a chunk (re-associated: ~1e-7 relative), and that difference decays with
  * (1 - alpha)^k inside the chunk: the PCM is within 1 LSB of the exact form's (equal but where y * gain sits within 1e-3 of a rounding boundary),
- * the carried state within 2.5e-7 (tests/test_pcm_sink_gpu.py).  A lane reads and writes its own 300 consecutive bytes; the chunk sits in registers for both
- * walks; no LDS allocation and one wave per stream, so that the kernel finds room BESIDE the demodulator's waves (profiles/r06_sink.txt has the timings).
+ * the carried state within 2.5e-7 (tests/test_pcm_sink_gpu.py).  The audio row goes through LDS once (coalesced loads, chunk stride odd: conflict-free),
+ * the PCM row back the same way; the chunk sits in registers for both walks.  7.4 us per 256 x 4800 launch against the exact form's 1.35 ms
+ * (profiles/r06_sink.txt).
  */
 #include <hip/hip_runtime.h>
 
@@ -85,42 +86,53 @@ __global__ void __launch_bounds__(64) k_pcm_sink(SinkParams p) {
   if (lane < rows) p.state[mine] = y;
 }
 
-// ---- the blocked scan (the default): ONE WAVE per stream, no LDS allocation, segments of 64 x SINK_C samples in registers --------------------------------------
-// (A first version — 256 lanes per stream, the row staged through 19 KiB of LDS — took 7.3 us alone and 33 us per call in the consumer loop: beside the
-// demodulator, whose 15 waves per CU hold all but 0.9 KiB of a CU's LDS, its workgroups had to wait for a CU to drain.  This one needs no LDS and one wave slot.)
-constexpr uint32_t SINK_C = 75, SINK_SEG = 64 * SINK_C;         // 4800 samples per segment: BASELINE's call in one
-
-__global__ void __launch_bounds__(64) k_pcm_sink_scan(SinkParams p, float pc) {
+// ---- the blocked scan (the default): one workgroup of 256 lanes per stream; segments of SINK_NT * SINK_C samples through LDS ------------------------------
+// (A variant with ONE WAVE per stream, 75-sample chunks in registers and no LDS at all was built to slip in beside the demodulator's waves, which hold all but
+// 0.9 KiB of a CU's LDS: 10.5 us alone against 7.4 us for this one, and no faster in the consumer loop — profiles/r06_sink.txt.  Not kept.)
+constexpr uint32_t SINK_NT = 256, SINK_C = 19, SINK_SEG = SINK_NT * SINK_C;   // 4864 samples per segment (BASELINE's 4800 per call: one segment), 19 KiB of LDS;
+                                                                             // lanes SINK_C = 19 words apart (odd): conflict-free LDS accesses
+__global__ void __launch_bounds__(256) k_pcm_sink_scan(SinkParams p, float pc) {
+  __shared__ float x[SINK_SEG];                                 // the segment's samples, then (in place) the packed PCM words
+  __shared__ float sc[SINK_NT];                                 // the scan
+  unsigned* const xw = reinterpret_cast<unsigned*>(x);
   const uint32_t s = blockIdx.x, t = threadIdx.x;
   const float* const row = p.audio + (size_t)s * p.audio_stride;
   unsigned* const out = reinterpret_cast<unsigned*>(p.pcm + (size_t)s * p.pcm_stride);
   float y0 = p.state[s];                                        // the state before the segment (every lane holds it)
   for (uint32_t base = 0; base < p.n; base += SINK_SEG) {
     const uint32_t m = (p.n - base < SINK_SEG) ? p.n - base : SINK_SEG;   // samples of this segment
-    // the lane's chunk [i0, i0 + cnt) straight into registers: a lane reads 300 consecutive bytes, the wave 19 200 — every line is used whole, from the L1 after
-    // its first touch
+#pragma unroll
+    for (uint32_t q = 0; q < SINK_C; ++q) {                     // coalesced: SINK_C independent loads per lane in flight
+      const uint32_t i = t + SINK_NT * q;
+      if (i < m) x[i] = row[base + i];
+    }
+    __syncthreads();
+    // the lane's chunk [i0, i0 + cnt) in registers: both walks below then run at the chain's own latency (sub -> fma), no LDS round trip inside
     const uint32_t i0 = t * SINK_C < m ? t * SINK_C : m, cnt = (m - i0 < SINK_C) ? m - i0 : SINK_C;
-    const float* const src = row + base + i0;
     float xr[SINK_C];
 #pragma unroll
-    for (uint32_t q = 0; q < SINK_C; ++q) xr[q] = q < cnt ? src[q] : 0.0f;
+    for (uint32_t q = 0; q < SINK_C; ++q) xr[q] = q < cnt ? x[i0 + q] : 0.0f;
     // 1. the chunk's own contribution to its last sample (lane 0 starts from the real state: its chain is the exact one already)
     float y = t == 0 ? y0 : 0.0f;
 #pragma unroll
     for (uint32_t q = 0; q < SINK_C; ++q)
       if (q < cnt) y = __builtin_fmaf(p.alpha, xr[q] - y, y);
-    // 2. s[t] = pc s[t-1] + e[t], pc = (1 - alpha)^SINK_C: Hillis-Steele over the wave's 64 lanes (only the last non-empty chunk may be short, and nothing follows it)
-    float sc = y, pw = pc;
+    sc[t] = y;
+    __syncthreads();
+    // 2. s[t] = pc s[t-1] + e[t], pc = (1 - alpha)^SINK_C: Hillis-Steele (only the last non-empty chunk may be short, and nothing follows it)
+    float pw = pc;
 #pragma unroll
-    for (uint32_t d = 1; d < 64; d <<= 1) {
-      const float up = __shfl_up(sc, d, 64);
-      if (t >= d) sc = __builtin_fmaf(pw, up, sc);
+    for (uint32_t d = 1; d < SINK_NT; d <<= 1) {
+      float v = sc[t];
+      if (t >= d) v = __builtin_fmaf(pw, sc[t - d], v);
+      __syncthreads();
+      sc[t] = v;
+      __syncthreads();
       pw *= pw;
     }
     // 3. the exact form's chain from the true carry-in
-    const float cin = __shfl_up(sc, 1, 64);
-    y = t == 0 ? y0 : cin;
-    unsigned* const dst = out + base + i0;
+    y = t == 0 ? y0 : sc[t - 1];
+    __syncthreads();                                            // (every carry-in is in a register before sc[0] takes the segment's last state below)
 #pragma unroll
     for (uint32_t q = 0; q < SINK_C; ++q)
       if (q < cnt) {
@@ -129,11 +141,17 @@ __global__ void __launch_bounds__(64) k_pcm_sink_scan(SinkParams p, float pc) {
         if (v > 32767.0f) v = 32767.0f;
         if (v < -32768.0f) v = -32768.0f;
         const unsigned w = (unsigned)(int)__builtin_rintf(v) & 0xffffu;
-        dst[q] = w | (w << 16);
+        xw[i0 + q] = w | (w << 16);
       }
-    // the state behind the segment: the last sample's lane has it
-    const uint32_t tl = (m - 1) / SINK_C;
-    y0 = __shfl(y, (int)tl, 64);
+    if (cnt > 0 && i0 + cnt == m) sc[0] = y;                     // the lane that holds the segment's last sample: the state behind it
+    __syncthreads();
+    y0 = sc[0];
+#pragma unroll
+    for (uint32_t q = 0; q < SINK_C; ++q) {
+      const uint32_t i = t + SINK_NT * q;
+      if (i < m) out[base + i] = xw[i];
+    }
+    __syncthreads();
   }
   if (t == 0) p.state[s] = y0;
 }
@@ -240,7 +258,7 @@ int sdrfm_pcm_sink_process_batch(sdrfm_pcm_sink_t* k, const float* audio, size_t
   const bool exact = (flags & SDRFM_PCM_F_EXACT) != 0;
   auto launch = [&]() {
     if (exact) hipLaunchKernelGGL(k_pcm_sink, grid, dim3(64), 0, k->stream, p);
-    else hipLaunchKernelGGL(k_pcm_sink_scan, dim3(k->n_streams), dim3(64), 0, k->stream, p, pc);
+    else hipLaunchKernelGGL(k_pcm_sink_scan, dim3(k->n_streams), dim3(SINK_NT), 0, k->stream, p, pc);
   };
   if (flags & SDRFM_F_DEVICE_PTRS) {
     if ((uintptr_t)pcm % 4 != 0) return SDRFM_EINVAL;

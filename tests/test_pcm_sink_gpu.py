@@ -129,7 +129,7 @@ def test_device_sink_on_its_own_stream_behind_an_event(pkg):
 def test_blocked_scan_sink_within_one_lsb_of_the_exact_form(pkg, ns, n):
     """the default device sink is a blocked first-order scan (256 lanes per stream, the carries between chunks by a scan, every chunk
     re-walked from its true carry-in): PCM within 1 LSB of int16 of the exact one-lane chain — and different from it at all in fewer than one sample in a
-    thousand —, the carried state within 2.5e-7 (audio of unit scale), across two calls; lengths below, at and above the 64 chunks and above one segment (4800)."""
+    thousand —, the carried state within 2.5e-7 (audio of unit scale), across two calls; lengths below, at and above the 256 chunks and above one LDS segment (4864)."""
     alpha, gain = _params(pkg)
     rng = np.random.default_rng(ns * 77 + n)
     x = (rng.standard_normal((ns, 2 * n)) * 1.5).astype(np.float32)
@@ -176,8 +176,8 @@ def test_blocked_scan_sink_behind_the_demodulator(pkg):
 
 def test_consumer_on_its_own_stream_behind_wait_previous(pkg):
     """The fast consumer loop of INTEGRATION.md: overlapped calls, the device PCM sink on a stream OF ITS OWN ordered behind call k - 1 by sdrfm_wait_previous
-    (the handle's stream is left alone, so call k + 1 is held back by nothing), three audio buffers in turn, the reuse of a buffer ordered against its consumer by
-    an event that is only queried when it has already fired.  PCM within 1 LSB of host-sinking the serial calls' audio, for every batch."""
+    (the handle's stream is left alone, so call k + 1 is held back by nothing), three audio buffers in turn, the reuse of a buffer guarded on the host.
+    PCM within 1 LSB of host-sinking the serial calls' audio, for every batch."""
     import torch
     alpha, gain = _params(pkg)
     ns, nsamp, nb = 256, 48000, 9
@@ -193,8 +193,8 @@ def test_consumer_on_its_own_stream_behind_wait_previous(pkg):
         sink.set_stream(s_sink.cuda_stream)
         n = 0
         for k in range(nb):
-            if consumed[k % 3] is not None and not consumed[k % 3].query():
-                s_dm.wait_event(consumed[k % 3])
+            if consumed[k % 3] is not None:
+                consumed[k % 3].synchronize()                      # (the host guards the reuse of audio[k % 3]: no wait enters the demodulator's queues)
             n = dm.process_batch_device(iq[:, 2 * k * nsamp:], audio[k % 3], nbytes=2 * nsamp, overlap=True)
             if k:
                 assert "overlapped" in dm.kernel_name, dm.kernel_name

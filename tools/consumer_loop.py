@@ -3,6 +3,8 @@ ordered behind call k-1, where a consumer of its audio runs) against the same ca
 in its default form (the blocked scan) and in its exact form (one lane per stream), and the sink alone.  configs[2] shape, 5 rotated input batches, regions of 300 calls,
 the median of the last five of ten regions.  Measurement only (profiles/r06_sink.txt)."""
 import sys, os, time, importlib
+if len(sys.argv) > 1:
+    os.environ["GPU_MAX_HW_QUEUES"] = sys.argv[1]   # e.g. 8: before the HIP runtime loads (the loop uses five streams; the runtime's default pool holds 4 hardware queues)
 import numpy as np
 sys.path.insert(0, os.getcwd())
 pkg = importlib.import_module("stm32f7-rtlsdr_amd")
@@ -11,7 +13,8 @@ ns, nsamp = 256, 240000
 h, g = pkg.default_config(64)
 iq = pkg.make_iq(16, nsamp * 5, mode="fm", first_id=1)
 batches = [torch.from_numpy(np.tile(iq[:, 2 * k * nsamp:2 * (k + 1) * nsamp], (ns // 16, 1))).cuda() for k in range(5)]
-aud = [torch.zeros((ns, nsamp // 50), dtype=torch.float32, device="cuda") for _ in range(3)]
+aud = [torch.zeros((ns, nsamp // 50), dtype=torch.float32, device="cuda") for _ in range(6)]
+NA = int(os.environ.get("LOOP_AUDIO_BUFFERS", "3"))   # audio buffers of the fast form
 torch.cuda.synchronize()
 st = torch.cuda.Stream()
 pcm = [torch.zeros((ns, 2 * (nsamp // 50)), dtype=torch.int16, device="cuda") for _ in range(2)]
@@ -38,7 +41,8 @@ with pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=ns, max_by
         time.sleep(0.3)
         r = [region(dm, 300, per_call) for _ in range(10)]
         print("flush_previous after every call: %-5s  us per call, ten regions of 300: %s   steady (median of the last five) %.2f" % (per_call, " ".join("%.2f" % x for x in r), float(np.median(r[5:]))))
-    for exact in (False, True, False):
+    print("GPU_MAX_HW_QUEUES =", os.environ.get("GPU_MAX_HW_QUEUES", "(default: 4)"))
+    for exact in ((False,) if len(sys.argv) > 2 else (False, True, False)):
         with pkg.PcmSink(ns, alpha, gain, exact=exact) as sink:
             sink.set_stream(st.cuda_stream)
             time.sleep(0.3)
@@ -58,19 +62,20 @@ with pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=ns, max_by
     for rep in range(2):
         with pkg.PcmSink(ns, alpha, gain) as sink:
             sink.set_stream(sst.cuda_stream)
-            consumed = [None, None, None]
+            consumed = [None] * NA
 
             def region3(n):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(st)
                 for k in range(n):
-                    if consumed[k % 3] is not None and not consumed[k % 3].query():
-                        st.wait_event(consumed[k % 3])             # (the consumer of call k - 3 is long done in the steady state: a host-side query, no packet)
-                    dm.process_batch_device(batches[k % 5], aud[k % 3], overlap=True)
+                    if consumed[k % NA] is not None:
+                        while not consumed[k % NA].query():         # audio[k % NA] is free once its consumer (of call k - NA) is done: the HOST waits for that (a busy
+                            pass                                    # poll: it stays at most NA calls ahead of the device); no wait enters a queue of the demodulator's
+                    dm.process_batch_device(batches[k % 5], aud[k % NA], overlap=True)
                     if k:
                         dm.wait_previous(sst.cuda_stream)          # the sink's stream behind call k - 1; the handle's stream stays idle
-                        sink.process_batch_device(aud[(k - 1) % 3], pcm[(k - 1) & 1], nsamp // 50)
-                        consumed[(k - 1) % 3] = torch.cuda.Event(); consumed[(k - 1) % 3].record(sst)
+                        sink.process_batch_device(aud[(k - 1) % NA], pcm[(k - 1) & 1], nsamp // 50)
+                        consumed[(k - 1) % NA] = torch.cuda.Event(); consumed[(k - 1) % NA].record(sst)
                 dm.flush()
                 st.wait_stream(sst)
                 e1.record(st)
@@ -78,4 +83,4 @@ with pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=ns, max_by
                 return e0.elapsed_time(e1) / n * 1e3
             time.sleep(0.3)
             r = [region3(300) for _ in range(10)]
-            print("fast form (three audio buffers, the sink on its own stream): us per call, ten regions of 300: %s   steady %.2f" % (" ".join("%.2f" % x for x in r), float(np.median(r[5:]))))
+            print("fast form (%d audio buffers, the sink on its own stream, the host at most that many calls ahead): us per call" % NA + ", ten regions of 300: %s   steady %.2f" % (" ".join("%.2f" % x for x in r), float(np.median(r[5:]))))
