@@ -440,7 +440,8 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
         __builtin_amdgcn_wave_barrier();
       }
     }
-    ringoff = (ringoff + STEPB == RINGB) ? 0 : ringoff + STEPB;
+    if constexpr (RINGB == 2 * STEPB) ringoff ^= STEPB;          // (a ring of two steps: one s_xor)
+    else ringoff = (ringoff + STEPB == RINGB) ? 0 : ringoff + STEPB;
   };
   auto refill_step = [&](int k) {                               // step k's window is in registers: its slots are free, refill them
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -449,6 +450,25 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
       for (int q = 0; q < CS; ++q) q_raw_buffer_load_lds(rsrc, slot_ptr(slot + q), 16, vpos + 1024 * q + lsw(q), 0, 0, SDRFM_Q_AUX);
       slot = slot ? 0 : CS;
       vpos += STEPB;
+      return;
+    }
+    if constexpr (NSLOT == 5 && SDRFM_Q_PEEL) {
+      // The ring of five chunks is two steps of 2.5: the slots a step frees repeat with period two — an odd step refills slots 2, 3, an even one slots 4, 0, 1 (step 0:
+      // 0, 1 only, the prologue having filled the ring) — so the slot is a compile-time constant on either side of ONE parity test (round 6: the running slot counter
+      // and its wrap-arounds were ten scalar instructions per step).
+      if (k & 1) {
+        q_raw_buffer_load_lds(rsrc, slot_ptr(2), 16, vpos, 0, 0, SDRFM_Q_AUX);
+        q_raw_buffer_load_lds(rsrc, slot_ptr(2), 16, vpos, 0, 1024, SDRFM_Q_AUX);
+        vpos += 2048;
+      } else {
+        if (k > 0) {
+          q_raw_buffer_load_lds(rsrc, slot_ptr(4), 16, vpos, 0, 0, SDRFM_Q_AUX);
+          vpos += 1024;
+        }
+        q_raw_buffer_load_lds(rsrc, slot_ptr(0), 16, vpos, 0, 0, SDRFM_Q_AUX);
+        q_raw_buffer_load_lds(rsrc, slot_ptr(0), 16, vpos, 0, 1024, SDRFM_Q_AUX);
+        vpos += 2048;
+      }
       return;
     }
     if (k > 0 && !(k & 1)) {
@@ -743,7 +763,8 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
           "v_cmp_gt_f32_e64 %[fm], %[t1], %[ga]"
           : [t1] "=&v"(t1), [fm] "=&s"(fm), [m0] "=&s"(m0), [m1] "=&s"(m1)
           : [x0] "v"(mx0), [x1] "v"(mx1), [d0] "v"(d0), [d1] "v"(d1), [gr] "v"(guard_r), [ga] "v"(guard_a));
-      fm |= m0 | m1 | (m1 << 16) | ((m1 >> 47) & 0xFFFEull) | cfl;
+      fm |= m0 | m1 | cfl;                                        // (a carrier: all four masks are empty — the shifted copies of m1 are formed only when something is set)
+      if (fm) fm |= (m1 << 16) | ((m1 >> 47) & 0xFFFEull);
       cfl = m1 >> 63;
 #else
       float t0, t1, t2;

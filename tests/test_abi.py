@@ -114,12 +114,13 @@ def test_host_evaluation_of_device_atan2_is_accurate(pkg):
 
 
 def test_ordering_calls_reject_a_null_handle_without_touching_the_gpu(pkg):
-    """sdrfm_flush / sdrfm_flush_previous / sdrfm_synchronize / sdrfm_set_stream (the ordering half of the boundary, include/sdrfm.h) answer
+    """sdrfm_flush / sdrfm_flush_previous / sdrfm_wait_previous / sdrfm_synchronize / sdrfm_set_stream (the ordering half of the boundary, include/sdrfm.h) answer
     SDRFM_EINVAL for a NULL handle — no device needed; what they do on a device is in tests/test_overlap_gpu.py."""
     lib = pkg.load_library()
     for fn in (lib.sdrfm_flush, lib.sdrfm_flush_previous, lib.sdrfm_synchronize):
         assert fn(None) == 16
     assert lib.sdrfm_set_stream(None, None) == 16
+    assert lib.sdrfm_wait_previous(None, None) == 16                       # (round 6: a consumer's own stream behind call k - 1)
     n = __import__("ctypes").c_uint32()
     assert lib.sdrfm_process_batch(None, None, 0, 0, None, 0, __import__("ctypes").byref(n), 3) == 16
 

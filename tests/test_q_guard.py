@@ -46,6 +46,33 @@ def test_guard_thresholds_of_the_baseline_taps(pkg):
     assert guard_of(pkg, pkg.default_config(64)[0], np.zeros(32, np.float32)) == (0.0, 4.0)
 
 
+def test_worst_case_radius_is_the_written_bound(pkg):
+    """SDRFM_CFG_GUARD_WORST_CASE (csrc/qtaps.c sdrfm_q_guard2): R = 2 max|g| E / 5e-6 with E = (T + 4) 127.5 sum|h| 2^-24 + 64 T max|h| / (127 * 65793) — every rounding of the
+    definition's chain and of the recombination the same way, every tap's quantisation error against a full-scale byte —; the branch-cut margin does not depend on E;
+    the statistical radius is the same function with E = 1.25 sqrt(T) 127.5 sum|h| 2^-24."""
+    lib = pkg.load_library()
+    for T in (16, 32, 64):
+        h, g = pkg.default_config(T)
+        out = {}
+        for wc in (0, 1):
+            r, a = C.c_float(), C.c_float()
+            assert lib.sdrfm_q_guard2(h.ctypes.data, h.size, g.ctypes.data, g.size, wc, C.byref(r), C.byref(a)) == 0
+            out[wc] = (r.value, a.value)
+        habs, hmax, gmax = float(np.abs(h.astype(np.float64)).sum()), float(np.abs(h).max()), float(np.abs(g).max())
+        e_wc = (T + 4) * 127.5 * habs * 2.0 ** -24 + 64.0 * T * hmax / (127 * 65793)
+        e_st = 1.25 * np.sqrt(T) * 127.5 * habs * 2.0 ** -24
+        assert out[1][0] == pytest.approx(2 * gmax * e_wc / 5e-6, rel=1e-6) and out[0][0] == pytest.approx(2 * gmax * e_st / 5e-6, rel=1e-6)
+        assert out[0][1] == out[1][1] == pytest.approx(np.pi - 2 * 5e-6 / gmax, abs=1e-6)
+        assert out[0] == guard_of(pkg, h, g)                              # sdrfm_q_guard = the statistical one
+        assert out[1][0] < 0.33 * 127.5 * abs(float(h.astype(np.float64).sum()))   # a carrier at a third of full scale clears it (sdrfm_create's gate for the flag)
+    # the proven |dy| bound really bounds what the emulation sees, on the class with the largest partial sums
+    import q_emulate as qe
+    h, g = pkg.default_config(64)
+    iq = pkg.make_iq(2, 60000, mode="fm", first_id=5)
+    _, _, ymax_err = qe.design_q_audio(iq[0], h, g)
+    assert ymax_err < (64 + 4) * 127.5 * float(np.abs(h.astype(np.float64)).sum()) * 2.0 ** -24
+
+
 @pytest.mark.parametrize("name,n_bad,worst", [("q_guard_branch_cut_T64", 7, 0.7), ("q_guard_deep_fade_T32", 1, 1.1e-5)])
 def test_the_soak_cases_fail_without_the_guard_and_pass_with_it(pkg, name, n_bad, worst):
     z = np.load(os.path.join(GOLD, name + ".npz"))
