@@ -12,12 +12,17 @@
 #   <tag>_driver_command_*                the driver's exact command under the kernel tracer, its dispatches grouped by burst
 set -u
 TAG=${1:-r06}; COMMIT=${2:-unknown}
+# PLAIN_ONLY=1: only the un-profiled comparison lines (no rocprofv3 passes)
 OUT=$PWD/gpurun_out/profiles_$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
 PROF_ARGS="--steps 100 --warmup 10 --no-cpu-baseline --no-steady --no-bit-exact-leg"
 run_wl() {   # name, kernel filter, bench args...
   local WL=$1 KF=$2; shift 2
   local W=$OUT/work_$WL; mkdir -p "$W"
   local ARGS="$PROF_ARGS $*"
+  if [ -n "${PLAIN_ONLY:-}" ]; then
+    python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-bit-exact-leg ${*//--no-overlap/} > "$OUT/${TAG}_${WL}_bench.json" 2> "$W/bench_plain.err"
+    return
+  fi
   rocprofv3 --output-format csv --kernel-trace --stats -d "$W/trace" -o trace -- python3 bench.py $ARGS > "$W/bench_trace.log" 2>&1
   find "$W/trace" -name "*kernel_stats.csv" -exec cp {} "$OUT/${TAG}_${WL}_kernel_stats.csv" \;
   grep "^{\"metric\"" "$W/bench_trace.log" | tail -1 > "$OUT/${TAG}_${WL}_bench_under_rocprof.json"
@@ -31,7 +36,7 @@ run_wl() {   # name, kernel filter, bench args...
   done
   python3 tools/profile_pmc_summarize.py "$W" "$OUT" "$TAG" "$WL" "$KF" "$COMMIT"
   # the un-profiled comparison line of the same workload (its own steady series, no CPU baseline)
-  python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-bit-exact-leg $* > "$OUT/${TAG}_${WL}_bench.json" 2> "$W/bench_plain.err"
+  python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-bit-exact-leg ${*//--no-overlap/} > "$OUT/${TAG}_${WL}_bench.json" 2> "$W/bench_plain.err"   # (overlapped calls too: the API's fastest way)
 }
 WLS=${WLS:-"fm256 fm512 fm256_T16 fm256_bitexact mixed10 mixed25 wbfm spectrum fm256_overlap fm512_overlap driver"}
 for wl in $WLS; do case $wl in
