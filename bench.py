@@ -33,7 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # The HIP runtime maps a process's streams onto a small pool of hardware queues (4 by default).  With RCCL initialised in the process its streams take some of them,
 # and the library's two internal streams of the overlapped calls then share queues with the launch stream: every call waits for the one before it across queues —
-# 49 us per call instead of 23 on one GPU with world size 1 (tools/r05/dist_probe.sh, profiles/r05_q_experiments.txt item 16).  Eight queues restore it.  Set before
+# 49 us per call instead of 23 on one GPU with world size 1 (profiles/r05_q_experiments.txt item 16).  Eight queues restore it.  Set before
 # anything initialises the runtime; a caller's own setting is respected.  (INTEGRATION.md says the same to hosts that run RCCL beside the library.)
 if "WORLD_SIZE" in os.environ or "TORCHELASTIC_RUN_ID" in os.environ:   # (a rank of a distributed run; the plain N = 1 run keeps the runtime's default: 4 and 8 queues measure the same there)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
