@@ -31,27 +31,28 @@ def test_traffic_lookup_matches_kernel_and_workload_size():
 
 def test_newest_round_traffic_feeds_the_headline_kernel():
     """The default bench line (design Q, configs[2]) takes `roofline.traffic` from the newest committed counter passes of the same kernel and size
-    (round 5: re-taken at the final kernel commit — runs cut in quads, the audio taps' LDS table)."""
+    (round 6: re-taken by tools/profile_round.sh at the kernel with the angle-difference discriminator and the peeled last step)."""
     b = _bench()
-    head = json.load(open(os.path.join(ROOT, "profiles", "traffic_r05.json")))       # (re-taken at the round's last kernel commit)
+    head = json.load(open(os.path.join(ROOT, "profiles", "traffic_r06.json")))
     assert head["kernel_name"].startswith("fast-q") and "k_mfir" in head["rocprof_kernel"]
     t = b.latest_traffic(head["kernel_name"], head["algorithmic_bytes_per_launch"])
-    assert t is not None and t["file"].startswith(("traffic_r05", "r05_")) and t["hbm_bytes_per_launch"] == head["hbm_bytes_per_launch"]
+    assert t is not None and t["file"].startswith(("traffic_r06", "r06_")) and abs(t["hbm_bytes_per_launch"] / head["hbm_bytes_per_launch"] - 1.0) < 0.01
     assert 1.0 <= t["hbm_bytes_per_launch"] / head["algorithmic_bytes_per_launch"] < 1.06       # warm-up re-reads: ~2 % of the bytes
-    # the pipe figures of the kernels that are not bound by the HBM come from the same round's passes
+    # the pipe figures of the kernels that are not bound by the HBM come from the same round's passes: `valu_frac` in their bench lines
     d = b.latest_pmc_derived("wbfm-fused (k_wbfm_steps<8,10>)")
-    assert d is not None and d["file"].startswith(("r04_", "r04b_")) and 0.5 < d["valu_issue_busy_fraction"] < 0.9
-    # (round 4, second pass: the spectrum view's 1024-point kernel was rebuilt; its line names the new kernel and finds that kernel's passes)
+    assert d is not None and d["file"] == "r06_wbfm_pmc.json" and 0.5 < d["valu_issue_busy_fraction"] < 0.9
     d = b.latest_pmc_derived("k_spectrum_chain<10, 12, 2>")
-    assert d is not None and d["file"] == "r04b_spectrum_pmc.json" and 0.5 < d["valu_issue_busy_fraction"] < 0.9
+    assert d is not None and d["file"] == "r06_spectrum_pmc.json" and 0.5 < d["valu_issue_busy_fraction"] < 0.9
     t = b.latest_traffic("k_spectrum_chain<10, 12, 2>", 256 * 234 * 1024 * 2.0 + 256 * 1024 * 4.0)
     assert t is not None and 1.0 <= t["hbm_bytes_per_launch"] / t["algorithmic_bytes_per_launch"] < 1.1
+    blk = b.bound_block("valu", "wbfm-fused (k_wbfm_steps<8,10>)", 0.108, 121241600.0, None)
+    assert blk["bound"] == "valu" and blk["valu_frac"] == blk["valu_issue_busy_fraction"] and 0.6 < blk["valu_frac"] < 0.8
 
 
 def test_traffic_never_below_algorithmic_bytes():
     """A committed summary whose traffic is below the algorithmic bytes would mean a broken counter pass."""
     import glob
-    for fn in glob.glob(os.path.join(ROOT, "profiles", "r0[2345]*_pmc.json")):
+    for fn in glob.glob(os.path.join(ROOT, "profiles", "r0[23456]*_pmc.json")):
         d = json.load(open(fn))
         assert d["hbm_bytes_per_launch"] >= 0.999 * d["algorithmic_bytes_per_launch"], fn
         assert d.get("commit") and d["commit"] != "wip", fn
