@@ -152,3 +152,23 @@ def test_c_pipeline_host_overlapped_equals_serial_and_the_host_sink(pkg, tmp_pat
             want, st = pkg.pcm_deemph_s16_host(audio[k][s_], alpha, gain, st)
             # (the program uses the device sink's default form, the blocked scan: within 1 LSB of the host routine's exact chain)
             assert np.abs(outs["overlapped"][k, s_].astype(np.int32) - want.astype(np.int32)).max() <= 1, (s_, k)
+
+
+def test_c_consumer_loop_host_runs_all_three_forms(pkg):
+    """examples/consumer_loop_main.c: the consumer loop of INTEGRATION.md section 3 from a plain-C host — overlapped calls alone, the device PCM sink on the handle's
+    stream behind sdrfm_flush_previous, and the sink on its own stream behind sdrfm_wait_previous with the audio buffers guarded on the host.  A short run of each
+    form completes and reports sane figures (the timings themselves are profiles/r06_sink.txt's business)."""
+    import json
+    exe = os.path.join(ROOT, "examples", "consumer_loop_main")
+    if not os.path.exists(exe):
+        import __graft_entry__ as g
+        g.build()
+    if not os.path.exists(exe):
+        pytest.skip("examples/consumer_loop_main did not build on this box")
+    r = subprocess.run([exe, "256", "2", "40", "4"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    info = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert info["kernel"].startswith("fast-q") and "overlapped" in info["kernel"], info
+    for form in ("calls", "simple", "fast"):
+        us = info[form]["us_per_call_regions"]
+        assert len(us) == 2 and all(5.0 < x < 5000.0 for x in us), (form, us)

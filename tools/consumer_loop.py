@@ -35,14 +35,15 @@ def region(dm, n, per_call, sink=None):
     e1.record(st)
     e1.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
+ONLY_FAST = bool(os.environ.get("LOOP_ONLY_FAST"))            # (for a kernel trace of the fast form alone)
 with pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=ns, max_bytes_per_call=2 * nsamp)) as dm:
     dm.set_stream(st.cuda_stream)
-    for per_call in (False, True, False, True):
+    for per_call in (() if ONLY_FAST else (False, True, False, True)):
         time.sleep(0.3)
         r = [region(dm, 300, per_call) for _ in range(10)]
-        print("flush_previous after every call: %-5s  us per call, ten regions of 300: %s   steady (median of the last five) %.2f" % (per_call, " ".join("%.2f" % x for x in r), float(np.median(r[5:]))))
+        print("flush_previous after every call: %-5s  us per call, ten regions of 300: %s   steady (median of the last five) %.2f" % (per_call, " ".join("%.2f" % x for x in r), float(np.median(r[len(r) // 2:]))))
     print("GPU_MAX_HW_QUEUES =", os.environ.get("GPU_MAX_HW_QUEUES", "(default: 4)"))
-    for exact in ((False,) if len(sys.argv) > 2 else (False, True, False)):
+    for exact in (() if ONLY_FAST else (False,) if len(sys.argv) > 2 else (False, True, False)):
         with pkg.PcmSink(ns, alpha, gain, exact=exact) as sink:
             sink.set_stream(st.cuda_stream)
             time.sleep(0.3)
@@ -82,5 +83,5 @@ with pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=ns, max_by
                 e1.synchronize()
                 return e0.elapsed_time(e1) / n * 1e3
             time.sleep(0.3)
-            r = [region3(300) for _ in range(10)]
-            print("fast form (%d audio buffers, the sink on its own stream, the host at most that many calls ahead): us per call" % NA + ", ten regions of 300: %s   steady %.2f" % (" ".join("%.2f" % x for x in r), float(np.median(r[5:]))))
+            r = [region3(300) for _ in range(3 if ONLY_FAST else 10)]
+            print("fast form (%d audio buffers, the sink on its own stream, the host at most that many calls ahead): us per call" % NA + ", ten regions of 300: %s   steady %.2f" % (" ".join("%.2f" % x for x in r), float(np.median(r[len(r) // 2:]))))
