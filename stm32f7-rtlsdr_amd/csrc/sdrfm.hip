@@ -996,8 +996,7 @@ struct sdrfm {
   // almost every audio stage (3 x the time of a carrier's call; the bit-exact kernels: 1.4 x), and a kernel lasts as long as its slowest
   // wave — so the choice is made PER STREAM (round 5; rounds 3 - 4: per handle).  Design Q's waves add their repair passes into a word per
   // stream (device memory); a window of SDRFM_Q_ADAPT_WINDOW design-Q calls is read back on a side stream behind the completion events of
-  // the window's last kernels (hipExtLaunchKernelGGL stop events: no marker packets in the compute queues, no host wait anywhere: a
-  // finished read-back is noticed by hipEventQuery at a later call).  A stream more than a quarter of whose audio stages needed a repair
+  // the window's last kernels (hipExtLaunchKernelGGL stop events: no marker packets in the compute queues).  A stream more than a quarter of whose audio stages needed a repair
   // pass is served by the bit-exact kernels for SDRFM_Q_ADAPT_BACKOFF calls (design-B workgroups over the list of such streams INSIDE design
   // Q's launch over the others — sdrfm_q.hip: k_mix — or, where design B has no instance, a launch ahead of it), then tried on design Q again.
   // DETERMINISTIC since round 6: a window's statistics take effect at a FIXED call — the first design-Q call of the window
