@@ -104,7 +104,8 @@ enum {
                                      caller is less than 48 calls ahead of it ("fast-q" handles: the per-stream statistics of a window of 16
                                      calls are read back on a side stream and take effect at a fixed call three windows after the window
                                      closed — a caller further ahead than that waits there for the read-back, which is what makes the kernel
-                                     assignment a function of the bytes and the calls and not of timing;
+                                     assignment a function of the bytes and the calls and not of timing (so a caller whose stream is held back by
+                                     work it has not issued yet must not run that far ahead of it);
                                      tests/test_route_gpu.py test_calls_return_without_waiting_for_the_device).  The handle's own stream is
                                      created non-blocking: it does NOT order itself against the null stream or any
                                      other stream, so work that produces iq or touches audio elsewhere must be
