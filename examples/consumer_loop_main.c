@@ -7,6 +7,8 @@
  *   simple    two audio buffers, sdrfm_flush_previous + the sink on the HANDLE'S stream after every call
  *   fast      NA audio buffers, the sink on a stream OF ITS OWN behind sdrfm_wait_previous, the reuse of an audio buffer guarded by hipEventQuery on the host
  *             (the host then stays at most NA calls ahead of the device: NA = 3 keeps the queues nearly empty, NA = 6 keeps them fed)
+ *   fused     sdrfm_process_batch_pcm: overlapped calls whose launch ends with the sink's chain (csrc/sdrfm_sink_tail.h) — no second launch, no stream to
+ *             order; NA audio and PCM buffers in turn, one sdrfm_flush per region
  *
  *   consumer_loop_main [n_streams=256] [regions=10] [calls_per_region=300] [NA=6]
  * Prints one JSON line: us per call of every region and the median of the later half, per form.  Measurement only: nothing is checked against the oracle here
@@ -91,14 +93,14 @@ int main(int argc, char** argv) {
   SDRC(sdrfm_set_stream(fm, st));
   unsigned char* d_iq[NBUF];
   float* d_audio[8];
-  short* d_pcm[2];
+  short* d_pcm[8];
   for (int b = 0; b < NBUF; ++b) {
     HIPC(hipMalloc((void**)&d_iq[b], (size_t)ns * nbytes));
     for (uint32_t s = 0; s < ns; ++s)
       HIPC(hipMemcpy(d_iq[b] + (size_t)s * nbytes, rows + ((size_t)(s % 8) * total + (size_t)b * nsamp) * 2, nbytes, hipMemcpyHostToDevice));
   }
   for (int i = 0; i < NA; ++i) HIPC(hipMalloc((void**)&d_audio[i], (size_t)ns * astride * sizeof(float)));
-  for (int i = 0; i < 2; ++i) HIPC(hipMalloc((void**)&d_pcm[i], (size_t)ns * 2 * astride * sizeof(short)));
+  for (int i = 0; i < NA; ++i) HIPC(hipMalloc((void**)&d_pcm[i], (size_t)ns * 2 * astride * sizeof(short)));
   hipEvent_t e0, e1, consumed[8];
   HIPC(hipEventCreate(&e0)); HIPC(hipEventCreate(&e1));
   for (int i = 0; i < NA; ++i) HIPC(hipEventCreateWithFlags(&consumed[i], hipEventDisableTiming));
@@ -107,15 +109,20 @@ int main(int argc, char** argv) {
   long call = 0;                                              /* calls made so far (the capture buffers and the audio buffers go round across regions) */
 
   printf("{\"n_streams\":%u,\"calls_per_region\":%d,\"fast_form_audio_buffers\":%d", ns, per, NA);
-  const char* names[3] = {"calls", "simple", "fast"};
-  for (int form = 0; form < 3; ++form) {
+  const char* names[4] = {"calls", "simple", "fast", "fused"};
+  char fused_kernel[128] = "";
+  for (int form = 0; form < 4; ++form) {
     SDRC(sdrfm_pcm_sink_set_stream(sink, form == 2 ? sst : st));
     int have[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     double* us = (double*)malloc(sizeof(double) * (size_t)regions);
     for (int r = 0; r < regions; ++r) {
       HIPC(hipEventRecord(e0, st));
       for (int k = 0; k < per; ++k, ++call) {
-        const int nab = form == 2 ? NA : 2, ab = (int)(call % nab), pab = (int)((call + nab - 1) % nab);
+        const int nab = form >= 2 ? NA : 2, ab = (int)(call % nab), pab = (int)((call + nab - 1) % nab);
+        if (form == 3) {
+          SDRC(sdrfm_process_batch_pcm(fm, sink, d_iq[call % NBUF], nbytes, nbytes, d_audio[ab], astride, d_pcm[ab], 2 * astride, &n, F));
+          continue;
+        }
         if (form == 2 && have[ab]) while (hipEventQuery(consumed[ab]) != hipSuccess) { }    /* audio[ab] is free once its consumer (of call - NA) is done */
         SDRC(sdrfm_process_batch(fm, d_iq[call % NBUF], nbytes, nbytes, d_audio[ab], astride, &n, F));
         if (form == 0 || k == 0) continue;
@@ -144,16 +151,17 @@ int main(int argc, char** argv) {
     qsort(tail, (size_t)nt, sizeof(double), cmp_d);
     printf("],\"steady_us_per_call\":%.2f}", nt ? tail[nt / 2] : 0.0);
     free(us);
+    if (form == 3) snprintf(fused_kernel, sizeof fused_kernel, "%s", sdrfm_kernel_name(fm));
     SDRC(sdrfm_synchronize(fm));
     HIPC(hipStreamSynchronize(sst));
   }
-  printf(",\"kernel\":\"%s\"}\n", sdrfm_kernel_name(fm));
+  printf(",\"kernel\":\"%s\"}\n", fused_kernel);
 
   sdrfm_pcm_sink_destroy(sink);
   sdrfm_destroy(fm);
   for (int b = 0; b < NBUF; ++b) HIPC(hipFree(d_iq[b]));
   for (int i = 0; i < NA; ++i) HIPC(hipFree(d_audio[i]));
-  for (int i = 0; i < 2; ++i) HIPC(hipFree(d_pcm[i]));
+  for (int i = 0; i < NA; ++i) HIPC(hipFree(d_pcm[i]));
   free(rows);
   return 0;
 }

@@ -1021,6 +1021,8 @@ struct sdrfm {
   // records ovl_done[k] behind the calls put on internal stream k and makes the handle's stream wait for it.
   hipStream_t ovl_stream[2];
   hipEvent_t ovl_in, ovl_done[2];
+  // sdrfm_process_batch_pcm: the sink whose chain the call's design-Q launch ends with (sdrfm_sink_tail.h); pcm_fused: that launch took it
+  sdrfm_pcm_sink* pcm_sink; int16_t* pcm_out; size_t pcm_out_stride; bool pcm_fused;
   bool ovl_pending[2], ovl_bound[2], ovl_join_style;   // (bound: the latest kernel of stream k carries ovl_done[k] as its stop event; join_style: the caller joins after every call)
   uint32_t ovl_next;
   // the previous call's device buffer (valid after a SDRFM_F_DEVICE_PTRS call): what an overlapped call warms its streams up from
@@ -1903,7 +1905,18 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
     // 100-call burst, +3 % per call; un-profiled within the noise): profiles/r05_q_experiments.txt item 15.
     const bool carry = ovl && h->ovl_join_style;
     if (carry) { done = h->ovl_done[k]; if (h->rt_win_used[k]) h->rt_win_need[k] = false; }
+    // sdrfm_process_batch_pcm: the sink's chain as the launch's tail — when this launch computes every stream's whole audio row (no routed stream, no
+    // outputs the generic kernel recomputes behind it at the start of a stream) and the shape's kernel has the tail; any other call is followed by the sink's own kernel
+    SdrfmSinkTail tail;
+    const bool with_tail = h->pcm_sink && !mixed && !(h->n_seen + 1 < c.fir_taps) && runs < 65536u && sdrfm_q_has_pcm_tail(h->q_c0, h->q_nslot, c.fir_decim, c.audio_decim) &&
+                           sdrfm_sink_tail_params(h->pcm_sink, h->device, ns_all, &tail);
     if (fuse && pb_blocks) HIP_TRY(sdrfm_q_launch_mix(q, h->q_c0, h->q_nslot, c.fir_decim, c.audio_decim, pb, pb_blocks, pb_R, qs, done), SDRFM_FAIL);
+    else if (with_tail) {
+      tail.pcm = h->pcm_out; tail.pcm_stride = h->pcm_out_stride;
+      HIP_TRY(sdrfm_q_launch_pcm(q, tail, h->q_c0, h->q_nslot, c.fir_decim, c.audio_decim, qs, done), SDRFM_FAIL);
+      sdrfm_sink_tail_issued(h->pcm_sink);
+      h->pcm_fused = true;
+    }
     else HIP_TRY(sdrfm_q_launch(q, h->q_c0, h->q_nslot, c.fir_decim, c.audio_decim, qs, done), SDRFM_FAIL);
     if (ovl) { h->ovl_pending[k] = true; h->ovl_bound[k] = carry; }
     h->prev_ovl_audio = ovl ? d_audio : nullptr; h->prev_ovl_audio_stride = audio_stride; h->prev_ovl_audio_n = A;
@@ -1930,7 +1943,7 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
         h->rt_set = (h->rt_set + 1u) % SDRFM_Q_ADAPT_SETS; h->rt_win_calls = 0; h->rt_win_stages = 0;
       }
     }
-    snprintf(q_name, sizeof(q_name), "%s%s", h->fast_q_name, ovl ? " overlapped" : "");
+    snprintf(q_name, sizeof(q_name), "%s%s%s", h->fast_q_name, ovl ? " overlapped" : "", h->pcm_fused ? " + pcm tail" : "");
   }
   if (mixed) {
     const char* sp = strchr(bx_name, ' ');                         // ("fast-b", "fast-s", "generic": the name's first word)
@@ -2005,6 +2018,30 @@ int sdrfm_process_batch(sdrfm_t* h, const uint8_t* iq, size_t iq_stride, uint32_
             SDRFM_FAIL);
   HIP_TRY(hipStreamSynchronize(h->stream), SDRFM_FAIL);
   return SDRFM_OK;
+}
+
+/* One call of the demodulator AND of the PCM sink (include/sdrfm.h).  Where design Q serves the whole call its launch ends with the sink's chain
+ * (sdrfm_sink_tail.h: no second launch, no queue to wait on); any other call — bit-exact kernels, routed streams, the first call of a stream — is followed
+ * by the sink's stand-alone kernel on the handle's stream behind the call. */
+int sdrfm_process_batch_pcm(sdrfm_t* h, sdrfm_pcm_sink_t* sink, const uint8_t* iq, size_t iq_stride, uint32_t nbytes, float* audio, size_t audio_stride,
+                            int16_t* pcm, size_t pcm_stride, uint32_t* n_audio, uint32_t flags) {
+  if (!h || !sink || !n_audio) return SDRFM_EINVAL;
+  if (!(flags & SDRFM_F_DEVICE_PTRS) || (flags & ~(SDRFM_F_DEVICE_PTRS | SDRFM_F_OVERLAP))) return SDRFM_EINVAL;
+  if (nbytes & 1u) return SDRFM_EODD;
+  if (nbytes == 0) { *n_audio = 0; return SDRFM_OK; }
+  uint32_t A = 0;
+  (void)sdrfm_audio_count(h, nbytes, &A);
+  if (A && (!pcm || ((uintptr_t)pcm & 3u) || (pcm_stride & 1u))) return SDRFM_EINVAL;
+  if (h->cfg.n_streams > 1 && pcm_stride < 2 * (size_t)A) return SDRFM_ECAPACITY;
+  SdrfmSinkTail probe;
+  if (!sdrfm_sink_tail_params(sink, h->device, h->cfg.n_streams, &probe)) return SDRFM_EINVAL;   // (a sink of this device and this many streams)
+  h->pcm_sink = sink; h->pcm_out = pcm; h->pcm_out_stride = pcm_stride; h->pcm_fused = false;
+  const int rc = sdrfm_process_batch(h, iq, iq_stride, nbytes, audio, audio_stride, n_audio, flags);
+  const bool fused = h->pcm_fused;
+  h->pcm_sink = nullptr; h->pcm_fused = false;
+  if (rc != SDRFM_OK || fused || *n_audio == 0) return rc;
+  { const int jrc = join_overlap(h); if (jrc != SDRFM_OK) return jrc; }
+  return sdrfm_sink_launch_on(sink, audio, audio_stride, *n_audio, pcm, pcm_stride, h->stream);
 }
 
 int sdrfm_process(sdrfm_t* h, const uint8_t* iq, uint32_t nbytes, float* audio, uint32_t audio_cap, uint32_t* n_audio) {

@@ -180,7 +180,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // The body of one workgroup (one wave): `bid` is its index among the launch's design-Q workgroups (the kernel's bid, or — in k_mix
 // below — its index among the workgroups that run this body).
-template <int C0, int NSLOT, int D, int DA>
+// WT (the launch with the PCM tail): the audio is stored THROUGH the L2 (device-scope stores: sc1), because the stream's last wave — on whatever XCD — reads
+// the whole row back; a release fence instead would be an L2 write-back per wave (buffer_wbl2: measured 340 us per call with 3072 waves).
+template <int C0, int NSLOT, int D, int DA, bool WT = false>
 __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t bid) {
   using G = QGeo<D, DA>;
   [[maybe_unused]] constexpr int NCH = G::NCH;
@@ -518,9 +520,16 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
     for (int e = lo - ((lo + par) & 1) + 2 * ln_; e < hi_; e += 128) {
       const bool v0 = e >= lo, v1 = e + 1 < hi_;
       const float a0 = v0 ? ab[e - jfl] : 0.0f, a1 = v1 ? ab[e + 1 - jfl] : 0.0f;
-      if (v0 && v1) *reinterpret_cast<qf2_t*>(row + e) = qf2_t{a0, a1};
-      else if (v0) row[e] = a0;
-      else if (v1) row[e + 1] = a1;
+      if constexpr (WT) {
+        const unsigned u0 = __builtin_bit_cast(unsigned, a0), u1 = __builtin_bit_cast(unsigned, a1);
+        if (v0 && v1) __hip_atomic_store(reinterpret_cast<unsigned long long*>(row + e), (unsigned long long)u0 | ((unsigned long long)u1 << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (v0) __hip_atomic_store(reinterpret_cast<unsigned*>(row + e), u0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (v1) __hip_atomic_store(reinterpret_cast<unsigned*>(row + e + 1), u1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        if (v0 && v1) *reinterpret_cast<qf2_t*>(row + e) = qf2_t{a0, a1};
+        else if (v0) row[e] = a0;
+        else if (v1) row[e + 1] = a1;
+      }
     }
     jfl += 128 * npend;
     npend = 0;
@@ -930,6 +939,35 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16
   mfir_body<C0, NSLOT, D, DA>(p, blockIdx.x);
 }
 
+// The same launch with the PCM sink's chain as its tail (round 6, sdrfm_sink_tail.h): every wave counts itself done behind its audio stores, the stream's last
+// wave walks the stream's row through the de-emphasis chain.  A kernel of its own, so that the instruction stream of k_mfir does not change by a byte.
+template <int D, int DA, int NSLOT>
+constexpr uint32_t q_lds() { return (uint32_t)(QGeo<D, DA>::PRE + 1024 * NSLOT + 4 * (QGeo<D, DA>::DBW + ABW + FLW + GTW)); }
+struct QPcmArgs { SdrfmQParams p; SdrfmSinkTail t; };
+template <int C0, int NSLOT, int D, int DA>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16 ? 3 : 4))) k_mfir_pcm(QPcmArgs a) {
+  // A stream's workgroups on ONE XCD (workgroups go round the eight XCDs in turn: XCD x takes the grid's x-th eighth), so that its audio row is written and read
+  // back within one L2 (sdrfm_sink_tail.h; the tail checks where the waves really ran and pays an invalidation when this does not hold)
+  const uint32_t G = gridDim.x, bid = (G & 7u) ? blockIdx.x : (blockIdx.x & 7u) * (G >> 3) + (blockIdx.x >> 3);
+  mfir_body<C0, NSLOT, D, DA, true>(a.p, bid);                  // (a run that owns nothing returns at once: it still counts)
+  // what the tail needs is read from the argument segment HERE, through an opaque pointer (as the body's rare branches do): kept in scalar registers across
+  // the step loop it would be spilled there
+  typedef const __attribute__((address_space(4))) QPcmArgs* ArgPtr;
+  ArgPtr ap = (ArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(ap));
+  SdrfmSinkTail t;
+  t.pcm = ap->t.pcm; t.pcm_stride = ap->t.pcm_stride; t.state = ap->t.state; t.gen = ap->t.gen; t.cnt = ap->t.cnt; t.call = ap->t.call; t.n_streams = ap->t.n_streams;
+  t.alpha = ap->t.alpha; t.gain = ap->t.gain; t.pc = ap->t.pc;
+  const uint32_t runs = ap->p.runs;
+  uint32_t G2 = gridDim.x, b2 = blockIdx.x;
+  asm volatile("" : "+s"(G2), "+s"(b2));
+  const uint32_t si = ((G2 & 7u) ? b2 : (b2 & 7u) * (G2 >> 3) + (b2 >> 3)) / runs;
+  const uint32_t* const sl = ap->p.slist;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  static_assert(q_lds<D, DA, NSLOT>() >= SDRFM_TAIL_LDS, "the tail stages its segments in the wave's LDS");
+  sdrfm_sink_tail(t, ap->p.audio, ap->p.audio_stride, ap->p.A_out, sl ? sl[si] : si, runs, reinterpret_cast<float*>(smem));
+}
+
 // =================================================================================================================
 //  One launch for a mixed batch (round 5, DESIGN.md 4.Q "Routing"): the first `nb` one-wave workgroups run design B (sdrfm_b.h: the bit-exact
 //  kernel with the smallest tile, R = 4) over the noise-only streams of b.slist, the others design Q over the streams of q.slist.  Two launches
@@ -990,11 +1028,11 @@ __global__ void __launch_bounds__(64) k_q_read_stream(const uint8_t* base, unsig
 }
 
 typedef void (*QKernel)(SdrfmQParams);
-struct QVariant { uint32_t c0, nslot, d, da, lds; QKernel k; const char* name; };
-template <int D, int DA, int NSLOT>
-constexpr uint32_t q_lds() { return (uint32_t)(QGeo<D, DA>::PRE + 1024 * NSLOT + 4 * (QGeo<D, DA>::DBW + ABW + FLW + GTW)); }
-#define QV(C0_, NS_) { C0_, NS_, 10, 5, q_lds<10, 5, NS_>(), k_mfir<C0_, NS_, 10, 5>, "k_mfir<" #C0_ "," #NS_ ">" }
-#define QVD(C0_, NS_, D_, DA_) { C0_, NS_, D_, DA_, q_lds<D_, DA_, NS_>(), k_mfir<C0_, NS_, D_, DA_>, "k_mfir<" #C0_ "," #NS_ "," #D_ "," #DA_ ">" }
+typedef void (*QPcmKernel)(QPcmArgs);
+struct QVariant { uint32_t c0, nslot, d, da, lds; QKernel k; const char* name; QPcmKernel kp; };
+// (the kernel with the PCM tail: for the ring sizes the library launches — sdrfm_q_default_nslot —, not for the experiments' 10 and 15)
+#define QV(C0_, NS_) { C0_, NS_, 10, 5, q_lds<10, 5, NS_>(), k_mfir<C0_, NS_, 10, 5>, "k_mfir<" #C0_ "," #NS_ ">", NS_ == 5 ? k_mfir_pcm<C0_, 5, 10, 5> : nullptr }
+#define QVD(C0_, NS_, D_, DA_) { C0_, NS_, D_, DA_, q_lds<D_, DA_, NS_>(), k_mfir<C0_, NS_, D_, DA_>, "k_mfir<" #C0_ "," #NS_ "," #D_ "," #DA_ ">", k_mfir_pcm<C0_, NS_, D_, DA_> }
 // D = 10 / DA = 5: the 2.4 MS/s front end of BASELINE (ring of 5 KiB; 10 and 15 for experiments).  D = 8 / DA = 8: 2.048 MS/s -> 256 kS/s ->
 // 32 kHz (ring of two 2-KiB steps).  D = 16 / DA = 5: 3.2 MS/s -> 200 kS/s -> 40 kHz (ring of two 4-KiB steps).
 const QVariant kQVariants[] = {QV(0, 5), QV(0, 10), QV(0, 15), QV(1, 5), QV(1, 10), QV(1, 15), QVD(0, 4, 8, 8), QVD(1, 4, 8, 8), QVD(0, 8, 16, 5), QVD(1, 8, 16, 5)};
@@ -1078,6 +1116,21 @@ hipError_t sdrfm_q_launch(const SdrfmQParams& p, uint32_t first_chunk, uint32_t 
   if (!v) return hipErrorInvalidValue;
   if (done) hipExtLaunchKernelGGL(v->k, dim3(p.n_streams * p.runs), dim3(64), v->lds, stream, nullptr, done, 0, p);
   else hipLaunchKernelGGL(v->k, dim3(p.n_streams * p.runs), dim3(64), v->lds, stream, p);
+  return hipGetLastError();
+}
+
+bool sdrfm_q_has_pcm_tail(uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da) {
+  const QVariant* v = q_find(first_chunk, nslot, d, da);
+  return v && v->kp;
+}
+
+hipError_t sdrfm_q_launch_pcm(const SdrfmQParams& p, const SdrfmSinkTail& t, uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da, hipStream_t stream,
+                              hipEvent_t done) {
+  const QVariant* v = q_find(first_chunk, nslot, d, da);
+  if (!v || !v->kp) return hipErrorInvalidValue;
+  const QPcmArgs a = {p, t};
+  if (done) hipExtLaunchKernelGGL(v->kp, dim3(p.n_streams * p.runs), dim3(64), v->lds, stream, nullptr, done, 0, a);
+  else hipLaunchKernelGGL(v->kp, dim3(p.n_streams * p.runs), dim3(64), v->lds, stream, a);
   return hipGetLastError();
 }
 

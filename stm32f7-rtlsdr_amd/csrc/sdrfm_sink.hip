@@ -40,6 +40,7 @@
 #include <new>
 
 #include "../../include/sdrfm.h"
+#include "sdrfm_sink_tail.h"
 
 namespace {
 
@@ -49,6 +50,8 @@ struct SinkParams {
   int16_t* pcm;
   size_t pcm_stride;     // int16 elements per stream (>= 2 * n)
   float* state;          // [n_streams] y[n-1]
+  uint32_t* gen;         // [n_streams] calls applied to the stream (sdrfm_sink_tail.h: the tail of a demodulator launch waits on it)
+  uint32_t gen_next;     // its value behind this call
   uint32_t n_streams, n;
   float alpha, gain;
 };
@@ -83,7 +86,7 @@ __global__ void __launch_bounds__(64) k_pcm_sink(SinkParams p) {
         reinterpret_cast<unsigned*>(p.pcm + (size_t)(s0 + r) * p.pcm_stride)[t0 + lane] = tile[r * 65 + lane];
     __syncthreads();
   }
-  if (lane < rows) p.state[mine] = y;
+  if (lane < rows) { p.state[mine] = y; p.gen[mine] = p.gen_next; }
 }
 
 // ---- the blocked scan (the default): one workgroup of 256 lanes per stream; segments of SINK_NT * SINK_C samples through LDS ------------------------------
@@ -153,7 +156,7 @@ __global__ void __launch_bounds__(256) k_pcm_sink_scan(SinkParams p, float pc) {
     }
     __syncthreads();
   }
-  if (t == 0) p.state[s] = y0;
+  if (t == 0) { p.state[s] = y0; p.gen[s] = p.gen_next; }
 }
 
 }  // namespace
@@ -164,6 +167,8 @@ struct sdrfm_pcm_sink {
   int device;
   hipStream_t own_stream, stream;
   float* d_state;
+  uint32_t* d_gen;     // [n_streams] calls applied to the stream; behind it the tail's "waves done" counters (sdrfm_sink_tail.h; sink_gen_bytes)
+  uint32_t calls;      // calls issued so far (mod 2^32): what d_gen holds when every one of them is through
   float* d_audio;      // staging for host-pointer calls
   int16_t* d_pcm;
   uint32_t cap;        // samples per stream the staging holds
@@ -178,14 +183,44 @@ struct sdrfm_pcm_sink {
     }                                                                                                          \
   } while (0)
 
+// gen[n_streams] (padded to 8 bytes), then SDRFM_TAIL_SETS x n_streams 64-bit counters
+static size_t sink_gen_bytes(uint32_t n_streams) { return sizeof(uint32_t) * (size_t)((n_streams + 1u) & ~1u) + 8u * SDRFM_TAIL_SETS * (size_t)n_streams; }
+
 static void sink_free(sdrfm_pcm_sink* k) {
   if (!k) return;
   (void)hipSetDevice(k->device);
   if (k->d_state) (void)hipFree(k->d_state);
+  if (k->d_gen) (void)hipFree(k->d_gen);
   if (k->d_audio) (void)hipFree(k->d_audio);
   if (k->d_pcm) (void)hipFree(k->d_pcm);
   if (k->own_stream) (void)hipStreamDestroy(k->own_stream);
   delete k;
+}
+
+// ---- the sink as the tail of a demodulator launch (sdrfm_sink_tail.h) ---------------------------------------------------------------------------------------
+bool sdrfm_sink_tail_params(sdrfm_pcm_sink* k, int device, uint32_t n_streams, SdrfmSinkTail* out) {
+  if (!k || !out || k->device != device || k->n_streams != n_streams) return false;
+  out->pcm = nullptr; out->pcm_stride = 0;
+  out->state = k->d_state; out->gen = k->d_gen; out->cnt = k->d_gen + ((n_streams + 1u) & ~1u);
+  out->call = k->calls; out->n_streams = n_streams;
+  out->alpha = k->alpha; out->gain = k->gain;
+  out->pc = (float)pow(1.0 - (double)k->alpha, (double)SDRFM_TAIL_C);
+  return true;
+}
+
+void sdrfm_sink_tail_issued(sdrfm_pcm_sink* k) { ++k->calls; }
+
+int sdrfm_sink_launch_on(sdrfm_pcm_sink* k, const float* audio, size_t audio_stride, uint32_t n, int16_t* pcm, size_t pcm_stride, hipStream_t stream) {
+  if (!k) return SDRFM_EINVAL;
+  if (n == 0) return SDRFM_OK;
+  SinkParams p;
+  p.state = k->d_state; p.n_streams = k->n_streams; p.n = n; p.alpha = k->alpha; p.gain = k->gain;
+  p.gen = k->d_gen; p.gen_next = k->calls + 1u;
+  p.audio = audio; p.audio_stride = audio_stride; p.pcm = pcm; p.pcm_stride = pcm_stride;
+  hipLaunchKernelGGL(k_pcm_sink_scan, dim3(k->n_streams), dim3(SINK_NT), 0, stream, p, (float)pow(1.0 - (double)k->alpha, (double)SINK_C));
+  STRY(hipGetLastError(), SDRFM_FAIL);
+  ++k->calls;
+  return SDRFM_OK;
 }
 
 extern "C" {
@@ -204,7 +239,8 @@ int sdrfm_pcm_sink_create(uint32_t n_streams, float alpha, float gain, int32_t d
   memset(static_cast<void*>(k), 0, sizeof(*k));
   k->n_streams = n_streams; k->alpha = alpha; k->gain = gain; k->device = device;
   if (hipStreamCreateWithFlags(&k->own_stream, hipStreamNonBlocking) != hipSuccess ||
-      hipMalloc(&k->d_state, sizeof(float) * n_streams) != hipSuccess) { sink_free(k); return SDRFM_ENOMEM; }
+      hipMalloc(&k->d_state, sizeof(float) * n_streams) != hipSuccess ||
+      hipMalloc(&k->d_gen, sink_gen_bytes(n_streams)) != hipSuccess) { sink_free(k); return SDRFM_ENOMEM; }
   k->stream = k->own_stream;
   const int rc = sdrfm_pcm_sink_reset(k);
   if (rc != SDRFM_OK) { sink_free(k); return rc; }
@@ -223,7 +259,9 @@ int sdrfm_pcm_sink_reset(sdrfm_pcm_sink_t* k) {
   if (!k) return SDRFM_EINVAL;
   STRY(hipSetDevice(k->device), SDRFM_FAIL);
   STRY(hipMemsetAsync(k->d_state, 0, sizeof(float) * k->n_streams, k->stream), SDRFM_FAIL);
+  STRY(hipMemsetAsync(k->d_gen, 0, sink_gen_bytes(k->n_streams), k->stream), SDRFM_FAIL);
   STRY(hipStreamSynchronize(k->stream), SDRFM_FAIL);
+  k->calls = 0;
   return SDRFM_OK;
 }
 
@@ -253,6 +291,7 @@ int sdrfm_pcm_sink_process_batch(sdrfm_pcm_sink_t* k, const float* audio, size_t
   STRY(hipSetDevice(k->device), SDRFM_FAIL);
   SinkParams p;
   p.state = k->d_state; p.n_streams = k->n_streams; p.n = n; p.alpha = k->alpha; p.gain = k->gain;
+  p.gen = k->d_gen; p.gen_next = k->calls + 1u;
   const dim3 grid((k->n_streams + 63) / 64);
   const float pc = (float)pow(1.0 - (double)k->alpha, (double)SINK_C);   // the blocked scan's carry factor: (1 - alpha)^(samples per chunk)
   const bool exact = (flags & SDRFM_PCM_F_EXACT) != 0;
@@ -265,6 +304,7 @@ int sdrfm_pcm_sink_process_batch(sdrfm_pcm_sink_t* k, const float* audio, size_t
     p.audio = audio; p.audio_stride = audio_stride; p.pcm = pcm; p.pcm_stride = pcm_stride;
     launch();
     STRY(hipGetLastError(), SDRFM_FAIL);
+    ++k->calls;
     return SDRFM_OK;
   }
   // host buffers: stage, run, copy back, synchronous
@@ -283,6 +323,7 @@ int sdrfm_pcm_sink_process_batch(sdrfm_pcm_sink_t* k, const float* audio, size_t
   p.audio = k->d_audio; p.audio_stride = k->cap; p.pcm = k->d_pcm; p.pcm_stride = 2 * (size_t)k->cap;
   launch();
   STRY(hipGetLastError(), SDRFM_FAIL);
+  ++k->calls;
   STRY(hipMemcpy2DAsync(pcm, sizeof(int16_t) * ps, k->d_pcm, sizeof(int16_t) * 2 * k->cap, sizeof(int16_t) * 2 * n, k->n_streams,
                         hipMemcpyDeviceToHost, k->stream), SDRFM_FAIL);
   STRY(hipStreamSynchronize(k->stream), SDRFM_FAIL);

@@ -15,7 +15,7 @@ F_OVERLAP = 2
 # every symbol include/sdrfm.h declares
 ABI_SYMBOLS = [
     "sdrfm_create", "sdrfm_destroy", "sdrfm_reset", "sdrfm_audio_count", "sdrfm_process", "sdrfm_process_batch",
-    "sdrfm_set_stream", "sdrfm_synchronize", "sdrfm_flush", "sdrfm_flush_previous", "sdrfm_wait_previous", "sdrfm_kernel_name", "sdrfm_abi_version", "sdrfm_strerror",
+    "sdrfm_set_stream", "sdrfm_synchronize", "sdrfm_flush", "sdrfm_flush_previous", "sdrfm_wait_previous", "sdrfm_process_batch_pcm", "sdrfm_kernel_name", "sdrfm_abi_version", "sdrfm_strerror",
     "sdrfm_wbfm_create", "sdrfm_wbfm_destroy", "sdrfm_wbfm_reset", "sdrfm_wbfm_audio_count", "sdrfm_wbfm_process_batch",
     "sdrfm_wbfm_set_stream", "sdrfm_wbfm_synchronize", "sdrfm_wbfm_kernel_name", "sdrfm_rtl_pack_fir", "sdrfm_rtl_resampler", "sdrfm_e4k_pll_params",
     "sdrfm_shard_range",
@@ -112,6 +112,8 @@ def load_library(dev=False):
     lib.sdrfm_flush_previous.restype = C.c_int
     lib.sdrfm_wait_previous.argtypes = [vp, vp]
     lib.sdrfm_wait_previous.restype = C.c_int
+    lib.sdrfm_process_batch_pcm.argtypes = [vp, vp, vp, C.c_size_t, C.c_uint32, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_uint32), C.c_uint32]
+    lib.sdrfm_process_batch_pcm.restype = C.c_int
     lib.sdrfm_kernel_name.argtypes = [vp]
     lib.sdrfm_kernel_name.restype = C.c_char_p
     lib.sdrfm_abi_version.argtypes = []

@@ -215,3 +215,141 @@ def test_consumer_on_its_own_stream_behind_wait_previous(pkg):
         for k in range(nb):
             want, st = pkg.pcm_deemph_s16_host(ref_audio[k][s], alpha, gain, st)
             assert np.abs(got[k][s].astype(np.int32) - want.astype(np.int32)).max() <= 1, (s, k)
+
+
+# ---- the sink's chain as the TAIL of the demodulator's launch (sdrfm_process_batch_pcm, csrc/sdrfm_sink_tail.h) ---------------------------------------------
+def _host_chain(pkg, auds, alpha, gain, s):
+    """PCM of stream s over the calls' audio, by the host routine carrying its state from call to call."""
+    st, out = 0.0, []
+    for a in auds:
+        want, st = pkg.pcm_deemph_s16_host(a[s], alpha, gain, st)
+        out.append(want)
+    return out, st
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_pcm_tail_of_the_demodulators_launch(pkg, overlap):
+    """sdrfm_process_batch_pcm over nine consecutive pieces of a capture: the first call (the start of a stream: the generic kernel recomputes its first outputs
+    behind design Q's launch) is followed by the sink's own kernel, every later one ends with the sink's chain in design Q's own launch ("+ pcm tail"); the PCM of
+    every call within 1 LSB of host-sinking that call's audio with the state carried across all of them, the carried state within 1e-6."""
+    import torch
+    alpha, gain = _params(pkg)
+    ns, nsamp, nb = 256, 48000, 9
+    h, g = pkg.default_config(64)
+    iq = torch.from_numpy(pkg.make_iq(ns, nb * nsamp, mode="fm", first_id=3100)).cuda()
+    na = nsamp // 50
+    audio = [torch.zeros((ns, na), dtype=torch.float32, device="cuda") for _ in range(nb)]
+    pcm = [torch.zeros((ns, 2 * na), dtype=torch.int16, device="cuda") for _ in range(nb)]
+    torch.cuda.synchronize()
+    names = []
+    with pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=ns, max_bytes_per_call=2 * nsamp)) as dm, pkg.PcmSink(ns, alpha, gain) as sink:
+        for k in range(nb):
+            n = dm.process_batch_pcm_device(sink, iq[:, 2 * k * nsamp:], audio[k], pcm[k], nbytes=2 * nsamp, overlap=overlap)
+            assert n == na
+            names.append(dm.kernel_name)
+        dm.synchronize()
+        state = sink.state()
+    assert "pcm tail" not in names[0], names[0]
+    assert all("pcm tail" in x for x in names[1:]), names
+    assert all(("overlapped" in x) == overlap for x in names[1:]), names
+    auds = [a.cpu().numpy() for a in audio]
+    got = [p.cpu().numpy() for p in pcm]
+    for s in (0, 1, 77, 128, 255):
+        want, st = _host_chain(pkg, auds, alpha, gain, s)
+        for k in range(nb):
+            d = np.abs(got[k][s].astype(np.int32) - want[k].astype(np.int32))
+            assert d.max() <= 1, (s, k, int(d.max()))
+            assert got[k][s][0::2].tobytes() == got[k][s][1::2].tobytes()          # L = R
+        assert abs(state[s] - st) <= 1e-6 * max(abs(st), 0.25), (s, state[s], st)
+
+
+def test_pcm_tail_rows_that_are_not_16_byte_aligned_and_ragged_lengths(pkg):
+    """The tail's two data paths: rows 16-byte aligned (four samples per instruction) or not (audio stride 961 floats), a call whose audio length is no multiple
+    of the tail's 76-sample chunks (968 outputs: the last lane's chunk is short), and a call longer than one segment of 4864 (0.12 s: 5760 outputs)."""
+    import torch
+    alpha, gain = _params(pkg)
+    ns = 64
+    h, g = pkg.default_config(64)
+    for nsamp, astride, pstride in ((48000, 961, 2 * 961), (48400, 1008, 2100), (288000, 5760, 11520)):   # (design Q: whole numbers of 8 audio periods)
+        na = nsamp // 50
+        assert astride >= na and pstride >= 2 * na
+        iq = torch.from_numpy(pkg.make_iq(ns, 3 * nsamp, mode="fm", first_id=3300)).cuda()
+        audio = [torch.zeros((ns, astride), dtype=torch.float32, device="cuda") for _ in range(3)]
+        pcm = [torch.full((ns, pstride), 12345, dtype=torch.int16, device="cuda") for _ in range(3)]
+        torch.cuda.synchronize()
+        with pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=ns, max_bytes_per_call=2 * nsamp)) as dm, pkg.PcmSink(ns, alpha, gain) as sink:
+            for k in range(3):
+                n = dm.process_batch_pcm_device(sink, iq[:, 2 * k * nsamp:], audio[k], pcm[k], nbytes=2 * nsamp, overlap=True)
+                assert n == na
+                assert ("pcm tail" in dm.kernel_name) == (k > 0), dm.kernel_name
+            dm.synchronize()
+        auds = [a[:, :na].cpu().numpy() for a in audio]
+        got = [p.cpu().numpy() for p in pcm]
+        for s in (0, 3, 63):
+            want, _ = _host_chain(pkg, auds, alpha, gain, s)
+            for k in range(3):
+                d = np.abs(got[k][s][:2 * na].astype(np.int32) - want[k].astype(np.int32))
+                assert d.max() <= 1, (nsamp, s, k, int(d.max()))
+                assert (got[k][s][2 * na:] == 12345).all(), (nsamp, s, k)            # nothing written past the call's samples
+
+
+def test_pcm_call_on_the_bit_exact_kernels_and_on_routed_streams(pkg):
+    """Calls no kernel with a tail serves — a bit-exact handle; a batch with routed noise-only streams (one launch of both designs) — are followed by the sink's own
+    kernel; a sequence that switches between the two styles carries the state through (the device-side order between calls: gen)."""
+    import torch
+    alpha, gain = _params(pkg)
+    ns, nsamp, nb = 128, 48000, 6
+    na = nsamp // 50
+    h, g = pkg.default_config(64)
+    iq_np = pkg.make_iq(ns, nb * nsamp, mode="fm", first_id=3500)
+    noisy = np.arange(ns) % 8 == 3
+    iq_np[noisy] = pkg.make_iq(int(noisy.sum()), nb * nsamp, mode="random", first_id=3600)
+    iq = torch.from_numpy(iq_np).cuda()
+    for bit_exact in (True, False):
+        audio = [torch.zeros((ns, na), dtype=torch.float32, device="cuda") for _ in range(nb)]
+        pcm = [torch.zeros((ns, 2 * na), dtype=torch.int16, device="cuda") for _ in range(nb)]
+        torch.cuda.synchronize()
+        names = []
+        with pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=ns, max_bytes_per_call=2 * nsamp, bit_exact=bit_exact)) as dm, \
+                pkg.PcmSink(ns, alpha, gain) as sink:
+            for k in range(nb):
+                if not bit_exact and k == 3:
+                    dm.route(noisy.astype(np.uint8))                                # calls 3, 4: the noisy streams on design B inside design Q's launch
+                if not bit_exact and k == 5:
+                    dm.route(np.zeros(ns, np.uint8))
+                n = dm.process_batch_pcm_device(sink, iq[:, 2 * k * nsamp:], audio[k], pcm[k], nbytes=2 * nsamp, overlap=True)
+                names.append(dm.kernel_name)
+            dm.synchronize()
+        if bit_exact:
+            assert not any("pcm tail" in x for x in names), names
+        else:
+            assert ["pcm tail" in x for x in names] == [False, True, True, False, False, True], names
+        auds = [a.cpu().numpy() for a in audio]
+        got = [p.cpu().numpy() for p in pcm]
+        for s in (0, 3, 11, 127):
+            want, _ = _host_chain(pkg, auds, alpha, gain, s)
+            for k in range(nb):
+                d = np.abs(got[k][s].astype(np.int32) - want[k].astype(np.int32))
+                assert d.max() <= 1, (bit_exact, s, k, int(d.max()))
+
+
+def test_pcm_call_argument_errors(pkg):
+    import torch
+    alpha, gain = _params(pkg)
+    h, g = pkg.default_config(64)
+    lib = pkg.load_library()
+    iq = torch.zeros((4, 96000), dtype=torch.uint8, device="cuda")
+    audio = torch.zeros((4, 960), dtype=torch.float32, device="cuda")
+    pcm = torch.zeros((4, 1920), dtype=torch.int16, device="cuda")
+    import ctypes as C
+    with pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=4)) as dm, pkg.PcmSink(3, alpha, gain) as other, pkg.PcmSink(4, alpha, gain) as sink:
+        n = C.c_uint32()
+        args = lambda k, pp, ps, fl: (dm._h, k._h, C.c_void_p(iq.data_ptr()), iq.stride(0), 96000, C.c_void_p(audio.data_ptr()), audio.stride(0),
+                                      C.c_void_p(pp), ps, C.byref(n), fl)
+        assert lib.sdrfm_process_batch_pcm(*args(other, pcm.data_ptr(), 1920, 1)) == pkg.lib.EINVAL     # a sink of another stream count
+        assert lib.sdrfm_process_batch_pcm(*args(sink, pcm.data_ptr(), 1920, 0)) == pkg.lib.EINVAL      # host buffers: not this call
+        assert lib.sdrfm_process_batch_pcm(*args(sink, pcm.data_ptr() + 2, 1920, 1)) == pkg.lib.EINVAL  # rows are written as (L, R) words
+        assert lib.sdrfm_process_batch_pcm(*args(sink, pcm.data_ptr(), 1919, 1)) == pkg.lib.EINVAL
+        assert lib.sdrfm_process_batch_pcm(*args(sink, pcm.data_ptr(), 1918, 1)) == pkg.lib.ECAPACITY
+        assert lib.sdrfm_process_batch_pcm(*args(sink, pcm.data_ptr(), 1920, 1)) == 0 and n.value == 960
+        dm.synchronize()

@@ -1,0 +1,1 @@
+timeout 2400 python3 -m pytest tests -x -q -m gpu 2>&1 | tail -5
