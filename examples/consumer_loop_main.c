@@ -9,6 +9,7 @@
  *             (the host then stays at most NA calls ahead of the device: NA = 3 keeps the queues nearly empty, NA = 6 keeps them fed)
  *   fused     sdrfm_process_batch_pcm: overlapped calls whose launch ends with the sink's chain (csrc/sdrfm_sink_tail.h) — no second launch, no stream to
  *             order; NA audio and PCM buffers in turn, one sdrfm_flush per region
+ *   fused_pcm_only   the same without an audio buffer: the launch stores the PCM only
  *
  *   consumer_loop_main [n_streams=256] [regions=10] [calls_per_region=300] [NA=6]
  * Prints one JSON line: us per call of every region and the median of the later half, per form.  Measurement only: nothing is checked against the oracle here
@@ -109,18 +110,20 @@ int main(int argc, char** argv) {
   long call = 0;                                              /* calls made so far (the capture buffers and the audio buffers go round across regions) */
 
   printf("{\"n_streams\":%u,\"calls_per_region\":%d,\"fast_form_audio_buffers\":%d", ns, per, NA);
-  const char* names[4] = {"calls", "simple", "fast", "fused"};
+  const char* names[5] = {"calls", "simple", "fast", "fused", "fused_pcm_only"};
   char fused_kernel[128] = "";
-  for (int form = 0; form < 4; ++form) {
+  for (int form = 0; form < 5; ++form) {
     SDRC(sdrfm_pcm_sink_set_stream(sink, form == 2 ? sst : st));
     int have[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (getenv("LOOP_PROGRESS")) { fprintf(stderr, "[form %s]\n", names[form]); fflush(stderr); }
     double* us = (double*)malloc(sizeof(double) * (size_t)regions);
     for (int r = 0; r < regions; ++r) {
+      if (getenv("LOOP_PROGRESS")) { fprintf(stderr, " r%d", r); fflush(stderr); }
       HIPC(hipEventRecord(e0, st));
       for (int k = 0; k < per; ++k, ++call) {
         const int nab = form >= 2 ? NA : 2, ab = (int)(call % nab), pab = (int)((call + nab - 1) % nab);
-        if (form == 3) {
-          SDRC(sdrfm_process_batch_pcm(fm, sink, d_iq[call % NBUF], nbytes, nbytes, d_audio[ab], astride, d_pcm[ab], 2 * astride, &n, F));
+        if (form >= 3) {                                       /* (form 4: no audio buffer — the PCM is all the call leaves) */
+          SDRC(sdrfm_process_batch_pcm(fm, sink, d_iq[call % NBUF], nbytes, nbytes, form == 3 ? d_audio[ab] : NULL, astride, d_pcm[ab], 2 * astride, &n, F));
           continue;
         }
         if (form == 2 && have[ab]) while (hipEventQuery(consumed[ab]) != hipSuccess) { }    /* audio[ab] is free once its consumer (of call - NA) is done */

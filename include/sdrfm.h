@@ -335,14 +335,17 @@ int  sdrfm_pcm_sink_get_state(sdrfm_pcm_sink_t* k, float* state_out /* n_streams
 
 /* ONE call of the demodulator and of the sink (round 6): sdrfm_process_batch(h, iq, ..., audio, ..., flags) and then the sink's default form over that
  * audio into pcm — device buffers only (flags must hold SDRFM_F_DEVICE_PTRS; SDRFM_F_OVERLAP as for sdrfm_process_batch, with pcm rotated like audio).
- * Where the matrix-pipe kernel serves the whole call, its launch ENDS with the sink's chain: every wave counts itself done behind its audio stores and the
- * stream's last wave walks the stream's row through the de-emphasis (csrc/sdrfm_sink_tail.h) — no second launch, no stream to order, nothing between two
- * overlapped calls: the consumer loop of INTEGRATION.md section 3 runs at the demodulator's own rate (profiles/r06_sink.txt).  Any other call (the bit-exact
- * kernels, routed streams, the first call of a stream) is followed by the sink's own kernel on the handle's stream, behind a join of the overlapped calls.
- * Same results either way up to the blocked scan's tolerance: PCM within 1 LSB of sdrfm_pcm_deemph_s16's, state within 1e-6 relative.  The audio is written
- * as by sdrfm_process_batch.  The sink must belong to h's device and have h's n_streams; between calls made this way and sdrfm_pcm_sink_process_batch
- * calls on the same sink, synchronise both (the tail of call c waits ON THE DEVICE for the sink's call c - 1, which must already be in a queue).
- * kernel name: "... + pcm tail". */
+ * Where the matrix-pipe kernel serves the whole call, the sink's chain runs INSIDE its launch (csrc/sdrfm_sink_tail.h): the de-emphasis forgets — (1 - alpha)^64
+ * is below rounding —, so every wave sinks the ~400 outputs it has just computed where they lie, publishes its end state in one word, and finishes its first 64
+ * outputs with its neighbour's.  No second launch, no stream to order, nothing between two overlapped calls: the consumer loop of INTEGRATION.md section 3 runs
+ * within 10 % of the demodulator's own rate (profiles/r06_sink.txt).  Any other call (the bit-exact kernels, routed streams, the first call of a stream, a sink
+ * whose alpha is below 0.231) is followed by the sink's own kernel on the handle's stream, behind a join of the overlapped calls.
+ * Same results either way up to the blocked scan's tolerance: PCM within 1 LSB of sdrfm_pcm_deemph_s16's, state within 1e-6 relative.
+ * audio may be NULL: the PCM is then all the call leaves (a launch that holds the chain does not store the float audio at all; other calls use rows of the
+ * library's own); otherwise the audio is written as by sdrfm_process_batch.
+ * The sink must belong to h's device and have h's n_streams; between calls made this way and sdrfm_pcm_sink_process_batch calls on the same sink, synchronise
+ * both (the chain of call c waits ON THE DEVICE for the sink's call c - 1, which must already be in a queue); sdrfm_pcm_sink_get_state after sdrfm_synchronize(h).
+ * kernel name: "... + pcm". */
 int  sdrfm_process_batch_pcm(sdrfm_t* h, sdrfm_pcm_sink_t* sink, const uint8_t* iq, size_t iq_stride, uint32_t nbytes, float* audio, size_t audio_stride,
                              int16_t* pcm, size_t pcm_stride, uint32_t* n_audio, uint32_t flags);
 

@@ -43,6 +43,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <cstddef>
 #include <cstdint>
 #include <type_traits>
 
@@ -166,6 +167,16 @@ __device__ __forceinline__ float q_wrap(float x) {
   return __builtin_fmaf(k, -0x1.921fb6p+2f, x);
 }
 
+// v -> (int16) rint(clamp(v, -32768, 32767)) in both halves of a word, as the host routine has it (csrc/pcm_sink.c): one v_med3 (v is never a NaN for finite
+// audio: the routine's two compares give the same value), the rounding to nearest-even through 1.5 * 2^23 (whose sum's low 16 bits are the integer's two's
+// complement), one v_perm for the two copies
+__device__ __forceinline__ unsigned q_pcm_word(float v) {
+  const float c = __builtin_amdgcn_fmed3f(v, -32768.0f, 32767.0f);
+  float t = c + 0x1.8p+23f;
+  asm volatile("" : "+v"(t));
+  return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, t), __builtin_bit_cast(unsigned, t), 0x05040504u);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   static_assert(N >= 0 && N < 16, "vmcnt immediate");
@@ -180,9 +191,13 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // The body of one workgroup (one wave): `bid` is its index among the launch's design-Q workgroups (the kernel's bid, or — in k_mix
 // below — its index among the workgroups that run this body).
-// WT (the launch with the PCM tail): the audio is stored THROUGH the L2 (device-scope stores: sc1), because the stream's last wave — on whatever XCD — reads
-// the whole row back; a release fence instead would be an L2 write-back per wave (buffer_wbl2: measured 340 us per call with 3072 waves).
-template <int C0, int NSLOT, int D, int DA, bool WT = false>
+// PCM (k_mfir_pcm: the kernel argument is a QPcmArgs): every run also sinks its own audio outputs — de-emphasis, int16 pairs — where they are parked
+// (sdrfm_sink_tail.h); 256 bytes of LDS behind the workgroup's q_lds bytes hold the 64 outputs its predecessor's state still reaches.
+template <int D, int DA, int NSLOT>
+constexpr uint32_t q_lds() { return (uint32_t)(QGeo<D, DA>::PRE + 1024 * NSLOT + 4 * (QGeo<D, DA>::DBW + ABW + FLW + GTW)); }
+struct QPcmArgs { SdrfmQParams p; SdrfmSinkTail t; };
+static_assert(ABS * 128 <= 64 * (int)SDRFM_TAIL_CH, "a flush of parked audio is one scan of the wave");
+template <int C0, int NSLOT, int D, int DA, bool PCM = false>
 __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t bid) {
   using G = QGeo<D, DA>;
   [[maybe_unused]] constexpr int NCH = G::NCH;
@@ -496,6 +511,16 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
   // the memory system every five steps (measured: 4.5 of 27.5 us per call on configs[2]).  The outputs are parked in LDS and stored
   // after the run's last step (every ABS stages in a long run), whole 8-byte pairs when the row allows.
   int npend = 0, jfl = jg0;                                     // parked stages; audio output index of the first parked word
+  // (PCM) the run's de-emphasis state so far, whether nothing has been flushed yet, the first outputs' values; the sink's parameters from the argument segment
+  [[maybe_unused]] float yrun = 0.0f;
+  [[maybe_unused]] bool pfirst = true;
+  [[maybe_unused]] float* const pstash = reinterpret_cast<float*>(smem + q_lds<D, DA, NSLOT>());
+  typedef const __attribute__((address_space(4))) SdrfmSinkTail* KTailPtr;
+  [[maybe_unused]] auto ktail = [&]() -> KTailPtr {
+    const __attribute__((address_space(4))) unsigned char* pp = (const __attribute__((address_space(4))) unsigned char*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(pp));
+    return (KTailPtr)(pp + offsetof(QPcmArgs, t));
+  };
   auto flush_audio = [&]() {
     __builtin_amdgcn_wave_barrier();
     // Row elements [max(jfl, jlo), min(jfl + 128 npend, j1)) come from ab[e - jfl] (the outputs before jlo — a warm-up's — are the previous
@@ -517,18 +542,71 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
     const int hi_ = (j1 < jfl + 128 * npend) ? j1 : jfl + 128 * npend;
 #endif
     const int par = (int)((reinterpret_cast<uintptr_t>(row) >> 2) & 1u);   // row + e is 8-byte aligned where e + par is even
-    for (int e = lo - ((lo + par) & 1) + 2 * ln_; e < hi_; e += 128) {
+    bool want_audio = true;
+    if constexpr (PCM) want_audio = kargs()->audio != nullptr;   // (sdrfm_process_batch_pcm without an audio buffer: the PCM is all the caller takes)
+    if (want_audio) for (int e = lo - ((lo + par) & 1) + 2 * ln_; e < hi_; e += 128) {
       const bool v0 = e >= lo, v1 = e + 1 < hi_;
       const float a0 = v0 ? ab[e - jfl] : 0.0f, a1 = v1 ? ab[e + 1 - jfl] : 0.0f;
-      if constexpr (WT) {
-        const unsigned u0 = __builtin_bit_cast(unsigned, a0), u1 = __builtin_bit_cast(unsigned, a1);
-        if (v0 && v1) __hip_atomic_store(reinterpret_cast<unsigned long long*>(row + e), (unsigned long long)u0 | ((unsigned long long)u1 << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else if (v0) __hip_atomic_store(reinterpret_cast<unsigned*>(row + e), u0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else if (v1) __hip_atomic_store(reinterpret_cast<unsigned*>(row + e + 1), u1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        if (v0 && v1) *reinterpret_cast<qf2_t*>(row + e) = qf2_t{a0, a1};
-        else if (v0) row[e] = a0;
-        else if (v1) row[e + 1] = a1;
+      if (v0 && v1) *reinterpret_cast<qf2_t*>(row + e) = qf2_t{a0, a1};
+      else if (v0) row[e] = a0;
+      else if (v1) row[e + 1] = a1;
+    }
+    if constexpr (PCM) {
+      // ---- the sink's chain over the same outputs, where they lie (sdrfm_sink_tail.h): a blocked scan of the wave from the run's state so far (0 at its
+      // first flush); the packed words take the outputs' place in LDS and are stored as they lie.  The first SDRFM_TAIL_FIX outputs of the run are kept as
+      // values: the predecessor's state still reaches them (finished after the run's last step).
+      const int cntf = hi_ - lo;
+      if (cntf > 0) {
+        constexpr int PCH = (int)SDRFM_TAIL_CH, FIX = (int)SDRFM_TAIL_FIX;
+        const KTailPtr tp = ktail();
+        const float alpha = tp->alpha, gain = tp->gain;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (the stores' operands have left the LDS)
+        __builtin_amdgcn_wave_barrier();
+        float* const xa = ab + (lo - jfl);
+        unsigned* const xw = reinterpret_cast<unsigned*>(xa);
+        const int i0 = PCH * ln_;
+        float xr[PCH];
+#pragma unroll
+        for (int q = 0; q < PCH; ++q) xr[q] = (i0 + q < cntf) ? xa[i0 + q] : 0.0f;
+        // 1. the chunk's own contribution to its last sample: sum of alpha d^(7-q) x[q] (the weights from the host, in scalar registers; lane 0 adds what is left
+        // of the run's state so far).  Samples past the flush's end are zeros: they add nothing.
+        float sc = 0.0f;
+#pragma unroll
+        for (int q = 0; q < PCH; ++q) sc = __builtin_fmaf(tp->w[q], xr[q], sc);
+        float pw = tp->pc;
+        if (ln_ == 0) sc = __builtin_fmaf(pw, yrun, sc);
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {                      // 2. the carries between chunks
+          const float o = __shfl_up(sc, (unsigned)d, 64);
+          const float sn = __builtin_fmaf(pw, o, sc);
+          sc = ln_ >= d ? sn : sc;
+          pw *= pw;
+        }
+        float y = __shfl_up(sc, 1u, 64);                        // 3. the exact form's chain from the true carry-in
+        if (ln_ == 0) y = yrun;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < PCH; ++q) {
+          const float yn = __builtin_fmaf(alpha, xr[q] - y, y);
+          y = (i0 + q < cntf) ? yn : y;
+          if (i0 + q < cntf) {
+            xw[i0 + q] = q_pcm_word(yn * gain);
+            if (pfirst && i0 + q < FIX) pstash[i0 + q] = yn;
+          }
+        }
+        yrun = __shfl(y, (cntf - 1) / PCH, 64);
+        __builtin_amdgcn_wave_barrier();
+        // the words as they lie, 8-byte pairs aligned in memory (as the audio above)
+        unsigned* const out = reinterpret_cast<unsigned*>(tp->pcm + (size_t)st_ * tp->pcm_stride);
+        const int parp = (int)((reinterpret_cast<uintptr_t>(out) >> 2) & 1u), ps = lo + (pfirst ? FIX : 0);
+        for (int e = ps - ((ps + parp) & 1) + 2 * ln_; e < hi_; e += 128) {
+          const bool v0 = e >= ps, v1 = e + 1 < hi_;
+          const unsigned w0 = v0 ? xw[e - lo] : 0u, w1 = v1 ? xw[e + 1 - lo] : 0u;
+          if (v0 && v1) *reinterpret_cast<uint2*>(out + e) = make_uint2(w0, w1);
+          else if (v0) out[e] = w0;
+          else if (v1) out[e + 1] = w1;
+        }
+        pfirst = false;
       }
     }
     jfl += 128 * npend;
@@ -897,6 +975,41 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
 #endif
   wait_vmcnt<0>();                                              // nothing may still be in flight towards this wave's LDS when it ends
   flush_audio();
+  if constexpr (PCM) {
+    // ---- the run's end state published, its predecessor's taken, the run's first outputs finished (sdrfm_sink_tail.h) ---------------------------------
+    const KTailPtr tp = ktail();
+    uint32_t st_ = stream, bid_ = bid;
+    int ln_ = lane;
+    asm volatile("" : "+s"(st_), "+s"(bid_), "+v"(ln_));
+    const uint32_t call = tp->call, nst = tp->n_streams;
+    unsigned long long* const rs = tp->runstate;
+    unsigned long long* const sg = tp->sg;
+    const float dp = ln_ < (int)SDRFM_TAIL_FIX ? tp->dpow[ln_] : 0.0f;
+    unsigned long long pv = 0;
+    if (ln_ == 0) {
+      const unsigned long long w = ((unsigned long long)(call + 1u) << 32) | __builtin_bit_cast(unsigned, yrun);
+      __hip_atomic_store(last_run ? sg + (size_t)((call + 1u) % SDRFM_TAIL_SG_SLOTS) * nst + st_ : rs + bid_, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned long long* const src = run == 0 ? sg + (size_t)(call % SDRFM_TAIL_SG_SLOTS) * nst + st_ : rs + (bid_ - 1u);
+      const uint32_t want = run == 0 ? call : call + 1u;
+      unsigned long long zero = 0ull;
+      asm volatile("" : "+v"(zero));                             // (opaque: "add 0" is a read-modify-write the compiler would turn back into a load, and a load may hit a stale line)
+      // (the predecessor ends when this run does: a few polls at most.  The wait is BOUNDED — a quarter of a second —: a protocol error must not hang the
+      // machine; it is reported through the sink instead — sdrfm_pcm_sink_synchronize / _get_state answer SDRFM_FAIL — and the run goes on from state 0)
+      int it = 0;
+      for (;; ++it) {
+        pv = __hip_atomic_fetch_add(src, zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(pv >> 32) == want || it == (1 << 19)) break;
+        __builtin_amdgcn_s_sleep(16);
+      }
+      if (it == (1 << 19)) { pv = 0ull; __hip_atomic_store(tp->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    }
+    const float carry = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane((int)(unsigned)pv));
+    const int nfix = (j1 - jlo < (int)SDRFM_TAIL_FIX) ? j1 - jlo : (int)SDRFM_TAIL_FIX;
+    if (ln_ < nfix) {
+      const float yv = __builtin_fmaf(dp, carry, pstash[ln_]);
+      reinterpret_cast<unsigned*>(tp->pcm + (size_t)st_ * tp->pcm_stride)[jlo + ln_] = q_pcm_word(yv * tp->gain);
+    }
+  }
   const KargPtr pe = kargs();
   if (pe->n_repaired && lane == 0) {
     const uint2 cnt = *reinterpret_cast<const uint2*>(fl16 + 128);
@@ -939,33 +1052,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16
   mfir_body<C0, NSLOT, D, DA>(p, blockIdx.x);
 }
 
-// The same launch with the PCM sink's chain as its tail (round 6, sdrfm_sink_tail.h): every wave counts itself done behind its audio stores, the stream's last
-// wave walks the stream's row through the de-emphasis chain.  A kernel of its own, so that the instruction stream of k_mfir does not change by a byte.
-template <int D, int DA, int NSLOT>
-constexpr uint32_t q_lds() { return (uint32_t)(QGeo<D, DA>::PRE + 1024 * NSLOT + 4 * (QGeo<D, DA>::DBW + ABW + FLW + GTW)); }
-struct QPcmArgs { SdrfmQParams p; SdrfmSinkTail t; };
+// The same launch with the PCM sink's chain in it (round 6, sdrfm_sink_tail.h): every run sinks its own audio outputs.  A kernel of its own, so that the
+// instruction stream of k_mfir does not change by a byte.
 template <int C0, int NSLOT, int D, int DA>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16 ? 3 : 4))) k_mfir_pcm(QPcmArgs a) {
-  // A stream's workgroups on ONE XCD (workgroups go round the eight XCDs in turn: XCD x takes the grid's x-th eighth), so that its audio row is written and read
-  // back within one L2 (sdrfm_sink_tail.h; the tail checks where the waves really ran and pays an invalidation when this does not hold)
-  const uint32_t G = gridDim.x, bid = (G & 7u) ? blockIdx.x : (blockIdx.x & 7u) * (G >> 3) + (blockIdx.x >> 3);
-  mfir_body<C0, NSLOT, D, DA, true>(a.p, bid);                  // (a run that owns nothing returns at once: it still counts)
-  // what the tail needs is read from the argument segment HERE, through an opaque pointer (as the body's rare branches do): kept in scalar registers across
-  // the step loop it would be spilled there
-  typedef const __attribute__((address_space(4))) QPcmArgs* ArgPtr;
-  ArgPtr ap = (ArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
-  asm volatile("" : "+s"(ap));
-  SdrfmSinkTail t;
-  t.pcm = ap->t.pcm; t.pcm_stride = ap->t.pcm_stride; t.state = ap->t.state; t.gen = ap->t.gen; t.cnt = ap->t.cnt; t.call = ap->t.call; t.n_streams = ap->t.n_streams;
-  t.alpha = ap->t.alpha; t.gain = ap->t.gain; t.pc = ap->t.pc;
-  const uint32_t runs = ap->p.runs;
-  uint32_t G2 = gridDim.x, b2 = blockIdx.x;
-  asm volatile("" : "+s"(G2), "+s"(b2));
-  const uint32_t si = ((G2 & 7u) ? b2 : (b2 & 7u) * (G2 >> 3) + (b2 >> 3)) / runs;
-  const uint32_t* const sl = ap->p.slist;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  static_assert(q_lds<D, DA, NSLOT>() >= SDRFM_TAIL_LDS, "the tail stages its segments in the wave's LDS");
-  sdrfm_sink_tail(t, ap->p.audio, ap->p.audio_stride, ap->p.A_out, sl ? sl[si] : si, runs, reinterpret_cast<float*>(smem));
+  mfir_body<C0, NSLOT, D, DA, true>(a.p, blockIdx.x);
 }
 
 // =================================================================================================================
@@ -1129,8 +1220,9 @@ hipError_t sdrfm_q_launch_pcm(const SdrfmQParams& p, const SdrfmSinkTail& t, uin
   const QVariant* v = q_find(first_chunk, nslot, d, da);
   if (!v || !v->kp) return hipErrorInvalidValue;
   const QPcmArgs a = {p, t};
-  if (done) hipExtLaunchKernelGGL(v->kp, dim3(p.n_streams * p.runs), dim3(64), v->lds, stream, nullptr, done, 0, a);
-  else hipLaunchKernelGGL(v->kp, dim3(p.n_streams * p.runs), dim3(64), v->lds, stream, a);
+  const uint32_t lds = v->lds + 4u * SDRFM_TAIL_FIX;             // (+ the run's first outputs, kept until its predecessor's state is there)
+  if (done) hipExtLaunchKernelGGL(v->kp, dim3(p.n_streams * p.runs), dim3(64), lds, stream, nullptr, done, 0, a);
+  else hipLaunchKernelGGL(v->kp, dim3(p.n_streams * p.runs), dim3(64), lds, stream, a);
   return hipGetLastError();
 }
 

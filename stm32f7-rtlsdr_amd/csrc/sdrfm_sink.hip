@@ -49,9 +49,9 @@ struct SinkParams {
   size_t audio_stride;   // floats
   int16_t* pcm;
   size_t pcm_stride;     // int16 elements per stream (>= 2 * n)
-  float* state;          // [n_streams] y[n-1]
-  uint32_t* gen;         // [n_streams] calls applied to the stream (sdrfm_sink_tail.h: the tail of a demodulator launch waits on it)
-  uint32_t gen_next;     // its value behind this call
+  const unsigned long long* sg_in;   // [n_streams] {tag << 32 | bits of y[n-1]}: the slot of the tag before this call (sdrfm_sink_tail.h) ...
+  unsigned long long* sg_out;        // ... and of the tag behind it
+  uint32_t gen_next;     // the tag behind this call
   uint32_t n_streams, n;
   float alpha, gain;
 };
@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(64) k_pcm_sink(SinkParams p) {
   const uint32_t s0 = blockIdx.x * 64;
   const uint32_t rows = (p.n_streams - s0 < 64u) ? p.n_streams - s0 : 64u;
   const uint32_t mine = s0 + lane;
-  float y = (lane < rows) ? p.state[mine] : 0.0f;
+  float y = (lane < rows) ? __uint_as_float((unsigned)p.sg_in[mine]) : 0.0f;
   for (uint32_t t0 = 0; t0 < p.n; t0 += 64) {
     const uint32_t cols = (p.n - t0 < 64u) ? p.n - t0 : 64u;
     if (lane < cols)
@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(64) k_pcm_sink(SinkParams p) {
         reinterpret_cast<unsigned*>(p.pcm + (size_t)(s0 + r) * p.pcm_stride)[t0 + lane] = tile[r * 65 + lane];
     __syncthreads();
   }
-  if (lane < rows) { p.state[mine] = y; p.gen[mine] = p.gen_next; }
+  if (lane < rows) p.sg_out[mine] = ((unsigned long long)p.gen_next << 32) | __float_as_uint(y);
 }
 
 // ---- the blocked scan (the default): one workgroup of 256 lanes per stream; segments of SINK_NT * SINK_C samples through LDS ------------------------------
@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256) k_pcm_sink_scan(SinkParams p, float pc) {
   const uint32_t s = blockIdx.x, t = threadIdx.x;
   const float* const row = p.audio + (size_t)s * p.audio_stride;
   unsigned* const out = reinterpret_cast<unsigned*>(p.pcm + (size_t)s * p.pcm_stride);
-  float y0 = p.state[s];                                        // the state before the segment (every lane holds it)
+  float y0 = __uint_as_float((unsigned)p.sg_in[s]);             // the state before the segment (every lane holds it)
   for (uint32_t base = 0; base < p.n; base += SINK_SEG) {
     const uint32_t m = (p.n - base < SINK_SEG) ? p.n - base : SINK_SEG;   // samples of this segment
 #pragma unroll
@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(256) k_pcm_sink_scan(SinkParams p, float pc) {
     }
     __syncthreads();
   }
-  if (t == 0) { p.state[s] = y0; p.gen[s] = p.gen_next; }
+  if (t == 0) p.sg_out[s] = ((unsigned long long)p.gen_next << 32) | __float_as_uint(y0);
 }
 
 }  // namespace
@@ -166,9 +166,9 @@ struct sdrfm_pcm_sink {
   float alpha, gain;
   int device;
   hipStream_t own_stream, stream;
-  float* d_state;
-  uint32_t* d_gen;     // [n_streams] calls applied to the stream; behind it the tail's "waves done" counters (sdrfm_sink_tail.h; sink_gen_bytes)
-  uint32_t calls;      // calls issued so far (mod 2^32): what d_gen holds when every one of them is through
+  unsigned long long* d_sg;   // [SDRFM_TAIL_SG_SLOTS][n_streams] {tag << 32 | bits of y[n-1]}, tag t in slot t % 8 (sdrfm_sink_tail.h)
+  float* d_dpow;       // [SDRFM_TAIL_FIX] (1 - alpha)^(k + 1)
+  uint32_t calls;      // calls issued so far (mod 2^32): the tag d_sg holds when every one of them is through
   float* d_audio;      // staging for host-pointer calls
   int16_t* d_pcm;
   uint32_t cap;        // samples per stream the staging holds
@@ -183,14 +183,11 @@ struct sdrfm_pcm_sink {
     }                                                                                                          \
   } while (0)
 
-// gen[n_streams] (padded to 8 bytes), then SDRFM_TAIL_SETS x n_streams 64-bit counters
-static size_t sink_gen_bytes(uint32_t n_streams) { return sizeof(uint32_t) * (size_t)((n_streams + 1u) & ~1u) + 8u * SDRFM_TAIL_SETS * (size_t)n_streams; }
-
 static void sink_free(sdrfm_pcm_sink* k) {
   if (!k) return;
   (void)hipSetDevice(k->device);
-  if (k->d_state) (void)hipFree(k->d_state);
-  if (k->d_gen) (void)hipFree(k->d_gen);
+  if (k->d_sg) (void)hipFree(k->d_sg);
+  if (k->d_dpow) (void)hipFree(k->d_dpow);
   if (k->d_audio) (void)hipFree(k->d_audio);
   if (k->d_pcm) (void)hipFree(k->d_pcm);
   if (k->own_stream) (void)hipStreamDestroy(k->own_stream);
@@ -198,14 +195,15 @@ static void sink_free(sdrfm_pcm_sink* k) {
 }
 
 // ---- the sink as the tail of a demodulator launch (sdrfm_sink_tail.h) ---------------------------------------------------------------------------------------
-bool sdrfm_sink_tail_params(sdrfm_pcm_sink* k, int device, uint32_t n_streams, SdrfmSinkTail* out) {
-  if (!k || !out || k->device != device || k->n_streams != n_streams) return false;
-  out->pcm = nullptr; out->pcm_stride = 0;
-  out->state = k->d_state; out->gen = k->d_gen; out->cnt = k->d_gen + ((n_streams + 1u) & ~1u);
-  out->call = k->calls; out->n_streams = n_streams;
+int sdrfm_sink_tail_params(sdrfm_pcm_sink* k, int device, uint32_t n_streams, SdrfmSinkTail* out) {
+  if (!k || !out || k->device != device || k->n_streams != n_streams) return 0;
+  out->pcm = nullptr; out->pcm_stride = 0; out->runstate = nullptr;
+  out->sg = k->d_sg; out->n_streams = n_streams; out->dpow = k->d_dpow; out->err = reinterpret_cast<uint32_t*>(k->d_dpow + SDRFM_TAIL_FIX);
+  out->call = k->calls;
   out->alpha = k->alpha; out->gain = k->gain;
-  out->pc = (float)pow(1.0 - (double)k->alpha, (double)SDRFM_TAIL_C);
-  return true;
+  out->pc = (float)pow(1.0 - (double)k->alpha, (double)SDRFM_TAIL_CH);
+  for (uint32_t q = 0; q < SDRFM_TAIL_CH; ++q) out->w[q] = (float)((double)k->alpha * pow(1.0 - (double)k->alpha, (double)(SDRFM_TAIL_CH - 1u - q)));
+  return k->alpha >= SDRFM_TAIL_MIN_ALPHA ? 2 : 1;
 }
 
 void sdrfm_sink_tail_issued(sdrfm_pcm_sink* k) { ++k->calls; }
@@ -214,8 +212,9 @@ int sdrfm_sink_launch_on(sdrfm_pcm_sink* k, const float* audio, size_t audio_str
   if (!k) return SDRFM_EINVAL;
   if (n == 0) return SDRFM_OK;
   SinkParams p;
-  p.state = k->d_state; p.n_streams = k->n_streams; p.n = n; p.alpha = k->alpha; p.gain = k->gain;
-  p.gen = k->d_gen; p.gen_next = k->calls + 1u;
+  p.sg_in = k->d_sg + (size_t)(k->calls % SDRFM_TAIL_SG_SLOTS) * k->n_streams; p.sg_out = k->d_sg + (size_t)((k->calls + 1u) % SDRFM_TAIL_SG_SLOTS) * k->n_streams;
+  p.n_streams = k->n_streams; p.n = n; p.alpha = k->alpha; p.gain = k->gain;
+  p.gen_next = k->calls + 1u;
   p.audio = audio; p.audio_stride = audio_stride; p.pcm = pcm; p.pcm_stride = pcm_stride;
   hipLaunchKernelGGL(k_pcm_sink_scan, dim3(k->n_streams), dim3(SINK_NT), 0, stream, p, (float)pow(1.0 - (double)k->alpha, (double)SINK_C));
   STRY(hipGetLastError(), SDRFM_FAIL);
@@ -239,8 +238,14 @@ int sdrfm_pcm_sink_create(uint32_t n_streams, float alpha, float gain, int32_t d
   memset(static_cast<void*>(k), 0, sizeof(*k));
   k->n_streams = n_streams; k->alpha = alpha; k->gain = gain; k->device = device;
   if (hipStreamCreateWithFlags(&k->own_stream, hipStreamNonBlocking) != hipSuccess ||
-      hipMalloc(&k->d_state, sizeof(float) * n_streams) != hipSuccess ||
-      hipMalloc(&k->d_gen, sink_gen_bytes(n_streams)) != hipSuccess) { sink_free(k); return SDRFM_ENOMEM; }
+      hipMalloc(&k->d_sg, sizeof(unsigned long long) * SDRFM_TAIL_SG_SLOTS * n_streams) != hipSuccess ||
+      hipMalloc(&k->d_dpow, sizeof(float) * (SDRFM_TAIL_FIX + 1)) != hipSuccess) { sink_free(k); return SDRFM_ENOMEM; }   // (+ the error word)
+  {
+    float dp[SDRFM_TAIL_FIX + 1];
+    for (uint32_t i = 0; i < SDRFM_TAIL_FIX; ++i) dp[i] = (float)pow(1.0 - (double)alpha, (double)(i + 1));
+    dp[SDRFM_TAIL_FIX] = 0.0f;
+    if (hipMemcpy(k->d_dpow, dp, sizeof(dp), hipMemcpyHostToDevice) != hipSuccess) { sink_free(k); return SDRFM_FAIL; }
+  }
   k->stream = k->own_stream;
   const int rc = sdrfm_pcm_sink_reset(k);
   if (rc != SDRFM_OK) { sink_free(k); return rc; }
@@ -258,8 +263,8 @@ void sdrfm_pcm_sink_destroy(sdrfm_pcm_sink_t* k) {
 int sdrfm_pcm_sink_reset(sdrfm_pcm_sink_t* k) {
   if (!k) return SDRFM_EINVAL;
   STRY(hipSetDevice(k->device), SDRFM_FAIL);
-  STRY(hipMemsetAsync(k->d_state, 0, sizeof(float) * k->n_streams, k->stream), SDRFM_FAIL);
-  STRY(hipMemsetAsync(k->d_gen, 0, sink_gen_bytes(k->n_streams), k->stream), SDRFM_FAIL);
+  STRY(hipMemsetAsync(k->d_sg, 0, sizeof(unsigned long long) * SDRFM_TAIL_SG_SLOTS * k->n_streams, k->stream), SDRFM_FAIL);
+  STRY(hipMemsetAsync(k->d_dpow + SDRFM_TAIL_FIX, 0, sizeof(uint32_t), k->stream), SDRFM_FAIL);   // (the chain's error word)
   STRY(hipStreamSynchronize(k->stream), SDRFM_FAIL);
   k->calls = 0;
   return SDRFM_OK;
@@ -273,11 +278,19 @@ int sdrfm_pcm_sink_set_stream(sdrfm_pcm_sink_t* k, void* hip_stream) {
   return SDRFM_OK;
 }
 
+// a run of a demodulator launch gave up waiting for its predecessor's word (sdrfm_sink_tail.h): the PCM since then is not to be trusted
+static int sink_chain_error(sdrfm_pcm_sink* k) {
+  uint32_t e = 0;
+  if (hipMemcpy(&e, k->d_dpow + SDRFM_TAIL_FIX, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return SDRFM_FAIL;
+  if (e) fprintf(stderr, "[sdrfm] PCM sink: a run of a demodulator launch waited in vain for its predecessor's state (csrc/sdrfm_sink_tail.h)\n");
+  return e ? SDRFM_FAIL : SDRFM_OK;
+}
+
 int sdrfm_pcm_sink_synchronize(sdrfm_pcm_sink_t* k) {
   if (!k) return SDRFM_EINVAL;
   STRY(hipSetDevice(k->device), SDRFM_FAIL);
   STRY(hipStreamSynchronize(k->stream), SDRFM_FAIL);
-  return SDRFM_OK;
+  return sink_chain_error(k);
 }
 
 int sdrfm_pcm_sink_process_batch(sdrfm_pcm_sink_t* k, const float* audio, size_t audio_stride, uint32_t n, int16_t* pcm,
@@ -290,8 +303,9 @@ int sdrfm_pcm_sink_process_batch(sdrfm_pcm_sink_t* k, const float* audio, size_t
   if (pcm_stride & 1u) return SDRFM_EINVAL;                          // rows are written as (L,R) dwords
   STRY(hipSetDevice(k->device), SDRFM_FAIL);
   SinkParams p;
-  p.state = k->d_state; p.n_streams = k->n_streams; p.n = n; p.alpha = k->alpha; p.gain = k->gain;
-  p.gen = k->d_gen; p.gen_next = k->calls + 1u;
+  p.sg_in = k->d_sg + (size_t)(k->calls % SDRFM_TAIL_SG_SLOTS) * k->n_streams; p.sg_out = k->d_sg + (size_t)((k->calls + 1u) % SDRFM_TAIL_SG_SLOTS) * k->n_streams;
+  p.n_streams = k->n_streams; p.n = n; p.alpha = k->alpha; p.gain = k->gain;
+  p.gen_next = k->calls + 1u;
   const dim3 grid((k->n_streams + 63) / 64);
   const float pc = (float)pow(1.0 - (double)k->alpha, (double)SINK_C);   // the blocked scan's carry factor: (1 - alpha)^(samples per chunk)
   const bool exact = (flags & SDRFM_PCM_F_EXACT) != 0;
@@ -335,8 +349,12 @@ int sdrfm_pcm_sink_get_state(sdrfm_pcm_sink_t* k, float* state_out) {
   if (!k || !state_out) return SDRFM_EINVAL;
   STRY(hipSetDevice(k->device), SDRFM_FAIL);
   STRY(hipStreamSynchronize(k->stream), SDRFM_FAIL);
-  STRY(hipMemcpy(state_out, k->d_state, sizeof(float) * k->n_streams, hipMemcpyDeviceToHost), SDRFM_FAIL);
-  return SDRFM_OK;
+  unsigned long long* tmp = new (std::nothrow) unsigned long long[k->n_streams];
+  if (!tmp) return SDRFM_ENOMEM;
+  const hipError_t e = hipMemcpy(tmp, k->d_sg + (size_t)(k->calls % SDRFM_TAIL_SG_SLOTS) * k->n_streams, sizeof(unsigned long long) * k->n_streams, hipMemcpyDeviceToHost);
+  for (uint32_t i = 0; e == hipSuccess && i < k->n_streams; ++i) { const unsigned b = (unsigned)tmp[i]; memcpy(state_out + i, &b, sizeof(float)); }
+  delete[] tmp;
+  return e == hipSuccess ? sink_chain_error(k) : SDRFM_FAIL;
 }
 
 }  // extern "C"

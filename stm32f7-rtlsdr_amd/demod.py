@@ -170,14 +170,15 @@ class FmDemod:
 
     def process_batch_pcm_device(self, sink, iq, audio, pcm, nbytes=None, overlap=False):
         """sdrfm_process_batch_pcm: one call of the demodulator and of the device PCM sink `sink` (a PcmSink of this device and this many streams) —
-        where design Q serves the call its launch ends with the sink's chain (kernel_name ends in "+ pcm tail"), any other call is followed by the sink's
+        where design Q serves the call the sink's chain runs inside its launch (kernel_name ends in "+ pcm"), any other call is followed by the sink's
         own kernel on the handle's stream.  pcm: torch.int16 [n_streams, >= 2 * n_audio]; with overlap=True rotate pcm like audio.  Returns n_audio."""
-        assert iq.is_cuda and audio.is_cuda and pcm.is_cuda and iq.dim() == 2 and audio.dim() == 2 and pcm.dim() == 2
-        assert iq.stride(1) == 1 and audio.stride(1) == 1 and pcm.stride(1) == 1
+        assert iq.is_cuda and pcm.is_cuda and iq.dim() == 2 and pcm.dim() == 2 and iq.stride(1) == 1 and pcm.stride(1) == 1
+        assert audio is None or (audio.is_cuda and audio.dim() == 2 and audio.stride(1) == 1)      # (None: the PCM is all the call leaves)
         nbytes = iq.shape[1] if nbytes is None else int(nbytes)
         n = C.c_uint32()
         self._ck(self._lib.sdrfm_process_batch_pcm(self._h, sink._h, C.c_void_p(iq.data_ptr()), iq.stride(0), nbytes,
-                                                   C.c_void_p(audio.data_ptr()), audio.stride(0), C.c_void_p(pcm.data_ptr()), pcm.stride(0),
+                                                   C.c_void_p(audio.data_ptr() if audio is not None else None), audio.stride(0) if audio is not None else 0,
+                                                   C.c_void_p(pcm.data_ptr()), pcm.stride(0),
                                                    C.byref(n), _l.F_DEVICE_PTRS | (_l.F_OVERLAP if overlap else 0)), "sdrfm_process_batch_pcm")
         return n.value
 

@@ -230,7 +230,7 @@ def _host_chain(pkg, auds, alpha, gain, s):
 @pytest.mark.parametrize("overlap", [False, True])
 def test_pcm_tail_of_the_demodulators_launch(pkg, overlap):
     """sdrfm_process_batch_pcm over nine consecutive pieces of a capture: the first call (the start of a stream: the generic kernel recomputes its first outputs
-    behind design Q's launch) is followed by the sink's own kernel, every later one ends with the sink's chain in design Q's own launch ("+ pcm tail"); the PCM of
+    behind design Q's launch) is followed by the sink's own kernel, every later one ends with the sink's chain in design Q's own launch ("+ pcm"); the PCM of
     every call within 1 LSB of host-sinking that call's audio with the state carried across all of them, the carried state within 1e-6."""
     import torch
     alpha, gain = _params(pkg)
@@ -249,8 +249,8 @@ def test_pcm_tail_of_the_demodulators_launch(pkg, overlap):
             names.append(dm.kernel_name)
         dm.synchronize()
         state = sink.state()
-    assert "pcm tail" not in names[0], names[0]
-    assert all("pcm tail" in x for x in names[1:]), names
+    assert "+ pcm" not in names[0], names[0]
+    assert all("+ pcm" in x for x in names[1:]), names
     assert all(("overlapped" in x) == overlap for x in names[1:]), names
     auds = [a.cpu().numpy() for a in audio]
     got = [p.cpu().numpy() for p in pcm]
@@ -281,7 +281,7 @@ def test_pcm_tail_rows_that_are_not_16_byte_aligned_and_ragged_lengths(pkg):
             for k in range(3):
                 n = dm.process_batch_pcm_device(sink, iq[:, 2 * k * nsamp:], audio[k], pcm[k], nbytes=2 * nsamp, overlap=True)
                 assert n == na
-                assert ("pcm tail" in dm.kernel_name) == (k > 0), dm.kernel_name
+                assert ("+ pcm" in dm.kernel_name) == (k > 0), dm.kernel_name
             dm.synchronize()
         auds = [a[:, :na].cpu().numpy() for a in audio]
         got = [p.cpu().numpy() for p in pcm]
@@ -321,9 +321,9 @@ def test_pcm_call_on_the_bit_exact_kernels_and_on_routed_streams(pkg):
                 names.append(dm.kernel_name)
             dm.synchronize()
         if bit_exact:
-            assert not any("pcm tail" in x for x in names), names
+            assert not any("+ pcm" in x for x in names), names
         else:
-            assert ["pcm tail" in x for x in names] == [False, True, True, False, False, True], names
+            assert ["+ pcm" in x for x in names] == [False, True, True, False, False, True], names
         auds = [a.cpu().numpy() for a in audio]
         got = [p.cpu().numpy() for p in pcm]
         for s in (0, 3, 11, 127):
@@ -353,3 +353,35 @@ def test_pcm_call_argument_errors(pkg):
         assert lib.sdrfm_process_batch_pcm(*args(sink, pcm.data_ptr(), 1918, 1)) == pkg.lib.ECAPACITY
         assert lib.sdrfm_process_batch_pcm(*args(sink, pcm.data_ptr(), 1920, 1)) == 0 and n.value == 960
         dm.synchronize()
+
+
+def test_pcm_call_without_an_audio_buffer(pkg):
+    """audio = NULL: the PCM is all the call leaves — the same PCM, bit for bit, as the calls that also store the audio (one PCM buffer per call; the first call
+    and a call with routed streams go through rows of the library's own)."""
+    import torch
+    alpha, gain = _params(pkg)
+    ns, nsamp, nb = 256, 48000, 6
+    na = nsamp // 50
+    h, g = pkg.default_config(64)
+    iq_np = pkg.make_iq(ns, nb * nsamp, mode="fm", first_id=3700)
+    noisy = np.arange(ns) % 16 == 5
+    iq_np[noisy] = pkg.make_iq(int(noisy.sum()), nb * nsamp, mode="random", first_id=3800)
+    iq = torch.from_numpy(iq_np).cuda()
+    res = []
+    for with_audio in (True, False):
+        audio = [torch.zeros((ns, na), dtype=torch.float32, device="cuda") for _ in range(nb)]
+        pcm = [torch.zeros((ns, 2 * na), dtype=torch.int16, device="cuda") for _ in range(nb)]
+        torch.cuda.synchronize()
+        names = []
+        with pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=ns, max_bytes_per_call=2 * nsamp)) as dm, pkg.PcmSink(ns, alpha, gain) as sink:
+            for k in range(nb):
+                if k == 4:
+                    dm.route(noisy.astype(np.uint8))
+                n = dm.process_batch_pcm_device(sink, iq[:, 2 * k * nsamp:], audio[k] if with_audio else None, pcm[k], nbytes=2 * nsamp, overlap=True)
+                assert n == na
+                names.append(dm.kernel_name)
+            dm.synchronize()
+        assert ["+ pcm" in x for x in names] == [False, True, True, True, False, False], names
+        assert all("overlapped" in x for x in names[1:5]), names           # (the second call in a row through the library's own audio rows cannot overlap the first)
+        res.append(torch.stack(pcm).cpu().numpy())
+    assert res[0].tobytes() == res[1].tobytes()
