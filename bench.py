@@ -62,6 +62,7 @@ def parse():
                     "random bytes, the others the FM test signal (dongles that are not tuned to a station: the library routes them per stream); "
                     "comparison figures, labelled as such")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-consumer-leg", action="store_true", help="skip the consumer-loop leg (sdrfm_process_batch_pcm, steady state; fm workload)")
     ap.add_argument("--no-steady", action="store_true", help="skip the steady-state series (ten regions of 300 calls; fm workload)")
     ap.add_argument("--no-bit-exact-leg", action="store_true", help="skip the SDRFM_CFG_BIT_EXACT comparison leg of the default line (bit_exact_kernel)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -531,6 +532,37 @@ def main():
         if overlap:
             time.sleep(REST_S)
             steady_ovl = steady_regions(torch, stream, step_ovl, finish=dm.flush)
+    # what a consumer of the audio gets: the same overlapped calls made through sdrfm_process_batch_pcm — the board's sink format
+    # (de-emphasis, int16 L = R) out of the demodulator's own launch —, steady state, with and without the float audio stored beside the PCM
+    consumer = None
+    if steady_ovl and overlap and not args.dev_library and args.iq_class == "fm" and not args.no_consumer_leg:
+        alpha, gain = float(pkg.load_library().sdrfm_pcm_alpha(48000.0, 75e-6)), float(32767.0 / (2 * np.pi * 75e3 / (fs / D)))
+        with torch.cuda.stream(stream):
+            pcm_ring = [torch.zeros((ns, 2 * n_audio_max + 2), dtype=torch.int16, device="cuda") for _ in range(3)]
+            audio_ring = audio_pair + [torch.zeros_like(audio)]
+        stream.synchronize()
+        with pkg.PcmSink(ns, alpha, gain, device=local_rank) as sink:
+            cc = {"n": 0, "names": set()}
+
+            def step_pcm(with_audio):
+                def f(i):
+                    k = cc["n"] % 3
+                    dm.process_batch_pcm_device(sink, batches[i % nb], audio_ring[k] if with_audio else None, pcm_ring[k], overlap=True)
+                    cc["n"] += 1
+                return f
+            time.sleep(REST_S)
+            both = steady_regions(torch, stream, step_pcm(True), finish=dm.flush)
+            name_pcm = dm.kernel_name
+            only = steady_regions(torch, stream, step_pcm(False), finish=dm.flush)
+            dm.synchronize()
+            sink_ok = sink.synchronize_status() == 0
+        consumer = {"call": "sdrfm_process_batch_pcm (SDRFM_F_OVERLAP), three PCM buffers in turn; steady = median of the last five of ten regions of 300 calls",
+                    "kernel": name_pcm, "ms_per_call_pcm_and_audio": round(float(np.median(both[5:])), 5), "ms_per_call_pcm_only": round(float(np.median(only[5:])), 5),
+                    "ms_per_call_demodulator_alone": round(float(np.median(steady_ovl[5:])), 5),
+                    "ms_per_call_regions_300": {"pcm_and_audio": [round(x, 4) for x in both], "pcm_only": [round(x, 4) for x in only]},
+                    "sink_chain_ok": sink_ok,
+                    "note": "the sink's chain runs inside the demodulator's launch (csrc/sdrfm_sink_tail.h); PCM within 1 LSB of the host routine's (tests/test_pcm_sink_gpu.py); "
+                            "the stand-alone sink kernel behind every call: profiles/r06_sink.txt"}
     # the north-star's literal design beside the default one: a SDRFM_CFG_BIT_EXACT handle — fp32 fmaf chains on the vector pipe, no matrix
     # instruction, bit-identical to the definition's chains — over the same rotated batches: K serial calls from rest (median of five regions when K is short) and
     # the steady series.  A second handle; nothing of the default handle's figures depends on it.
@@ -654,6 +686,8 @@ def main():
         rl["target_judged_on"] = {"frac_read_basis": judged, "which": ("overlapped calls, steady state" if rb.get("overlapped_calls", {}).get("frac_steady") else
                                                                       "overlapped calls, the timed region" if rb.get("overlapped_calls", {}).get("frac") else
                                                                       "serial calls, steady state" if rb["frac_steady"] else "serial calls, the timed region")}
+        if consumer:
+            res["consumer_loop"] = consumer
         if bit_exact_leg:
             bx = bit_exact_leg
             res["bit_exact_kernel"] = {

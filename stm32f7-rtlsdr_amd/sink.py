@@ -66,6 +66,10 @@ class PcmSink:
     def synchronize(self):
         self._ck(self._lib.sdrfm_pcm_sink_synchronize(self._h), "sdrfm_pcm_sink_synchronize")
 
+    def synchronize_status(self):
+        """sdrfm_pcm_sink_synchronize's status as it is (0 = fine; SDRFM_FAIL when a run of a demodulator launch waited in vain for its predecessor's state)."""
+        return int(self._lib.sdrfm_pcm_sink_synchronize(self._h))
+
     def state(self):
         out = np.zeros(self.n_streams, np.float32)
         self._ck(self._lib.sdrfm_pcm_sink_get_state(self._h, out.ctypes.data_as(C.POINTER(C.c_float))), "sdrfm_pcm_sink_get_state")

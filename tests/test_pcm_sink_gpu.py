@@ -385,3 +385,61 @@ def test_pcm_call_without_an_audio_buffer(pkg):
         assert all("overlapped" in x for x in names[1:5]), names           # (the second call in a row through the library's own audio rows cannot overlap the first)
         res.append(torch.stack(pcm).cpu().numpy())
     assert res[0].tobytes() == res[1].tobytes()
+
+
+def test_pcm_chain_in_runs_that_flush_twice(pkg):
+    """Runs longer than the four audio stages design Q parks (0.133 s x 256 streams: 21 steps = 4.2 stages per run) store — and sink — their outputs in two
+    goes: the second scan continues from the run's own state, the first 64 outputs are still finished at the run's end."""
+    import torch
+    alpha, gain = _params(pkg)
+    ns, nsamp, nb = 256, 320000, 3
+    na = nsamp // 50
+    h, g = pkg.default_config(64)
+    rows = pkg.make_iq(8, nb * nsamp, mode="fm", first_id=3900)
+    iq = torch.from_numpy(rows).cuda().repeat(ns // 8, 1)                       # (stream s carries row s % 8)
+    audio = [torch.zeros((ns, na), dtype=torch.float32, device="cuda") for _ in range(nb)]
+    pcm = [torch.zeros((ns, 2 * na), dtype=torch.int16, device="cuda") for _ in range(nb)]
+    torch.cuda.synchronize()
+    with pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=ns, max_bytes_per_call=2 * nsamp)) as dm, pkg.PcmSink(ns, alpha, gain) as sink:
+        for k in range(nb):
+            assert dm.process_batch_pcm_device(sink, iq[:, 2 * k * nsamp:], audio[k], pcm[k], nbytes=2 * nsamp, overlap=True) == na
+            assert ("+ pcm" in dm.kernel_name) == (k > 0), dm.kernel_name
+        dm.synchronize()
+        state = sink.state()
+    auds = [a.cpu().numpy() for a in audio]
+    got = [p.cpu().numpy() for p in pcm]
+    for s in (0, 9, 255):
+        want, st = _host_chain(pkg, auds, alpha, gain, s)
+        for k in range(nb):
+            d = np.abs(got[k][s].astype(np.int32) - want[k].astype(np.int32))
+            assert d.max() <= 1, (s, k, int(d.max()), int(np.argmax(d)))
+        assert abs(state[s] - st) <= 1e-6 * max(abs(st), 0.25), (s, state[s], st)
+
+
+@pytest.mark.parametrize("fs,decim,adecim,taps", [(2.048e6, 8, 8, 64), (3.2e6, 16, 5, 64), (2.4e6, 10, 5, 16)])
+def test_pcm_chain_at_the_other_front_end_rates(pkg, fs, decim, adecim, taps):
+    """The kernels with the sink's chain exist for every shape design Q has an instance for: 2.048 MS/s / 8 / 8, 3.2 MS/s / 16 / 5, and 16 channel taps."""
+    import torch
+    alpha, gain = _params(pkg)
+    ns, nb = 256, 4
+    nsamp = decim * adecim * 8 * 120                                             # whole numbers of 8 audio periods: 960 outputs per call
+    na = nsamp // (decim * adecim)
+    h, g = pkg.default_config(taps, fs=fs, fir_decim=decim, audio_decim=adecim) if decim != 10 else pkg.default_config(taps)
+    rows = pkg.make_iq(8, nb * nsamp, mode="fm", first_id=4100)
+    iq = torch.from_numpy(rows).cuda().repeat(ns // 8, 1)
+    audio = [torch.zeros((ns, na), dtype=torch.float32, device="cuda") for _ in range(nb)]
+    pcm = [torch.zeros((ns, 2 * na), dtype=torch.int16, device="cuda") for _ in range(nb)]
+    torch.cuda.synchronize()
+    with pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=ns, fir_decim=decim, audio_decim=adecim, max_bytes_per_call=2 * nsamp)) as dm, \
+            pkg.PcmSink(ns, alpha, gain) as sink:
+        for k in range(nb):
+            assert dm.process_batch_pcm_device(sink, iq[:, 2 * k * nsamp:], audio[k], pcm[k], nbytes=2 * nsamp, overlap=True) == na
+            assert ("+ pcm" in dm.kernel_name) == (k > 0), dm.kernel_name
+        dm.synchronize()
+    auds = [a.cpu().numpy() for a in audio]
+    got = [p.cpu().numpy() for p in pcm]
+    for s in (0, 13, 255):
+        want, _ = _host_chain(pkg, auds, alpha, gain, s)
+        for k in range(nb):
+            d = np.abs(got[k][s].astype(np.int32) - want[k].astype(np.int32))
+            assert d.max() <= 1, (s, k, int(d.max()))

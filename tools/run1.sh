@@ -1,4 +1,7 @@
-timeout 2400 python3 -m pytest tests -x -q -m gpu 2>&1 | tail -5
-for i in 1 2 3 4 5 6; do timeout 60 ./examples/consumer_loop_main 256 10 300 6 | python3 -c "
-import sys,json
-d=json.loads(sys.stdin.read()); print({k:(v['steady_us_per_call'] if isinstance(v,dict) else v) for k,v in d.items() if k!='kernel'})"; done
+(cd /tmp && time python3 $OLDPWD/bench.py --gpus 1 --steps 20 --warmup 5 > $OLDPWD/gpurun_out/bench_c.json 2> $OLDPWD/gpurun_out/bench_c.err); tail -3 gpurun_out/bench_c.err
+python3 - <<'PY'
+import json
+d=json.load(open('gpurun_out/bench_c.json'))
+print(d['value'], d['ms_per_step'], d['roofline']['read_basis']['overlapped_calls'])
+print(json.dumps(d.get('consumer_loop'))[:900])
+PY
