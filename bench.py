@@ -561,7 +561,7 @@ def main():
                     "ms_per_call_demodulator_alone": round(float(np.median(steady_ovl[5:])), 5),
                     "ms_per_call_regions_300": {"pcm_and_audio": [round(x, 4) for x in both], "pcm_only": [round(x, 4) for x in only]},
                     "sink_chain_ok": sink_ok,
-                    "note": "the sink's chain runs inside the demodulator's launch (csrc/sdrfm_sink_tail.h); PCM within 1 LSB of the host routine's (tests/test_pcm_sink_gpu.py); "
+                    "note": "the sink's chain runs inside the demodulator's launch (csrc/sdrfm_sink_chain.h); PCM within 1 LSB of the host routine's (tests/test_pcm_sink_gpu.py); "
                             "the stand-alone sink kernel behind every call: profiles/r06_sink.txt"}
     # the north-star's literal design beside the default one: a SDRFM_CFG_BIT_EXACT handle — fp32 fmaf chains on the vector pipe, no matrix
     # instruction, bit-identical to the definition's chains — over the same rotated batches: K serial calls from rest (median of five regions when K is short) and

@@ -7,7 +7,7 @@
  *   simple    two audio buffers, sdrfm_flush_previous + the sink on the HANDLE'S stream after every call
  *   fast      NA audio buffers, the sink on a stream OF ITS OWN behind sdrfm_wait_previous, the reuse of an audio buffer guarded by hipEventQuery on the host
  *             (the host then stays at most NA calls ahead of the device: NA = 3 keeps the queues nearly empty, NA = 6 keeps them fed)
- *   fused     sdrfm_process_batch_pcm: overlapped calls whose launch ends with the sink's chain (csrc/sdrfm_sink_tail.h) — no second launch, no stream to
+ *   fused     sdrfm_process_batch_pcm: overlapped calls whose launch ends with the sink's chain (csrc/sdrfm_sink_chain.h) — no second launch, no stream to
  *             order; NA audio and PCM buffers in turn, one sdrfm_flush per region
  *   fused_pcm_only   the same without an audio buffer: the launch stores the PCM only
  *

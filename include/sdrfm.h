@@ -335,7 +335,7 @@ int  sdrfm_pcm_sink_get_state(sdrfm_pcm_sink_t* k, float* state_out /* n_streams
 
 /* ONE call of the demodulator and of the sink (round 6): sdrfm_process_batch(h, iq, ..., audio, ..., flags) and then the sink's default form over that
  * audio into pcm — device buffers only (flags must hold SDRFM_F_DEVICE_PTRS; SDRFM_F_OVERLAP as for sdrfm_process_batch, with pcm rotated like audio).
- * Where the matrix-pipe kernel serves the whole call, the sink's chain runs INSIDE its launch (csrc/sdrfm_sink_tail.h): the de-emphasis forgets — (1 - alpha)^64
+ * Where the matrix-pipe kernel serves the whole call, the sink's chain runs INSIDE its launch (csrc/sdrfm_sink_chain.h): the de-emphasis forgets — (1 - alpha)^64
  * is below rounding —, so every wave sinks the ~400 outputs it has just computed where they lie, publishes its end state in one word, and finishes its first 64
  * outputs with its neighbour's.  No second launch, no stream to order, nothing between two overlapped calls: the consumer loop of INTEGRATION.md section 3 runs
  * within 10 % of the demodulator's own rate (profiles/r06_sink.txt).  Any other call (the bit-exact kernels, routed streams, the first call of a stream, a sink

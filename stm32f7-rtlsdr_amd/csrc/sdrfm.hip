@@ -1021,11 +1021,11 @@ struct sdrfm {
   // records ovl_done[k] behind the calls put on internal stream k and makes the handle's stream wait for it.
   hipStream_t ovl_stream[2];
   hipEvent_t ovl_in, ovl_done[2];
-  // sdrfm_process_batch_pcm: the sink whose chain the call's design-Q launch ends with (sdrfm_sink_tail.h); pcm_fused: that launch took it
+  // sdrfm_process_batch_pcm: the sink whose chain the call's design-Q launch ends with (sdrfm_sink_chain.h); pcm_fused: that launch took it
   sdrfm_pcm_sink* pcm_sink; int16_t* pcm_out; size_t pcm_out_stride; bool pcm_fused;
   bool pcm_no_audio; float* d_pcm_audio; size_t pcm_audio_stride; uint32_t pcm_audio_cap;   // a call without an audio buffer: the library's own, for the calls that need one
   const int16_t* prev_ovl_pcm; size_t prev_ovl_pcm_stride;       // the PCM rows the previous overlapped call may still be writing
-  unsigned long long* d_runstate; uint32_t runstate_cap;        // the runs' hand-off words (sdrfm_sink_tail.h), allocated at the first such call
+  unsigned long long* d_runstate; uint32_t runstate_cap;        // the runs' hand-off words (sdrfm_sink_chain.h), allocated at the first such call
   bool ovl_pending[2], ovl_bound[2], ovl_join_style;   // (bound: the latest kernel of stream k carries ovl_done[k] as its stop event; join_style: the caller joins after every call)
   uint32_t ovl_next;
   // the previous call's device buffer (valid after a SDRFM_F_DEVICE_PTRS call): what an overlapped call warms its streams up from
@@ -1709,23 +1709,23 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
   // whatever call comes next without the flag).  Any other call first orders the handle's stream behind the overlapped ones.
   // What the flag asks of the caller is checked where that is cheap: a call whose rows overlap the previous call's rows (one buffer used
   // for every call) or whose audio buffer is the one the previous overlapped call may still be writing runs as if the flag were absent.
-  // sdrfm_process_batch_pcm: will design Q's launch hold the sink's chain (sdrfm_sink_tail.h)?  Every stream's whole audio row from this launch (no routed stream,
+  // sdrfm_process_batch_pcm: will design Q's launch hold the sink's chain (sdrfm_sink_chain.h)?  Every stream's whole audio row from this launch (no routed stream,
   // no outputs the generic kernel recomputes behind it at the start of a stream), enough quads for runs longer than their predecessor's reach, a sink whose time
   // constant lets runs be sunk independently.  Any other call is followed by the sink's own kernel.
-  SdrfmSinkTail tail;
+  SdrfmSinkChain chain;
   const uint32_t q_quads = ((M + 7u) / 8u + 3u) / 4u;
-  bool with_tail = q_ok && h->pcm_sink && !mixed && !(h->n_seen + 1 < c.fir_taps) && q_quads >= 13u &&
-                   sdrfm_q_has_pcm_tail(h->q_c0, h->q_nslot, c.fir_decim, c.audio_decim) && sdrfm_sink_tail_params(h->pcm_sink, h->device, ns_all, &tail) == 2;
-  if (with_tail && !h->d_runstate) {                              // per-run hand-off words: SDRFM_TAIL_SETS sets of one word per workgroup of the largest grid
+  bool with_chain = q_ok && h->pcm_sink && !mixed && !(h->n_seen + 1 < c.fir_taps) && q_quads >= 13u &&
+                   sdrfm_q_has_pcm_chain(h->q_c0, h->q_nslot, c.fir_decim, c.audio_decim) && sdrfm_sink_chain_params(h->pcm_sink, h->device, ns_all, &chain) == 2;
+  if (with_chain && !h->d_runstate) {                              // per-run hand-off words: SDRFM_CHAIN_SETS sets of one word per workgroup of the largest grid
     h->runstate_cap = h->q_waves_per_cu * h->n_cu;
-    if (hipMalloc(&h->d_runstate, sizeof(unsigned long long) * SDRFM_TAIL_SETS * h->runstate_cap) != hipSuccess ||
+    if (hipMalloc(&h->d_runstate, sizeof(unsigned long long) * SDRFM_CHAIN_SETS * h->runstate_cap) != hipSuccess ||
         // (zeroed BEFORE any launch can see it: hipMemset alone may return before the device has done it, and the internal streams do not wait for the null stream —
         // a memset landing in the middle of the first launch wiped the runs' published words and their successors waited for ever)
-        hipMemsetAsync(h->d_runstate, 0, sizeof(unsigned long long) * SDRFM_TAIL_SETS * h->runstate_cap, h->stream) != hipSuccess ||
+        hipMemsetAsync(h->d_runstate, 0, sizeof(unsigned long long) * SDRFM_CHAIN_SETS * h->runstate_cap, h->stream) != hipSuccess ||
         hipStreamSynchronize(h->stream) != hipSuccess) {
       (void)hipGetLastError();
       if (h->d_runstate) (void)hipFree(h->d_runstate);
-      h->d_runstate = nullptr; with_tail = false;
+      h->d_runstate = nullptr; with_chain = false;
     }
   }
   const bool ovl = q_ok && (call_flags & SDRFM_F_OVERLAP) && h->prev_iq && h->n_seen + 1 >= c.fir_taps &&
@@ -1733,11 +1733,11 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
                    (h->prev_stride % 16 == 0) &&
                    !rows_overlap(h->prev_iq, h->prev_stride, h->prev_nbytes, d_iq, iq_stride, nbytes, c.n_streams) &&
                    // (a call that writes no audio — no buffer given, the chain inside the launch — has no audio rows to collide)
-                   !(!(with_tail && h->pcm_no_audio) && h->prev_ovl_audio &&
+                   !(!(with_chain && h->pcm_no_audio) && h->prev_ovl_audio &&
                      rows_overlap(reinterpret_cast<const uint8_t*>(h->prev_ovl_audio), h->prev_ovl_audio_stride * sizeof(float),
                                   h->prev_ovl_audio_n * sizeof(float), reinterpret_cast<const uint8_t*>(d_audio),
                                   audio_stride * sizeof(float), (size_t)A * sizeof(float), c.n_streams)) &&
-                   !(with_tail && h->prev_ovl_pcm && rows_overlap(reinterpret_cast<const uint8_t*>(h->prev_ovl_pcm), h->prev_ovl_pcm_stride * sizeof(int16_t),
+                   !(with_chain && h->prev_ovl_pcm && rows_overlap(reinterpret_cast<const uint8_t*>(h->prev_ovl_pcm), h->prev_ovl_pcm_stride * sizeof(int16_t),
                                                                    h->prev_ovl_audio_n * 2 * sizeof(int16_t), reinterpret_cast<const uint8_t*>(h->pcm_out),
                                                                    h->pcm_out_stride * sizeof(int16_t), (size_t)A * 2 * sizeof(int16_t), c.n_streams));
   if (!ovl) { const int jrc = join_overlap(h); if (jrc != SDRFM_OK) return jrc; }
@@ -1916,8 +1916,8 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
     const uint32_t min_steps = ((uint64_t)n_clean * (q_steps / 4) >= (uint64_t)q_total / 2) ? 4u : 2u;
     if (runs > q_steps / min_steps) runs = q_steps / min_steps;
     // (the sink's chain inside the launch: every run must own more outputs than its predecessor's state reaches — 13 quads: 12 owned = 76 audio outputs >=
-    // SDRFM_TAIL_FIX —: a small call is cut into fewer runs for it)
-    if (with_tail && runs > q_quads / 13u) runs = q_quads / 13u;
+    // SDRFM_CHAIN_FIX —: a small call is cut into fewer runs for it)
+    if (with_chain && runs > q_quads / 13u) runs = q_quads / 13u;
     if (runs < 1) runs = 1;
     q.runs = runs;
     // the window of per-stream repair statistics this call adds to (none while the set's previous read-back is still under way), and
@@ -1938,20 +1938,20 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
     // 100-call burst, +3 % per call; un-profiled within the noise): profiles/r05_q_experiments.txt item 15.
     const bool carry = ovl && h->ovl_join_style;
     if (carry) { done = h->ovl_done[k]; if (h->rt_win_used[k]) h->rt_win_need[k] = false; }
-    if (with_tail && (uint64_t)n_clean * runs > h->runstate_cap) with_tail = false;
+    if (with_chain && (uint64_t)n_clean * runs > h->runstate_cap) with_chain = false;
     if (fuse && pb_blocks) HIP_TRY(sdrfm_q_launch_mix(q, h->q_c0, h->q_nslot, c.fir_decim, c.audio_decim, pb, pb_blocks, pb_R, qs, done), SDRFM_FAIL);
-    else if (with_tail) {
-      tail.pcm = h->pcm_out; tail.pcm_stride = h->pcm_out_stride;
+    else if (with_chain) {
+      chain.pcm = h->pcm_out; chain.pcm_stride = h->pcm_out_stride;
       if (h->pcm_no_audio) q.audio = nullptr;
-      tail.runstate = h->d_runstate + (size_t)(tail.call % SDRFM_TAIL_SETS) * h->runstate_cap;
-      HIP_TRY(sdrfm_q_launch_pcm(q, tail, h->q_c0, h->q_nslot, c.fir_decim, c.audio_decim, qs, done), SDRFM_FAIL);
-      sdrfm_sink_tail_issued(h->pcm_sink);
+      chain.runstate = h->d_runstate + (size_t)(chain.call % SDRFM_CHAIN_SETS) * h->runstate_cap;
+      HIP_TRY(sdrfm_q_launch_pcm(q, chain, h->q_c0, h->q_nslot, c.fir_decim, c.audio_decim, qs, done), SDRFM_FAIL);
+      sdrfm_sink_chain_issued(h->pcm_sink);
       h->pcm_fused = true;
     }
     else HIP_TRY(sdrfm_q_launch(q, h->q_c0, h->q_nslot, c.fir_decim, c.audio_decim, qs, done), SDRFM_FAIL);
     if (ovl) { h->ovl_pending[k] = true; h->ovl_bound[k] = carry; }
-    h->prev_ovl_audio = (ovl && !(with_tail && h->pcm_no_audio)) ? d_audio : nullptr; h->prev_ovl_audio_stride = audio_stride; h->prev_ovl_audio_n = A;
-    h->prev_ovl_pcm = (ovl && with_tail) ? h->pcm_out : nullptr; h->prev_ovl_pcm_stride = h->pcm_out_stride;
+    h->prev_ovl_audio = (ovl && !(with_chain && h->pcm_no_audio)) ? d_audio : nullptr; h->prev_ovl_audio_stride = audio_stride; h->prev_ovl_audio_n = A;
+    h->prev_ovl_pcm = (ovl && with_chain) ? h->pcm_out : nullptr; h->prev_ovl_pcm_stride = h->pcm_out_stride;
     h->yprev_exact = false; h->hist_q_valid = true;
     if (h->rt_noisy && !h->rt_off) {
       h->rt_win_stages += (uint64_t)runs * ((q_steps / runs + c.audio_decim - 1) / c.audio_decim);   // audio stages of ONE stream's waves in this call
@@ -2053,7 +2053,7 @@ int sdrfm_process_batch(sdrfm_t* h, const uint8_t* iq, size_t iq_stride, uint32_
 }
 
 /* One call of the demodulator AND of the PCM sink (include/sdrfm.h).  Where design Q serves the whole call its launch ends with the sink's chain
- * (sdrfm_sink_tail.h: no second launch, no queue to wait on); any other call — bit-exact kernels, routed streams, the first call of a stream — is followed
+ * (sdrfm_sink_chain.h: no second launch, no queue to wait on); any other call — bit-exact kernels, routed streams, the first call of a stream — is followed
  * by the sink's stand-alone kernel on the handle's stream behind the call. */
 int sdrfm_process_batch_pcm(sdrfm_t* h, sdrfm_pcm_sink_t* sink, const uint8_t* iq, size_t iq_stride, uint32_t nbytes, float* audio, size_t audio_stride,
                             int16_t* pcm, size_t pcm_stride, uint32_t* n_audio, uint32_t flags) {
@@ -2079,8 +2079,8 @@ int sdrfm_process_batch_pcm(sdrfm_t* h, sdrfm_pcm_sink_t* sink, const uint8_t* i
     }
     audio = h->d_pcm_audio; audio_stride = h->pcm_audio_stride;
   }
-  SdrfmSinkTail probe;
-  if (sdrfm_sink_tail_params(sink, h->device, h->cfg.n_streams, &probe) == 0) return SDRFM_EINVAL;   // (a sink of this device and this many streams)
+  SdrfmSinkChain probe;
+  if (sdrfm_sink_chain_params(sink, h->device, h->cfg.n_streams, &probe) == 0) return SDRFM_EINVAL;   // (a sink of this device and this many streams)
   h->pcm_sink = sink; h->pcm_out = pcm; h->pcm_out_stride = pcm_stride; h->pcm_fused = false; h->pcm_no_audio = no_audio;
   const int rc = sdrfm_process_batch(h, iq, iq_stride, nbytes, audio, audio_stride, n_audio, flags);
   const bool fused = h->pcm_fused;

@@ -9,7 +9,7 @@
 #include <stdint.h>
 
 #include "sdrfm_q_host.h"
-#include "sdrfm_sink_tail.h"
+#include "sdrfm_sink_chain.h"
 
 struct SdrfmQParams {
   const uint8_t* iq;            // [n_streams][iq_stride] interleaved u8 I/Q (device), rows 16-byte aligned
@@ -68,9 +68,9 @@ int sdrfm_q_blocks_per_cu(uint32_t first_chunk, uint32_t nslot, uint32_t d, uint
 // Returns hipSuccess or the launch error.
 // done != nullptr: the event is signalled by the kernel's own completion (hipExtLaunchKernelGGL's stop event: no marker packet in the queue).
 hipError_t sdrfm_q_launch(const SdrfmQParams& p, uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da, hipStream_t stream, hipEvent_t done = nullptr);
-// the same launch with the PCM sink's chain as its tail (sdrfm_sink_tail.h): p must serve every stream of the handle that owns the sink's counters
-bool sdrfm_q_has_pcm_tail(uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da);
-hipError_t sdrfm_q_launch_pcm(const SdrfmQParams& p, const SdrfmSinkTail& t, uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da, hipStream_t stream,
+// the same launch with the PCM sink's chain as its tail (sdrfm_sink_chain.h): p must serve every stream of the handle that owns the sink's counters
+bool sdrfm_q_has_pcm_chain(uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da);
+hipError_t sdrfm_q_launch_pcm(const SdrfmQParams& p, const SdrfmSinkChain& t, uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da, hipStream_t stream,
                               hipEvent_t done = nullptr);
 const char* sdrfm_q_kernel_symbol(uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da);
 // ---- one launch for a mixed batch (sdrfm_q.hip: k_mix): b_blocks design-B workgroups (tile R = b_R; b as k_fastb takes it, fold_state = 1) over the

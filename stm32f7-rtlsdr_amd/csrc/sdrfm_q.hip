@@ -192,11 +192,11 @@ __device__ __forceinline__ void wait_vmcnt() {
 // The body of one workgroup (one wave): `bid` is its index among the launch's design-Q workgroups (the kernel's bid, or — in k_mix
 // below — its index among the workgroups that run this body).
 // PCM (k_mfir_pcm: the kernel argument is a QPcmArgs): every run also sinks its own audio outputs — de-emphasis, int16 pairs — where they are parked
-// (sdrfm_sink_tail.h); 256 bytes of LDS behind the workgroup's q_lds bytes hold the 64 outputs its predecessor's state still reaches.
+// (sdrfm_sink_chain.h); 256 bytes of LDS behind the workgroup's q_lds bytes hold the 64 outputs its predecessor's state still reaches.
 template <int D, int DA, int NSLOT>
 constexpr uint32_t q_lds() { return (uint32_t)(QGeo<D, DA>::PRE + 1024 * NSLOT + 4 * (QGeo<D, DA>::DBW + ABW + FLW + GTW)); }
-struct QPcmArgs { SdrfmQParams p; SdrfmSinkTail t; };
-static_assert(ABS * 128 <= 64 * (int)SDRFM_TAIL_CH, "a flush of parked audio is one scan of the wave");
+struct QPcmArgs { SdrfmQParams p; SdrfmSinkChain t; };
+static_assert(ABS * 128 <= 64 * (int)SDRFM_CHAIN_CH, "a flush of parked audio is one scan of the wave");
 template <int C0, int NSLOT, int D, int DA, bool PCM = false>
 __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t bid) {
   using G = QGeo<D, DA>;
@@ -515,11 +515,11 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
   [[maybe_unused]] float yrun = 0.0f;
   [[maybe_unused]] bool pfirst = true;
   [[maybe_unused]] float* const pstash = reinterpret_cast<float*>(smem + q_lds<D, DA, NSLOT>());
-  typedef const __attribute__((address_space(4))) SdrfmSinkTail* KTailPtr;
-  [[maybe_unused]] auto ktail = [&]() -> KTailPtr {
+  typedef const __attribute__((address_space(4))) SdrfmSinkChain* KChainPtr;
+  [[maybe_unused]] auto kchain = [&]() -> KChainPtr {
     const __attribute__((address_space(4))) unsigned char* pp = (const __attribute__((address_space(4))) unsigned char*)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(pp));
-    return (KTailPtr)(pp + offsetof(QPcmArgs, t));
+    return (KChainPtr)(pp + offsetof(QPcmArgs, t));
   };
   auto flush_audio = [&]() {
     __builtin_amdgcn_wave_barrier();
@@ -552,13 +552,13 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
       else if (v1) row[e + 1] = a1;
     }
     if constexpr (PCM) {
-      // ---- the sink's chain over the same outputs, where they lie (sdrfm_sink_tail.h): a blocked scan of the wave from the run's state so far (0 at its
-      // first flush); the packed words take the outputs' place in LDS and are stored as they lie.  The first SDRFM_TAIL_FIX outputs of the run are kept as
+      // ---- the sink's chain over the same outputs, where they lie (sdrfm_sink_chain.h): a blocked scan of the wave from the run's state so far (0 at its
+      // first flush); the packed words take the outputs' place in LDS and are stored as they lie.  The first SDRFM_CHAIN_FIX outputs of the run are kept as
       // values: the predecessor's state still reaches them (finished after the run's last step).
       const int cntf = hi_ - lo;
       if (cntf > 0) {
-        constexpr int PCH = (int)SDRFM_TAIL_CH, FIX = (int)SDRFM_TAIL_FIX;
-        const KTailPtr tp = ktail();
+        constexpr int PCH = (int)SDRFM_CHAIN_CH, FIX = (int)SDRFM_CHAIN_FIX;
+        const KChainPtr tp = kchain();
         const float alpha = tp->alpha, gain = tp->gain;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (the stores' operands have left the LDS)
         __builtin_amdgcn_wave_barrier();
@@ -976,20 +976,20 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
   wait_vmcnt<0>();                                              // nothing may still be in flight towards this wave's LDS when it ends
   flush_audio();
   if constexpr (PCM) {
-    // ---- the run's end state published, its predecessor's taken, the run's first outputs finished (sdrfm_sink_tail.h) ---------------------------------
-    const KTailPtr tp = ktail();
+    // ---- the run's end state published, its predecessor's taken, the run's first outputs finished (sdrfm_sink_chain.h) ---------------------------------
+    const KChainPtr tp = kchain();
     uint32_t st_ = stream, bid_ = bid;
     int ln_ = lane;
     asm volatile("" : "+s"(st_), "+s"(bid_), "+v"(ln_));
     const uint32_t call = tp->call, nst = tp->n_streams;
     unsigned long long* const rs = tp->runstate;
     unsigned long long* const sg = tp->sg;
-    const float dp = ln_ < (int)SDRFM_TAIL_FIX ? tp->dpow[ln_] : 0.0f;
+    const float dp = ln_ < (int)SDRFM_CHAIN_FIX ? tp->dpow[ln_] : 0.0f;
     unsigned long long pv = 0;
     if (ln_ == 0) {
       const unsigned long long w = ((unsigned long long)(call + 1u) << 32) | __builtin_bit_cast(unsigned, yrun);
-      __hip_atomic_store(last_run ? sg + (size_t)((call + 1u) % SDRFM_TAIL_SG_SLOTS) * nst + st_ : rs + bid_, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      unsigned long long* const src = run == 0 ? sg + (size_t)(call % SDRFM_TAIL_SG_SLOTS) * nst + st_ : rs + (bid_ - 1u);
+      __hip_atomic_store(last_run ? sg + (size_t)((call + 1u) % SDRFM_CHAIN_SG_SLOTS) * nst + st_ : rs + bid_, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned long long* const src = run == 0 ? sg + (size_t)(call % SDRFM_CHAIN_SG_SLOTS) * nst + st_ : rs + (bid_ - 1u);
       const uint32_t want = run == 0 ? call : call + 1u;
       unsigned long long zero = 0ull;
       asm volatile("" : "+v"(zero));                             // (opaque: "add 0" is a read-modify-write the compiler would turn back into a load, and a load may hit a stale line)
@@ -1004,7 +1004,7 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
       if (it == (1 << 19)) { pv = 0ull; __hip_atomic_store(tp->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     }
     const float carry = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane((int)(unsigned)pv));
-    const int nfix = (j1 - jlo < (int)SDRFM_TAIL_FIX) ? j1 - jlo : (int)SDRFM_TAIL_FIX;
+    const int nfix = (j1 - jlo < (int)SDRFM_CHAIN_FIX) ? j1 - jlo : (int)SDRFM_CHAIN_FIX;
     if (ln_ < nfix) {
       const float yv = __builtin_fmaf(dp, carry, pstash[ln_]);
       reinterpret_cast<unsigned*>(tp->pcm + (size_t)st_ * tp->pcm_stride)[jlo + ln_] = q_pcm_word(yv * tp->gain);
@@ -1052,7 +1052,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16
   mfir_body<C0, NSLOT, D, DA>(p, blockIdx.x);
 }
 
-// The same launch with the PCM sink's chain in it (round 6, sdrfm_sink_tail.h): every run sinks its own audio outputs.  A kernel of its own, so that the
+// The same launch with the PCM sink's chain in it (round 6, sdrfm_sink_chain.h): every run sinks its own audio outputs.  A kernel of its own, so that the
 // instruction stream of k_mfir does not change by a byte.
 template <int C0, int NSLOT, int D, int DA>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 16 ? 3 : 4))) k_mfir_pcm(QPcmArgs a) {
@@ -1121,7 +1121,7 @@ __global__ void __launch_bounds__(64) k_q_read_stream(const uint8_t* base, unsig
 typedef void (*QKernel)(SdrfmQParams);
 typedef void (*QPcmKernel)(QPcmArgs);
 struct QVariant { uint32_t c0, nslot, d, da, lds; QKernel k; const char* name; QPcmKernel kp; };
-// (the kernel with the PCM tail: for the ring sizes the library launches — sdrfm_q_default_nslot —, not for the experiments' 10 and 15)
+// (the kernel with the PCM chain: for the ring sizes the library launches — sdrfm_q_default_nslot —, not for the experiments' 10 and 15)
 #define QV(C0_, NS_) { C0_, NS_, 10, 5, q_lds<10, 5, NS_>(), k_mfir<C0_, NS_, 10, 5>, "k_mfir<" #C0_ "," #NS_ ">", NS_ == 5 ? k_mfir_pcm<C0_, 5, 10, 5> : nullptr }
 #define QVD(C0_, NS_, D_, DA_) { C0_, NS_, D_, DA_, q_lds<D_, DA_, NS_>(), k_mfir<C0_, NS_, D_, DA_>, "k_mfir<" #C0_ "," #NS_ "," #D_ "," #DA_ ">", k_mfir_pcm<C0_, NS_, D_, DA_> }
 // D = 10 / DA = 5: the 2.4 MS/s front end of BASELINE (ring of 5 KiB; 10 and 15 for experiments).  D = 8 / DA = 8: 2.048 MS/s -> 256 kS/s ->
@@ -1210,17 +1210,17 @@ hipError_t sdrfm_q_launch(const SdrfmQParams& p, uint32_t first_chunk, uint32_t 
   return hipGetLastError();
 }
 
-bool sdrfm_q_has_pcm_tail(uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da) {
+bool sdrfm_q_has_pcm_chain(uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da) {
   const QVariant* v = q_find(first_chunk, nslot, d, da);
   return v && v->kp;
 }
 
-hipError_t sdrfm_q_launch_pcm(const SdrfmQParams& p, const SdrfmSinkTail& t, uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da, hipStream_t stream,
+hipError_t sdrfm_q_launch_pcm(const SdrfmQParams& p, const SdrfmSinkChain& t, uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da, hipStream_t stream,
                               hipEvent_t done) {
   const QVariant* v = q_find(first_chunk, nslot, d, da);
   if (!v || !v->kp) return hipErrorInvalidValue;
   const QPcmArgs a = {p, t};
-  const uint32_t lds = v->lds + 4u * SDRFM_TAIL_FIX;             // (+ the run's first outputs, kept until its predecessor's state is there)
+  const uint32_t lds = v->lds + 4u * SDRFM_CHAIN_FIX;             // (+ the run's first outputs, kept until its predecessor's state is there)
   if (done) hipExtLaunchKernelGGL(v->kp, dim3(p.n_streams * p.runs), dim3(64), lds, stream, nullptr, done, 0, a);
   else hipLaunchKernelGGL(v->kp, dim3(p.n_streams * p.runs), dim3(64), lds, stream, a);
   return hipGetLastError();

@@ -40,7 +40,7 @@
 #include <new>
 
 #include "../../include/sdrfm.h"
-#include "sdrfm_sink_tail.h"
+#include "sdrfm_sink_chain.h"
 
 namespace {
 
@@ -49,7 +49,7 @@ struct SinkParams {
   size_t audio_stride;   // floats
   int16_t* pcm;
   size_t pcm_stride;     // int16 elements per stream (>= 2 * n)
-  const unsigned long long* sg_in;   // [n_streams] {tag << 32 | bits of y[n-1]}: the slot of the tag before this call (sdrfm_sink_tail.h) ...
+  const unsigned long long* sg_in;   // [n_streams] {tag << 32 | bits of y[n-1]}: the slot of the tag before this call (sdrfm_sink_chain.h) ...
   unsigned long long* sg_out;        // ... and of the tag behind it
   uint32_t gen_next;     // the tag behind this call
   uint32_t n_streams, n;
@@ -166,8 +166,8 @@ struct sdrfm_pcm_sink {
   float alpha, gain;
   int device;
   hipStream_t own_stream, stream;
-  unsigned long long* d_sg;   // [SDRFM_TAIL_SG_SLOTS][n_streams] {tag << 32 | bits of y[n-1]}, tag t in slot t % 8 (sdrfm_sink_tail.h)
-  float* d_dpow;       // [SDRFM_TAIL_FIX] (1 - alpha)^(k + 1)
+  unsigned long long* d_sg;   // [SDRFM_CHAIN_SG_SLOTS][n_streams] {tag << 32 | bits of y[n-1]}, tag t in slot t % 8 (sdrfm_sink_chain.h)
+  float* d_dpow;       // [SDRFM_CHAIN_FIX] (1 - alpha)^(k + 1)
   uint32_t calls;      // calls issued so far (mod 2^32): the tag d_sg holds when every one of them is through
   float* d_audio;      // staging for host-pointer calls
   int16_t* d_pcm;
@@ -194,25 +194,25 @@ static void sink_free(sdrfm_pcm_sink* k) {
   delete k;
 }
 
-// ---- the sink as the tail of a demodulator launch (sdrfm_sink_tail.h) ---------------------------------------------------------------------------------------
-int sdrfm_sink_tail_params(sdrfm_pcm_sink* k, int device, uint32_t n_streams, SdrfmSinkTail* out) {
+// ---- the sink inside a demodulator launch (sdrfm_sink_chain.h) ---------------------------------------------------------------------------------------
+int sdrfm_sink_chain_params(sdrfm_pcm_sink* k, int device, uint32_t n_streams, SdrfmSinkChain* out) {
   if (!k || !out || k->device != device || k->n_streams != n_streams) return 0;
   out->pcm = nullptr; out->pcm_stride = 0; out->runstate = nullptr;
-  out->sg = k->d_sg; out->n_streams = n_streams; out->dpow = k->d_dpow; out->err = reinterpret_cast<uint32_t*>(k->d_dpow + SDRFM_TAIL_FIX);
+  out->sg = k->d_sg; out->n_streams = n_streams; out->dpow = k->d_dpow; out->err = reinterpret_cast<uint32_t*>(k->d_dpow + SDRFM_CHAIN_FIX);
   out->call = k->calls;
   out->alpha = k->alpha; out->gain = k->gain;
-  out->pc = (float)pow(1.0 - (double)k->alpha, (double)SDRFM_TAIL_CH);
-  for (uint32_t q = 0; q < SDRFM_TAIL_CH; ++q) out->w[q] = (float)((double)k->alpha * pow(1.0 - (double)k->alpha, (double)(SDRFM_TAIL_CH - 1u - q)));
-  return k->alpha >= SDRFM_TAIL_MIN_ALPHA ? 2 : 1;
+  out->pc = (float)pow(1.0 - (double)k->alpha, (double)SDRFM_CHAIN_CH);
+  for (uint32_t q = 0; q < SDRFM_CHAIN_CH; ++q) out->w[q] = (float)((double)k->alpha * pow(1.0 - (double)k->alpha, (double)(SDRFM_CHAIN_CH - 1u - q)));
+  return k->alpha >= SDRFM_CHAIN_MIN_ALPHA ? 2 : 1;
 }
 
-void sdrfm_sink_tail_issued(sdrfm_pcm_sink* k) { ++k->calls; }
+void sdrfm_sink_chain_issued(sdrfm_pcm_sink* k) { ++k->calls; }
 
 int sdrfm_sink_launch_on(sdrfm_pcm_sink* k, const float* audio, size_t audio_stride, uint32_t n, int16_t* pcm, size_t pcm_stride, hipStream_t stream) {
   if (!k) return SDRFM_EINVAL;
   if (n == 0) return SDRFM_OK;
   SinkParams p;
-  p.sg_in = k->d_sg + (size_t)(k->calls % SDRFM_TAIL_SG_SLOTS) * k->n_streams; p.sg_out = k->d_sg + (size_t)((k->calls + 1u) % SDRFM_TAIL_SG_SLOTS) * k->n_streams;
+  p.sg_in = k->d_sg + (size_t)(k->calls % SDRFM_CHAIN_SG_SLOTS) * k->n_streams; p.sg_out = k->d_sg + (size_t)((k->calls + 1u) % SDRFM_CHAIN_SG_SLOTS) * k->n_streams;
   p.n_streams = k->n_streams; p.n = n; p.alpha = k->alpha; p.gain = k->gain;
   p.gen_next = k->calls + 1u;
   p.audio = audio; p.audio_stride = audio_stride; p.pcm = pcm; p.pcm_stride = pcm_stride;
@@ -238,12 +238,12 @@ int sdrfm_pcm_sink_create(uint32_t n_streams, float alpha, float gain, int32_t d
   memset(static_cast<void*>(k), 0, sizeof(*k));
   k->n_streams = n_streams; k->alpha = alpha; k->gain = gain; k->device = device;
   if (hipStreamCreateWithFlags(&k->own_stream, hipStreamNonBlocking) != hipSuccess ||
-      hipMalloc(&k->d_sg, sizeof(unsigned long long) * SDRFM_TAIL_SG_SLOTS * n_streams) != hipSuccess ||
-      hipMalloc(&k->d_dpow, sizeof(float) * (SDRFM_TAIL_FIX + 1)) != hipSuccess) { sink_free(k); return SDRFM_ENOMEM; }   // (+ the error word)
+      hipMalloc(&k->d_sg, sizeof(unsigned long long) * SDRFM_CHAIN_SG_SLOTS * n_streams) != hipSuccess ||
+      hipMalloc(&k->d_dpow, sizeof(float) * (SDRFM_CHAIN_FIX + 1)) != hipSuccess) { sink_free(k); return SDRFM_ENOMEM; }   // (+ the error word)
   {
-    float dp[SDRFM_TAIL_FIX + 1];
-    for (uint32_t i = 0; i < SDRFM_TAIL_FIX; ++i) dp[i] = (float)pow(1.0 - (double)alpha, (double)(i + 1));
-    dp[SDRFM_TAIL_FIX] = 0.0f;
+    float dp[SDRFM_CHAIN_FIX + 1];
+    for (uint32_t i = 0; i < SDRFM_CHAIN_FIX; ++i) dp[i] = (float)pow(1.0 - (double)alpha, (double)(i + 1));
+    dp[SDRFM_CHAIN_FIX] = 0.0f;
     if (hipMemcpy(k->d_dpow, dp, sizeof(dp), hipMemcpyHostToDevice) != hipSuccess) { sink_free(k); return SDRFM_FAIL; }
   }
   k->stream = k->own_stream;
@@ -263,8 +263,8 @@ void sdrfm_pcm_sink_destroy(sdrfm_pcm_sink_t* k) {
 int sdrfm_pcm_sink_reset(sdrfm_pcm_sink_t* k) {
   if (!k) return SDRFM_EINVAL;
   STRY(hipSetDevice(k->device), SDRFM_FAIL);
-  STRY(hipMemsetAsync(k->d_sg, 0, sizeof(unsigned long long) * SDRFM_TAIL_SG_SLOTS * k->n_streams, k->stream), SDRFM_FAIL);
-  STRY(hipMemsetAsync(k->d_dpow + SDRFM_TAIL_FIX, 0, sizeof(uint32_t), k->stream), SDRFM_FAIL);   // (the chain's error word)
+  STRY(hipMemsetAsync(k->d_sg, 0, sizeof(unsigned long long) * SDRFM_CHAIN_SG_SLOTS * k->n_streams, k->stream), SDRFM_FAIL);
+  STRY(hipMemsetAsync(k->d_dpow + SDRFM_CHAIN_FIX, 0, sizeof(uint32_t), k->stream), SDRFM_FAIL);   // (the chain's error word)
   STRY(hipStreamSynchronize(k->stream), SDRFM_FAIL);
   k->calls = 0;
   return SDRFM_OK;
@@ -278,11 +278,11 @@ int sdrfm_pcm_sink_set_stream(sdrfm_pcm_sink_t* k, void* hip_stream) {
   return SDRFM_OK;
 }
 
-// a run of a demodulator launch gave up waiting for its predecessor's word (sdrfm_sink_tail.h): the PCM since then is not to be trusted
+// a run of a demodulator launch gave up waiting for its predecessor's word (sdrfm_sink_chain.h): the PCM since then is not to be trusted
 static int sink_chain_error(sdrfm_pcm_sink* k) {
   uint32_t e = 0;
-  if (hipMemcpy(&e, k->d_dpow + SDRFM_TAIL_FIX, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return SDRFM_FAIL;
-  if (e) fprintf(stderr, "[sdrfm] PCM sink: a run of a demodulator launch waited in vain for its predecessor's state (csrc/sdrfm_sink_tail.h)\n");
+  if (hipMemcpy(&e, k->d_dpow + SDRFM_CHAIN_FIX, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return SDRFM_FAIL;
+  if (e) fprintf(stderr, "[sdrfm] PCM sink: a run of a demodulator launch waited in vain for its predecessor's state (csrc/sdrfm_sink_chain.h)\n");
   return e ? SDRFM_FAIL : SDRFM_OK;
 }
 
@@ -303,7 +303,7 @@ int sdrfm_pcm_sink_process_batch(sdrfm_pcm_sink_t* k, const float* audio, size_t
   if (pcm_stride & 1u) return SDRFM_EINVAL;                          // rows are written as (L,R) dwords
   STRY(hipSetDevice(k->device), SDRFM_FAIL);
   SinkParams p;
-  p.sg_in = k->d_sg + (size_t)(k->calls % SDRFM_TAIL_SG_SLOTS) * k->n_streams; p.sg_out = k->d_sg + (size_t)((k->calls + 1u) % SDRFM_TAIL_SG_SLOTS) * k->n_streams;
+  p.sg_in = k->d_sg + (size_t)(k->calls % SDRFM_CHAIN_SG_SLOTS) * k->n_streams; p.sg_out = k->d_sg + (size_t)((k->calls + 1u) % SDRFM_CHAIN_SG_SLOTS) * k->n_streams;
   p.n_streams = k->n_streams; p.n = n; p.alpha = k->alpha; p.gain = k->gain;
   p.gen_next = k->calls + 1u;
   const dim3 grid((k->n_streams + 63) / 64);
@@ -351,7 +351,7 @@ int sdrfm_pcm_sink_get_state(sdrfm_pcm_sink_t* k, float* state_out) {
   STRY(hipStreamSynchronize(k->stream), SDRFM_FAIL);
   unsigned long long* tmp = new (std::nothrow) unsigned long long[k->n_streams];
   if (!tmp) return SDRFM_ENOMEM;
-  const hipError_t e = hipMemcpy(tmp, k->d_sg + (size_t)(k->calls % SDRFM_TAIL_SG_SLOTS) * k->n_streams, sizeof(unsigned long long) * k->n_streams, hipMemcpyDeviceToHost);
+  const hipError_t e = hipMemcpy(tmp, k->d_sg + (size_t)(k->calls % SDRFM_CHAIN_SG_SLOTS) * k->n_streams, sizeof(unsigned long long) * k->n_streams, hipMemcpyDeviceToHost);
   for (uint32_t i = 0; e == hipSuccess && i < k->n_streams; ++i) { const unsigned b = (unsigned)tmp[i]; memcpy(state_out + i, &b, sizeof(float)); }
   delete[] tmp;
   return e == hipSuccess ? sink_chain_error(k) : SDRFM_FAIL;

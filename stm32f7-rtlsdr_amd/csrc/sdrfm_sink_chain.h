@@ -1,5 +1,5 @@
 /*
- * sdrfm_sink_tail.h — the PCM sink's chain INSIDE the demodulator's own launch (round 6).  Internal to the library: the
+ * sdrfm_sink_chain.h — the PCM sink's chain INSIDE the demodulator's own launch (round 6).  Internal to the library: the
  * interface between sdrfm_sink.hip (which owns the sink's state), sdrfm_q.hip (whose kernels run the chain) and sdrfm.hip (the C-ABI call
  * sdrfm_process_batch_pcm).
  *
@@ -27,40 +27,40 @@
  * word is never overwritten while a call that may still read it is incomplete); run 0 of call c + 1 waits (an s_sleep loop of one lane) for that tag.  Call c was launched before call c + 1 and none of its waves waits on anything but its own lower-numbered
  * neighbour, so it always gets there.  The stand-alone sink kernels keep sg up to date too (stream order), so the two styles can follow one another.
  */
-#ifndef SDRFM_SINK_TAIL_H
-#define SDRFM_SINK_TAIL_H
+#ifndef SDRFM_SINK_CHAIN_H
+#define SDRFM_SINK_CHAIN_H
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 struct sdrfm_pcm_sink;
 
-#define SDRFM_TAIL_FIX 64u        /* outputs of a run its predecessor's state still reaches */
-#define SDRFM_TAIL_CH 8u          /* samples per lane of a run's scan: 512 = the most design Q parks before it stores */
-#define SDRFM_TAIL_SETS 4u        /* sets of per-run words: calls c and c + 1 may be in flight together, c + 2 is ordered behind c */
-#define SDRFM_TAIL_SG_SLOTS 8u    /* slots of the per-stream word: tag t lives in slot t % 8.  Call t reads tag t; while call t is incomplete only calls t, t + 1 and
+#define SDRFM_CHAIN_FIX 64u        /* outputs of a run its predecessor's state still reaches */
+#define SDRFM_CHAIN_CH 8u          /* samples per lane of a run's scan: 512 = the most design Q parks before it stores */
+#define SDRFM_CHAIN_SETS 4u        /* sets of per-run words: calls c and c + 1 may be in flight together, c + 2 is ordered behind c */
+#define SDRFM_CHAIN_SG_SLOTS 8u    /* slots of the per-stream word: tag t lives in slot t % 8.  Call t reads tag t; while call t is incomplete only calls t, t + 1 and
                                      t + 3 can publish (t + 2 waits for t on its queue, t + 5 for t + 3, which needs t + 2's state): tags t + 1, t + 2, t + 4 — never t + 8 */
-#define SDRFM_TAIL_MIN_ALPHA 0.231f   /* (1 - alpha)^64 <= 5e-8: below it a run's end state would still depend on its predecessor's */
+#define SDRFM_CHAIN_MIN_ALPHA 0.231f   /* (1 - alpha)^64 <= 5e-8: below it a run's end state would still depend on its predecessor's */
 
-struct SdrfmSinkTail {
+struct SdrfmSinkChain {
   int16_t* pcm;                   // [n_streams][pcm_stride] interleaved (L, R) int16, rows 4-byte aligned
   size_t pcm_stride;              // int16 elements, even
-  unsigned long long* sg;         // [SDRFM_TAIL_SG_SLOTS][n_streams] {tag << 32 | bits of y[n-1]}: the stream's state behind `tag` calls, in slot tag % 8
+  unsigned long long* sg;         // [SDRFM_CHAIN_SG_SLOTS][n_streams] {tag << 32 | bits of y[n-1]}: the stream's state behind `tag` calls, in slot tag % 8
   uint32_t n_streams;             // of the handle (the slots' row length)
   unsigned long long* runstate;   // [grid] this call's set of per-run words {call + 1 << 32 | bits of the run's end state} (sdrfm.hip owns it)
-  const float* dpow;              // [SDRFM_TAIL_FIX] (1 - alpha)^(k + 1)
+  const float* dpow;              // [SDRFM_CHAIN_FIX] (1 - alpha)^(k + 1)
   uint32_t* err;                  // one word: set when a run gave up waiting for its predecessor's word (a protocol error: the sink reports it)
   uint32_t call;                  // this call's number (mod 2^32)
-  float alpha, gain, pc;          // pc = (1 - alpha)^SDRFM_TAIL_CH
-  float w[SDRFM_TAIL_CH];         // w[q] = alpha (1 - alpha)^(SDRFM_TAIL_CH - 1 - q): what sample q of a chunk adds to the chunk's last output
+  float alpha, gain, pc;          // pc = (1 - alpha)^SDRFM_CHAIN_CH
+  float w[SDRFM_CHAIN_CH];         // w[q] = alpha (1 - alpha)^(SDRFM_CHAIN_CH - 1 - q): what sample q of a chunk adds to the chunk's last output
 };
 
 // ---- host side (sdrfm_sink.hip) ---------------------------------------------------------------------------------------------------------------------------
 // The parameters for the sink's NEXT call (pcm / pcm_stride / runstate left for the caller to fill).  0: the sink does not fit the handle (other device, other
-// stream count); 1: it fits, but its time constant is too long for runs to be sunk independently (alpha < SDRFM_TAIL_MIN_ALPHA): stand-alone kernel only; 2: fits.
-int sdrfm_sink_tail_params(sdrfm_pcm_sink* k, int device, uint32_t n_streams, SdrfmSinkTail* out);
+// stream count); 1: it fits, but its time constant is too long for runs to be sunk independently (alpha < SDRFM_CHAIN_MIN_ALPHA): stand-alone kernel only; 2: fits.
+int sdrfm_sink_chain_params(sdrfm_pcm_sink* k, int device, uint32_t n_streams, SdrfmSinkChain* out);
 // The launch that carried `out` is in the queue: the sink's call counter moves on.
-void sdrfm_sink_tail_issued(sdrfm_pcm_sink* k);
+void sdrfm_sink_chain_issued(sdrfm_pcm_sink* k);
 // The stand-alone blocked scan on `stream` (device buffers), as one call of the sink: what a call that no kernel with the chain served is followed by.
 int sdrfm_sink_launch_on(sdrfm_pcm_sink* k, const float* audio, size_t audio_stride, uint32_t n, int16_t* pcm, size_t pcm_stride, hipStream_t stream);
 

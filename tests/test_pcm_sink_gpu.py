@@ -217,7 +217,7 @@ def test_consumer_on_its_own_stream_behind_wait_previous(pkg):
             assert np.abs(got[k][s].astype(np.int32) - want.astype(np.int32)).max() <= 1, (s, k)
 
 
-# ---- the sink's chain as the TAIL of the demodulator's launch (sdrfm_process_batch_pcm, csrc/sdrfm_sink_tail.h) ---------------------------------------------
+# ---- the sink's chain as the TAIL of the demodulator's launch (sdrfm_process_batch_pcm, csrc/sdrfm_sink_chain.h) ---------------------------------------------
 def _host_chain(pkg, auds, alpha, gain, s):
     """PCM of stream s over the calls' audio, by the host routine carrying its state from call to call."""
     st, out = 0.0, []
@@ -228,7 +228,7 @@ def _host_chain(pkg, auds, alpha, gain, s):
 
 
 @pytest.mark.parametrize("overlap", [False, True])
-def test_pcm_tail_of_the_demodulators_launch(pkg, overlap):
+def test_pcm_chain_inside_the_demodulators_launch(pkg, overlap):
     """sdrfm_process_batch_pcm over nine consecutive pieces of a capture: the first call (the start of a stream: the generic kernel recomputes its first outputs
     behind design Q's launch) is followed by the sink's own kernel, every later one ends with the sink's chain in design Q's own launch ("+ pcm"); the PCM of
     every call within 1 LSB of host-sinking that call's audio with the state carried across all of them, the carried state within 1e-6."""
@@ -263,7 +263,7 @@ def test_pcm_tail_of_the_demodulators_launch(pkg, overlap):
         assert abs(state[s] - st) <= 1e-6 * max(abs(st), 0.25), (s, state[s], st)
 
 
-def test_pcm_tail_rows_that_are_not_16_byte_aligned_and_ragged_lengths(pkg):
+def test_pcm_chain_rows_that_are_not_16_byte_aligned_and_odd_lengths(pkg):
     """The tail's two data paths: rows 16-byte aligned (four samples per instruction) or not (audio stride 961 floats), a call whose audio length is no multiple
     of the tail's 76-sample chunks (968 outputs: the last lane's chunk is short), and a call longer than one segment of 4864 (0.12 s: 5760 outputs)."""
     import torch
@@ -294,7 +294,7 @@ def test_pcm_tail_rows_that_are_not_16_byte_aligned_and_ragged_lengths(pkg):
 
 
 def test_pcm_call_on_the_bit_exact_kernels_and_on_routed_streams(pkg):
-    """Calls no kernel with a tail serves — a bit-exact handle; a batch with routed noise-only streams (one launch of both designs) — are followed by the sink's own
+    """Calls no kernel with the chain serves — a bit-exact handle; a batch with routed noise-only streams (one launch of both designs) — are followed by the sink's own
     kernel; a sequence that switches between the two styles carries the state through (the device-side order between calls: gen)."""
     import torch
     alpha, gain = _params(pkg)
@@ -443,3 +443,31 @@ def test_pcm_chain_at_the_other_front_end_rates(pkg, fs, decim, adecim, taps):
         for k in range(nb):
             d = np.abs(got[k][s].astype(np.int32) - want[k].astype(np.int32))
             assert d.max() <= 1, (s, k, int(d.max()))
+
+
+@pytest.mark.parametrize("taps", [16, 64])
+def test_pcm_chain_for_one_dongle(pkg, taps):
+    """BASELINE configs[1]'s shape through the PCM call: ONE stream, a second of IQ per call — hundreds of short runs of one stream, each finishing its first 64 outputs
+    with its neighbour's state."""
+    import torch
+    alpha, gain = _params(pkg)
+    nsamp, nb = 2400000, 3
+    na = nsamp // 50
+    h, g = pkg.default_config(taps)
+    iq = torch.from_numpy(pkg.make_iq(1, nb * nsamp, mode="fm", first_id=4300)).cuda()
+    audio = [torch.zeros((1, na), dtype=torch.float32, device="cuda") for _ in range(nb)]
+    pcm = [torch.zeros((1, 2 * na), dtype=torch.int16, device="cuda") for _ in range(nb)]
+    torch.cuda.synchronize()
+    with pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=1, max_bytes_per_call=2 * nsamp)) as dm, pkg.PcmSink(1, alpha, gain) as sink:
+        for k in range(nb):
+            assert dm.process_batch_pcm_device(sink, iq[:, 2 * k * nsamp:], audio[k], pcm[k], nbytes=2 * nsamp, overlap=True) == na
+            assert ("+ pcm" in dm.kernel_name) == (k > 0), dm.kernel_name
+        dm.synchronize()
+        assert sink.synchronize_status() == 0
+        state = sink.state()
+    auds = [a.cpu().numpy() for a in audio]
+    want, st = _host_chain(pkg, auds, alpha, gain, 0)
+    for k in range(nb):
+        d = np.abs(pcm[k][0].cpu().numpy().astype(np.int32) - want[k].astype(np.int32))
+        assert d.max() <= 1, (k, int(d.max()), int(np.argmax(d)))
+    assert abs(state[0] - st) <= 1e-6 * max(abs(st), 0.25)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/fuzz_pcm.py [seconds=120] [seed=1] — soak of sdrfm_process_batch_pcm (the PCM sink inside the demodulator's launch, csrc/sdrfm_sink_tail.h): random
+"""tools/fuzz_pcm.py [seconds=120] [seed=1] — soak of sdrfm_process_batch_pcm (the PCM sink inside the demodulator's launch, csrc/sdrfm_sink_chain.h): random
 stream counts, call lengths, call styles (overlapped or not, with or without an audio buffer), time constants, resets and routed streams; every call's PCM of a few
 streams against the host routine carried over the calls' audio (1 LSB), and the sink must report no chain error.  Prints one summary line; exit status 1 on a failure.
 Measurement / test infrastructure: uses the oracle-free host routine sdrfm_pcm_deemph_s16 as the checker of the sink only (the audio itself is design Q's, held to the
