@@ -535,7 +535,7 @@ def main():
     # what a consumer of the audio gets: the same overlapped calls made through sdrfm_process_batch_pcm — the board's sink format
     # (de-emphasis, int16 L = R) out of the demodulator's own launch —, steady state, with and without the float audio stored beside the PCM
     consumer = None
-    if steady_ovl and overlap and not args.dev_library and args.iq_class == "fm" and not args.no_consumer_leg:
+    if steady_ovl and overlap and not args.dev_library and not args.no_consumer_leg:
         alpha, gain = float(pkg.load_library().sdrfm_pcm_alpha(48000.0, 75e-6)), float(32767.0 / (2 * np.pi * 75e3 / (fs / D)))
         with torch.cuda.stream(stream):
             pcm_ring = [torch.zeros((ns, 2 * n_audio_max + 2), dtype=torch.int16, device="cuda") for _ in range(3)]

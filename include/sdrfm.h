@@ -338,8 +338,10 @@ int  sdrfm_pcm_sink_get_state(sdrfm_pcm_sink_t* k, float* state_out /* n_streams
  * Where the matrix-pipe kernel serves the whole call, the sink's chain runs INSIDE its launch (csrc/sdrfm_sink_chain.h): the de-emphasis forgets — (1 - alpha)^64
  * is below rounding —, so every wave sinks the ~400 outputs it has just computed where they lie, publishes its end state in one word, and finishes its first 64
  * outputs with its neighbour's.  No second launch, no stream to order, nothing between two overlapped calls: the consumer loop of INTEGRATION.md section 3 runs
- * within 10 % of the demodulator's own rate (profiles/r06_sink.txt).  Any other call (the bit-exact kernels, routed streams, the first call of a stream, a sink
- * whose alpha is below 0.231) is followed by the sink's own kernel on the handle's stream, behind a join of the overlapped calls.
+ * within 10 % of the demodulator's own rate (profiles/r06_sink.txt).  A batch with streams routed to the bit-exact kernels keeps the chain for the others (both
+ * designs in one launch) and is followed, on the call's own queue, by the sink's kernel over the routed streams only (+4.5 us per call).  Any other call (the
+ * bit-exact kernels alone, the first call of a stream, a sink whose alpha is below 0.231) is followed by the sink's own kernel on the handle's stream, behind a join
+ * of the overlapped calls.
  * Same results either way up to the blocked scan's tolerance: PCM within 1 LSB of sdrfm_pcm_deemph_s16's, state within 1e-6 relative.
  * audio may be NULL: the PCM is then all the call leaves (a launch that holds the chain does not store the float audio at all; other calls use rows of the
  * library's own); otherwise the audio is written as by sdrfm_process_batch.

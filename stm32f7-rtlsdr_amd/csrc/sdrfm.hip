@@ -1023,7 +1023,7 @@ struct sdrfm {
   hipEvent_t ovl_in, ovl_done[2];
   // sdrfm_process_batch_pcm: the sink whose chain the call's design-Q launch ends with (sdrfm_sink_chain.h); pcm_fused: that launch took it
   sdrfm_pcm_sink* pcm_sink; int16_t* pcm_out; size_t pcm_out_stride; bool pcm_fused;
-  bool pcm_no_audio; float* d_pcm_audio; size_t pcm_audio_stride; uint32_t pcm_audio_cap;   // a call without an audio buffer: the library's own, for the calls that need one
+  bool pcm_no_audio; float* d_pcm_audio; size_t pcm_audio_stride; uint32_t pcm_audio_cap, pcm_audio_flip;   // a call without an audio buffer: the library's own, for the calls that need one
   const int16_t* prev_ovl_pcm; size_t prev_ovl_pcm_stride;       // the PCM rows the previous overlapped call may still be writing
   unsigned long long* d_runstate; uint32_t runstate_cap;        // the runs' hand-off words (sdrfm_sink_chain.h), allocated at the first such call
   bool ovl_pending[2], ovl_bound[2], ovl_join_style;   // (bound: the latest kernel of stream k carries ovl_done[k] as its stop event; join_style: the caller joins after every call)
@@ -1714,7 +1714,10 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
   // constant lets runs be sunk independently.  Any other call is followed by the sink's own kernel.
   SdrfmSinkChain chain;
   const uint32_t q_quads = ((M + 7u) / 8u + 3u) / 4u;
-  bool with_chain = q_ok && h->pcm_sink && !mixed && !(h->n_seen + 1 < c.fir_taps) && q_quads >= 13u &&
+  // (a batch with routed streams: where both designs go out in ONE launch — fuse, below — its design-Q workgroups hold the chain for the clean streams and the sink's
+  // list kernel follows on the same queue for the routed ones)
+  const bool fuse_early = mixed && h->mix_lds && fast_ok && h->fast_mix && M >= c.audio_taps && h->fold_state_ok;
+  bool with_chain = q_ok && h->pcm_sink && (!mixed || fuse_early) && !(h->n_seen + 1 < c.fir_taps) && q_quads >= 13u &&
                    sdrfm_q_has_pcm_chain(h->q_c0, h->q_nslot, c.fir_decim, c.audio_decim) && sdrfm_sink_chain_params(h->pcm_sink, h->device, ns_all, &chain) == 2;
   if (with_chain && !h->d_runstate) {                              // per-run hand-off words: SDRFM_CHAIN_SETS sets of one word per workgroup of the largest grid
     h->runstate_cap = h->q_waves_per_cu * h->n_cu;
@@ -1791,7 +1794,7 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
   // waves are the longer ones).
   // Where the shape has a one-launch kernel (k_mix) both kinds of workgroup go out in ONE grid that fills the machine once: the wave slots are dealt out by
   // the same shares, a design-B segment is about as long as a design-Q run, and neither launch waits for the other.
-  const bool fuse = mixed && h->mix_lds && fast_ok && h->fast_mix && M >= c.audio_taps && h->fold_state_ok;
+  const bool fuse = fuse_early;
   uint32_t q_total = h->q_waves_per_cu * h->n_cu, bx_waves = h->waves_target;   // design Q's workgroups, the bit-exact kernels' waves
   if (mixed) {
     const double cost = fuse ? h->mix_cost : 2.0;
@@ -1939,7 +1942,19 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
     const bool carry = ovl && h->ovl_join_style;
     if (carry) { done = h->ovl_done[k]; if (h->rt_win_used[k]) h->rt_win_need[k] = false; }
     if (with_chain && (uint64_t)n_clean * runs > h->runstate_cap) with_chain = false;
-    if (fuse && pb_blocks) HIP_TRY(sdrfm_q_launch_mix(q, h->q_c0, h->q_nslot, c.fir_decim, c.audio_decim, pb, pb_blocks, pb_R, qs, done), SDRFM_FAIL);
+    if (fuse && pb_blocks && with_chain) {
+      // one launch of both designs with the chain in design Q's workgroups, then the sink's list kernel for the routed streams on the same queue (their audio is the
+      // launch's design-B workgroups'); the call's completion event rides on that last kernel
+      chain.pcm = h->pcm_out; chain.pcm_stride = h->pcm_out_stride;
+      if (h->pcm_no_audio) q.audio = nullptr;                      // (the clean streams store no audio; the routed ones' goes to the library's own rows)
+      chain.runstate = h->d_runstate + (size_t)(chain.call % SDRFM_CHAIN_SETS) * h->runstate_cap;
+      HIP_TRY(sdrfm_q_launch_mix_pcm(q, chain, h->q_c0, h->q_nslot, c.fir_decim, c.audio_decim, pb, pb_blocks, pb_R, qs, nullptr), SDRFM_FAIL);
+      { const int lrc = sdrfm_sink_launch_list_on(h->pcm_sink, chain, list_dev + n_clean, n_noisy, d_audio, audio_stride, A, h->pcm_out, h->pcm_out_stride, qs, done);
+        if (lrc != SDRFM_OK) return lrc; }
+      sdrfm_sink_chain_issued(h->pcm_sink);
+      h->pcm_fused = true;
+    }
+    else if (fuse && pb_blocks) HIP_TRY(sdrfm_q_launch_mix(q, h->q_c0, h->q_nslot, c.fir_decim, c.audio_decim, pb, pb_blocks, pb_R, qs, done), SDRFM_FAIL);
     else if (with_chain) {
       chain.pcm = h->pcm_out; chain.pcm_stride = h->pcm_out_stride;
       if (h->pcm_no_audio) q.audio = nullptr;
@@ -2053,7 +2068,8 @@ int sdrfm_process_batch(sdrfm_t* h, const uint8_t* iq, size_t iq_stride, uint32_
 }
 
 /* One call of the demodulator AND of the PCM sink (include/sdrfm.h).  Where design Q serves the whole call its launch ends with the sink's chain
- * (sdrfm_sink_chain.h: no second launch, no queue to wait on); any other call — bit-exact kernels, routed streams, the first call of a stream — is followed
+ * (sdrfm_sink_chain.h: no second launch, no queue to wait on; a batch with routed streams: the sink's list kernel for those on the call's own queue); any other
+ * call — bit-exact kernels alone, the first call of a stream — is followed
  * by the sink's stand-alone kernel on the handle's stream behind the call. */
 int sdrfm_process_batch_pcm(sdrfm_t* h, sdrfm_pcm_sink_t* sink, const uint8_t* iq, size_t iq_stride, uint32_t nbytes, float* audio, size_t audio_stride,
                             int16_t* pcm, size_t pcm_stride, uint32_t* n_audio, uint32_t flags) {
@@ -2074,10 +2090,12 @@ int sdrfm_process_batch_pcm(sdrfm_t* h, sdrfm_pcm_sink_t* sink, const uint8_t* i
       if (h->d_pcm_audio) (void)hipFree(h->d_pcm_audio);
       h->d_pcm_audio = nullptr; h->pcm_audio_cap = 0;
       const uint32_t cap = (A + 63u) & ~63u;
-      if (hipMalloc(&h->d_pcm_audio, sizeof(float) * (size_t)cap * h->cfg.n_streams) != hipSuccess) { (void)hipGetLastError(); return SDRFM_ENOMEM; }
+      if (hipMalloc(&h->d_pcm_audio, 2 * sizeof(float) * (size_t)cap * h->cfg.n_streams) != hipSuccess) { (void)hipGetLastError(); return SDRFM_ENOMEM; }
       h->pcm_audio_cap = cap; h->pcm_audio_stride = cap;
     }
-    audio = h->d_pcm_audio; audio_stride = h->pcm_audio_stride;
+    // two sets of rows in turn: the routed streams of an overlapped call write theirs while the previous call's are still being read
+    h->pcm_audio_flip ^= 1u;
+    audio = h->d_pcm_audio + (size_t)h->pcm_audio_flip * h->pcm_audio_cap * h->cfg.n_streams; audio_stride = h->pcm_audio_stride;
   }
   SdrfmSinkChain probe;
   if (sdrfm_sink_chain_params(sink, h->device, h->cfg.n_streams, &probe) == 0) return SDRFM_EINVAL;   // (a sink of this device and this many streams)

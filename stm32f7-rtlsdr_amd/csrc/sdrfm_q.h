@@ -80,6 +80,9 @@ uint32_t sdrfm_q_mix_lds(uint32_t first_chunk, uint32_t nslot, uint32_t d, uint3
 int sdrfm_q_mix_blocks_per_cu(uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da, uint32_t T, uint32_t b_R);
 hipError_t sdrfm_q_launch_mix(const SdrfmQParams& q, uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da, const CallParams& b, uint32_t b_blocks,
                               uint32_t b_R, hipStream_t stream, hipEvent_t done);
+// the same launch with the PCM sink's chain in its design-Q workgroups (sdrfm_sink_chain.h): the clean streams' PCM; q.slist's streams only
+hipError_t sdrfm_q_launch_mix_pcm(const SdrfmQParams& q, const SdrfmSinkChain& t, uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da, const CallParams& b,
+                                  uint32_t b_blocks, uint32_t b_R, hipStream_t stream, hipEvent_t done);
 // yprev[s] = the definition's y[-1] of stream s from the SDRFM_Q_TP raw samples in hist_q (a bit-exact kernel takes over from design Q)
 // (of the streams list[0 .. n_streams), or of streams 0 .. n_streams-1 when list is nullptr)
 hipError_t sdrfm_q_fix_yprev(const uint8_t* hist_q, const float* hpad, float2* yprev, uint32_t n_streams, const uint32_t* list, hipStream_t stream);

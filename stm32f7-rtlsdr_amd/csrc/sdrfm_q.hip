@@ -1073,6 +1073,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4)))
   else mfir_body<C0, NSLOT, D, DA>(q, blockIdx.x - nb);
 }
 
+// ... with the PCM sink's chain in the design-Q workgroups (the clean streams; the noisy streams' audio is sunk by the sink's own list kernel behind this launch:
+// sdrfm.hip).  The argument's first member is k_mfir_pcm's argument: the body reads both parts through the same offsets.
+struct MixPcmArgs { QPcmArgs qa; CallParams b; uint32_t nb; };
+template <int C0, int NSLOT, int D, int DA, int T, int R>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) k_mix_pcm(MixPcmArgs a) {
+  if (blockIdx.x < a.nb) fastb_body<T, D, R, (int)SDRFM_Q_TA, DA, 0>(a.b, blockIdx.x);
+  else mfir_body<C0, NSLOT, D, DA, true>(a.qa.p, blockIdx.x - a.nb);
+}
+
 // y[-1] as the definition has it, from the 64 raw samples before the next call (hist_q) — for a bit-exact kernel that takes over from
 // design Q (whose own carried y[-1] is only within 1e-4 of it).  One lane per stream; the chain of sdrfm_math.h / DESIGN.md "Frozen spec".
 __global__ void __launch_bounds__(64) k_q_fix_yprev(const uint8_t* hist_q, const float* hpad, float2* yprev, uint32_t n_streams, const uint32_t* list) {
@@ -1137,12 +1146,18 @@ const QVariant* q_find(uint32_t c0, uint32_t nslot, uint32_t d, uint32_t da) {
 
 // ---- the one-launch kernel of a mixed batch: every shape both designs serve (where design B has no instance the host launches two kernels) ----------
 typedef void (*MixKernel)(SdrfmQParams, CallParams, uint32_t);
-struct MixVariant { uint32_t c0, nslot, d, da, T, R, lds; MixKernel k; };
+typedef void (*MixPcmKernel)(MixPcmArgs);
+struct MixVariant { uint32_t c0, nslot, d, da, T, R, lds; MixKernel k; MixPcmKernel kp; uint32_t lds_pcm; };
 template <int T, int D, int R, int TA>
 constexpr uint32_t b_lds() { return (uint32_t)fastb_xbytes(T, D, R) + 4u * (uint32_t)(((TA - 1 + 3) & ~3) + fastb_ab(R) * 64 * R + T + TA); }   // as sdrfm.hip sizes design B's workgroup
 template <int C0, int NSLOT, int D, int DA, int T, int R>
 constexpr uint32_t mix_lds() { return q_lds<D, DA, NSLOT>() > b_lds<T, D, R, (int)SDRFM_Q_TA>() ? q_lds<D, DA, NSLOT>() : b_lds<T, D, R, (int)SDRFM_Q_TA>(); }
-#define MV(C0_, NS_, D_, DA_, T_, R_) { C0_, NS_, D_, DA_, T_, R_, mix_lds<C0_, NS_, D_, DA_, T_, R_>(), k_mix<C0_, NS_, D_, DA_, T_, R_> }
+template <int C0, int NSLOT, int D, int DA, int T, int R>
+constexpr uint32_t mix_lds_pcm() {   // (design Q's workgroups keep SDRFM_CHAIN_FIX words behind their own bytes)
+  return q_lds<D, DA, NSLOT>() + 4u * SDRFM_CHAIN_FIX > b_lds<T, D, R, (int)SDRFM_Q_TA>() ? q_lds<D, DA, NSLOT>() + 4u * SDRFM_CHAIN_FIX : b_lds<T, D, R, (int)SDRFM_Q_TA>();
+}
+#define MV(C0_, NS_, D_, DA_, T_, R_) { C0_, NS_, D_, DA_, T_, R_, mix_lds<C0_, NS_, D_, DA_, T_, R_>(), k_mix<C0_, NS_, D_, DA_, T_, R_>, \
+                                        k_mix_pcm<C0_, NS_, D_, DA_, T_, R_>, mix_lds_pcm<C0_, NS_, D_, DA_, T_, R_>() }
 // (design B's tile: R = 4 everywhere; R = 8 — 12.9 KB of LDS — measured no faster at the BASELINE shape)
 const MixVariant kMixVariants[] = {MV(0, 5, 10, 5, 64, 4), MV(1, 5, 10, 5, 64, 4), MV(0, 5, 10, 5, 32, 4), MV(1, 5, 10, 5, 32, 4), MV(0, 5, 10, 5, 16, 4), MV(1, 5, 10, 5, 16, 4),
                                    MV(0, 4, 8, 8, 64, 4), MV(1, 4, 8, 8, 64, 4), MV(0, 4, 8, 8, 16, 4), MV(1, 4, 8, 8, 16, 4), MV(0, 8, 16, 5, 64, 4), MV(1, 8, 16, 5, 64, 4)};
@@ -1173,6 +1188,15 @@ hipError_t sdrfm_q_launch_mix(const SdrfmQParams& q, uint32_t first_chunk, uint3
   const MixVariant* v = mix_find(first_chunk, nslot, d, da, b.T, b_R);
   if (!v || b.Ta != SDRFM_Q_TA || b.Da != da || b.D != d) return hipErrorInvalidValue;
   hipExtLaunchKernelGGL(v->k, dim3(b_blocks + q.n_streams * q.runs), dim3(64), v->lds, stream, nullptr, done, 0, q, b, b_blocks);
+  return hipGetLastError();
+}
+
+hipError_t sdrfm_q_launch_mix_pcm(const SdrfmQParams& q, const SdrfmSinkChain& t, uint32_t first_chunk, uint32_t nslot, uint32_t d, uint32_t da, const CallParams& b,
+                                  uint32_t b_blocks, uint32_t b_R, hipStream_t stream, hipEvent_t done) {
+  const MixVariant* v = mix_find(first_chunk, nslot, d, da, b.T, b_R);
+  if (!v || b.Ta != SDRFM_Q_TA || b.Da != da || b.D != d) return hipErrorInvalidValue;
+  const MixPcmArgs a = {{q, t}, b, b_blocks};
+  hipExtLaunchKernelGGL(v->kp, dim3(b_blocks + q.n_streams * q.runs), dim3(64), v->lds_pcm, stream, nullptr, done, 0, a);
   return hipGetLastError();
 }
 

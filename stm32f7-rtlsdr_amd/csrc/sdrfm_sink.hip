@@ -32,6 +32,7 @@
  * (profiles/r06_sink.txt).
  */
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdint>
@@ -94,14 +95,36 @@ __global__ void __launch_bounds__(64) k_pcm_sink(SinkParams p) {
 // 0.9 KiB of a CU's LDS: 10.5 us alone against 7.4 us for this one, and no faster in the consumer loop — profiles/r06_sink.txt.  Not kept.)
 constexpr uint32_t SINK_NT = 256, SINK_C = 19, SINK_SEG = SINK_NT * SINK_C;   // 4864 samples per segment (BASELINE's 4800 per call: one segment), 19 KiB of LDS;
                                                                              // lanes SINK_C = 19 words apart (odd): conflict-free LDS accesses
-__global__ void __launch_bounds__(256) k_pcm_sink_scan(SinkParams p, float pc) {
+// LIST: the workgroup's stream is list[blockIdx.x], and the call is PART of a sink call whose other streams the chain inside a demodulator launch serves
+// (sdrfm_sink_chain.h): the state is taken by that protocol — the tagged word of slot sg_in, waited for on the device (bounded) — and published the same way.
+template <bool LIST>
+__global__ void __launch_bounds__(256) k_pcm_sink_scan(SinkParams p, float pc, const uint32_t* list, uint32_t* err) {
   __shared__ float x[SINK_SEG];                                 // the segment's samples, then (in place) the packed PCM words
   __shared__ float sc[SINK_NT];                                 // the scan
   unsigned* const xw = reinterpret_cast<unsigned*>(x);
-  const uint32_t s = blockIdx.x, t = threadIdx.x;
+  const uint32_t s = LIST ? list[blockIdx.x] : blockIdx.x, t = threadIdx.x;
   const float* const row = p.audio + (size_t)s * p.audio_stride;
   unsigned* const out = reinterpret_cast<unsigned*>(p.pcm + (size_t)s * p.pcm_stride);
-  float y0 = __uint_as_float((unsigned)p.sg_in[s]);             // the state before the segment (every lane holds it)
+  float y0;                                                     // the state before the segment (every lane holds it)
+  if constexpr (LIST) {
+    if (t == 0) {
+      unsigned long long pv = 0ull, zero = 0ull;
+      asm volatile("" : "+v"(zero));                             // (an opaque 0: a read-modify-write the compiler cannot turn back into a load, which may hit a stale line)
+      int it = 0;
+      for (;; ++it) {
+        pv = __hip_atomic_fetch_add(const_cast<unsigned long long*>(p.sg_in) + s, zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(pv >> 32) == p.gen_next - 1u || it == (1 << 19)) break;
+        __builtin_amdgcn_s_sleep(16);
+      }
+      if (it == (1 << 19)) { pv = 0ull; __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      sc[0] = __uint_as_float((unsigned)pv);
+    }
+    __syncthreads();
+    y0 = sc[0];
+    __syncthreads();
+  } else {
+    y0 = __uint_as_float((unsigned)p.sg_in[s]);
+  }
   for (uint32_t base = 0; base < p.n; base += SINK_SEG) {
     const uint32_t m = (p.n - base < SINK_SEG) ? p.n - base : SINK_SEG;   // samples of this segment
 #pragma unroll
@@ -156,7 +179,11 @@ __global__ void __launch_bounds__(256) k_pcm_sink_scan(SinkParams p, float pc) {
     }
     __syncthreads();
   }
-  if (t == 0) p.sg_out[s] = ((unsigned long long)p.gen_next << 32) | __float_as_uint(y0);
+  if (t == 0) {
+    const unsigned long long w = ((unsigned long long)p.gen_next << 32) | __float_as_uint(y0);
+    if constexpr (LIST) __hip_atomic_store(p.sg_out + s, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else p.sg_out[s] = w;
+  }
 }
 
 }  // namespace
@@ -216,9 +243,23 @@ int sdrfm_sink_launch_on(sdrfm_pcm_sink* k, const float* audio, size_t audio_str
   p.n_streams = k->n_streams; p.n = n; p.alpha = k->alpha; p.gain = k->gain;
   p.gen_next = k->calls + 1u;
   p.audio = audio; p.audio_stride = audio_stride; p.pcm = pcm; p.pcm_stride = pcm_stride;
-  hipLaunchKernelGGL(k_pcm_sink_scan, dim3(k->n_streams), dim3(SINK_NT), 0, stream, p, (float)pow(1.0 - (double)k->alpha, (double)SINK_C));
+  hipLaunchKernelGGL(k_pcm_sink_scan<false>, dim3(k->n_streams), dim3(SINK_NT), 0, stream, p, (float)pow(1.0 - (double)k->alpha, (double)SINK_C), nullptr, nullptr);
   STRY(hipGetLastError(), SDRFM_FAIL);
   ++k->calls;
+  return SDRFM_OK;
+}
+
+int sdrfm_sink_launch_list_on(sdrfm_pcm_sink* k, const SdrfmSinkChain& c, const uint32_t* list_dev, uint32_t n_list, const float* audio, size_t audio_stride, uint32_t n,
+                              int16_t* pcm, size_t pcm_stride, hipStream_t stream, hipEvent_t done) {
+  if (!k || !list_dev) return SDRFM_EINVAL;
+  if (n == 0 || n_list == 0) return SDRFM_OK;
+  SinkParams p;
+  p.sg_in = k->d_sg + (size_t)(c.call % SDRFM_CHAIN_SG_SLOTS) * k->n_streams; p.sg_out = k->d_sg + (size_t)((c.call + 1u) % SDRFM_CHAIN_SG_SLOTS) * k->n_streams;
+  p.n_streams = k->n_streams; p.n = n; p.alpha = k->alpha; p.gain = k->gain;
+  p.gen_next = c.call + 1u;
+  p.audio = audio; p.audio_stride = audio_stride; p.pcm = pcm; p.pcm_stride = pcm_stride;
+  hipExtLaunchKernelGGL(k_pcm_sink_scan<true>, dim3(n_list), dim3(SINK_NT), 0, stream, nullptr, done, 0, p, (float)pow(1.0 - (double)k->alpha, (double)SINK_C), list_dev, c.err);
+  STRY(hipGetLastError(), SDRFM_FAIL);
   return SDRFM_OK;
 }
 
@@ -311,7 +352,7 @@ int sdrfm_pcm_sink_process_batch(sdrfm_pcm_sink_t* k, const float* audio, size_t
   const bool exact = (flags & SDRFM_PCM_F_EXACT) != 0;
   auto launch = [&]() {
     if (exact) hipLaunchKernelGGL(k_pcm_sink, grid, dim3(64), 0, k->stream, p);
-    else hipLaunchKernelGGL(k_pcm_sink_scan, dim3(k->n_streams), dim3(SINK_NT), 0, k->stream, p, pc);
+    else hipLaunchKernelGGL(k_pcm_sink_scan<false>, dim3(k->n_streams), dim3(SINK_NT), 0, k->stream, p, pc, nullptr, nullptr);
   };
   if (flags & SDRFM_F_DEVICE_PTRS) {
     if ((uintptr_t)pcm % 4 != 0) return SDRFM_EINVAL;

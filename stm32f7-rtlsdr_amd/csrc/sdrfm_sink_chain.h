@@ -62,6 +62,12 @@ int sdrfm_sink_chain_params(sdrfm_pcm_sink* k, int device, uint32_t n_streams, S
 // The launch that carried `out` is in the queue: the sink's call counter moves on.
 void sdrfm_sink_chain_issued(sdrfm_pcm_sink* k);
 // The stand-alone blocked scan on `stream` (device buffers), as one call of the sink: what a call that no kernel with the chain served is followed by.
+// The stand-alone blocked scan over the streams list[0 .. n_list) only, as PART of the sink's call `c.call` (the chain inside a launch serves the other streams): on
+// `stream`, behind the launch that wrote those streams' audio; it takes each stream's state by the chain's own protocol (the tagged word, a bounded wait on the device)
+// and publishes the next.  Does not move the sink's call counter (sdrfm_sink_chain_issued does, once per call).
+// done != nullptr: the event is signalled by this kernel's own completion (a stop event).
+int sdrfm_sink_launch_list_on(sdrfm_pcm_sink* k, const SdrfmSinkChain& c, const uint32_t* list_dev, uint32_t n_list, const float* audio, size_t audio_stride, uint32_t n,
+                              int16_t* pcm, size_t pcm_stride, hipStream_t stream, hipEvent_t done);
 int sdrfm_sink_launch_on(sdrfm_pcm_sink* k, const float* audio, size_t audio_stride, uint32_t n, int16_t* pcm, size_t pcm_stride, hipStream_t stream);
 
 #endif
