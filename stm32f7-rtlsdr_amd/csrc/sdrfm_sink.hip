@@ -23,12 +23,13 @@
  * The default since round 6 is a BLOCKED SCAN (k_pcm_sink_scan): the recursion is linear — y[n] = (1 - alpha) y[n-1] + alpha x[n] —,
  * so a stream's call is cut into segments of 256 chunks of 19 samples, one lane per chunk, one workgroup of 256 lanes per stream:
  *   1. lane t walks its chunk from state 0 (lane 0: from the carried state) -> e[t], the chunk's own contribution to its last sample;
- *   2. the carries s[t] = (1 - alpha)^c s[t-1] + e[t] by a Hillis-Steele scan over the 256 lanes in LDS (8 steps, the powers squared on the way);
+ *   2. the carries s[t] = (1 - alpha)^c s[t-1] + e[t]: six shuffle steps within each wave (the powers squared on the way), the four waves' totals combined through
+ *      four words of LDS (one barrier; the first version's Hillis-Steele scan over 256 lanes in LDS took sixteen: 7.4 -> 7.0 us per launch);
  *   3. lane t walks its chunk AGAIN, now from its true carry-in s[t-1], with exactly the exact form's operations, and packs the PCM.
  * What differs from the exact chain is therefore only the carry-in of a chunk (re-associated: ~1e-7 relative), and that difference decays with
  * (1 - alpha)^k inside the chunk: the PCM is within 1 LSB of the exact form's (equal but where y * gain sits within 1e-3 of a rounding boundary),
  * the carried state within 2.5e-7 (tests/test_pcm_sink_gpu.py).  The audio row goes through LDS once (coalesced loads, chunk stride odd: conflict-free),
- * the PCM row back the same way; the chunk sits in registers for both walks.  7.4 us per 256 x 4800 launch against the exact form's 1.35 ms
+ * the PCM row back the same way; the chunk sits in registers for both walks.  7.0 us per 256 x 4800 launch against the exact form's 1.35 ms
  * (profiles/r06_sink.txt).
  */
 #include <hip/hip_runtime.h>
@@ -93,14 +94,15 @@ __global__ void __launch_bounds__(64) k_pcm_sink(SinkParams p) {
 // ---- the blocked scan (the default): one workgroup of 256 lanes per stream; segments of SINK_NT * SINK_C samples through LDS ------------------------------
 // (A variant with ONE WAVE per stream, 75-sample chunks in registers and no LDS at all was built to slip in beside the demodulator's waves, which hold all but
 // 0.9 KiB of a CU's LDS: 10.5 us alone against 7.4 us for this one, and no faster in the consumer loop — profiles/r06_sink.txt.  Not kept.)
-constexpr uint32_t SINK_NT = 256, SINK_C = 19, SINK_SEG = SINK_NT * SINK_C;   // 4864 samples per segment (BASELINE's 4800 per call: one segment), 19 KiB of LDS;
+constexpr uint32_t SINK_NT = 256, SINK_C = 19, SINK_SEG = SINK_NT * SINK_C;
+static_assert(SINK_NT == 256, "four waves: the carries between them are combined by hand");   // 4864 samples per segment (BASELINE's 4800 per call: one segment), 19 KiB of LDS;
                                                                              // lanes SINK_C = 19 words apart (odd): conflict-free LDS accesses
 // LIST: the workgroup's stream is list[blockIdx.x], and the call is PART of a sink call whose other streams the chain inside a demodulator launch serves
 // (sdrfm_sink_chain.h): the state is taken by that protocol — the tagged word of slot sg_in, waited for on the device (bounded) — and published the same way.
 template <bool LIST>
 __global__ void __launch_bounds__(256) k_pcm_sink_scan(SinkParams p, float pc, const uint32_t* list, uint32_t* err) {
   __shared__ float x[SINK_SEG];                                 // the segment's samples, then (in place) the packed PCM words
-  __shared__ float sc[SINK_NT];                                 // the scan
+  __shared__ float sc[4];                                       // the waves' totals; then the segment's last state
   unsigned* const xw = reinterpret_cast<unsigned*>(x);
   const uint32_t s = LIST ? list[blockIdx.x] : blockIdx.x, t = threadIdx.x;
   const float* const row = p.audio + (size_t)s * p.audio_stride;
@@ -143,21 +145,32 @@ __global__ void __launch_bounds__(256) k_pcm_sink_scan(SinkParams p, float pc, c
 #pragma unroll
     for (uint32_t q = 0; q < SINK_C; ++q)
       if (q < cnt) y = __builtin_fmaf(p.alpha, xr[q] - y, y);
-    sc[t] = y;
-    __syncthreads();
-    // 2. s[t] = pc s[t-1] + e[t], pc = (1 - alpha)^SINK_C: Hillis-Steele (only the last non-empty chunk may be short, and nothing follows it)
-    float pw = pc;
+    // 2. s[t] = pc s[t-1] + e[t], pc = (1 - alpha)^SINK_C (only the last non-empty chunk may be short, and nothing follows it): within a wave by six shuffle steps
+    // (the powers squared on the way), between the four waves through four words of LDS — one barrier where a Hillis-Steele scan over 256 lanes in LDS took sixteen
+    const uint32_t wl = t & 63u, wv = t >> 6;
+    float sv = y, pw = pc;
 #pragma unroll
-    for (uint32_t d = 1; d < SINK_NT; d <<= 1) {
-      float v = sc[t];
-      if (t >= d) v = __builtin_fmaf(pw, sc[t - d], v);
-      __syncthreads();
-      sc[t] = v;
-      __syncthreads();
+    for (uint32_t d = 1; d < 64u; d <<= 1) {
+      const float o = __shfl_up(sv, d, 64);
+      const float sn = __builtin_fmaf(pw, o, sv);
+      sv = wl >= d ? sn : sv;
       pw *= pw;
+    }                                                           // (pw = pc^64 now: what a whole wave's chunks leave of a state)
+    if (wl == 63u) sc[wv] = sv;
+    float pl = 1.0f, pb = pc;                                   // pc^wl: what the chunks of this wave before the lane's leave of the wave's carry-in
+#pragma unroll
+    for (uint32_t bit = 0; bit < 6u; ++bit) {
+      pl = ((wl >> bit) & 1u) ? pl * pb : pl;
+      pb *= pb;
     }
+    const float prev = __shfl_up(sv, 1u, 64);
+    __syncthreads();
+    float cw = 0.0f;                                            // the state at the end of the previous wave's chunks
+    if (wv >= 1u) cw = sc[0];
+    if (wv >= 2u) cw = __builtin_fmaf(pw, cw, sc[1]);
+    if (wv >= 3u) cw = __builtin_fmaf(pw, cw, sc[2]);
     // 3. the exact form's chain from the true carry-in
-    y = t == 0 ? y0 : sc[t - 1];
+    y = wl == 0u ? (wv == 0u ? y0 : cw) : __builtin_fmaf(pl, cw, prev);
     __syncthreads();                                            // (every carry-in is in a register before sc[0] takes the segment's last state below)
 #pragma unroll
     for (uint32_t q = 0; q < SINK_C; ++q)
