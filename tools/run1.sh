@@ -1,2 +1,2 @@
-timeout 900 python3 -m pytest tests/test_pcm_sink_gpu.py tests/test_c_frontend_gpu.py tests/test_overlap_gpu.py -x -q -m gpu 2>&1 | tail -4
-timeout 300 python3 tools/consumer_loop.py 2>&1 | tail -12 | cut -c1-250
+WLS="driver" bash tools/profile_round.sh r06 $1 > gpurun_out/prof_driver.log 2>&1; tail -5 gpurun_out/prof_driver.log
+head -12 gpurun_out/profiles_r06/r06_driver_command_kernel_stats.csv | cut -c1-200
