@@ -347,7 +347,7 @@ int  sdrfm_pcm_sink_get_state(sdrfm_pcm_sink_t* k, float* state_out /* n_streams
  * library's own); otherwise the audio is written as by sdrfm_process_batch.
  * The sink must belong to h's device and have h's n_streams; between calls made this way and sdrfm_pcm_sink_process_batch calls on the same sink, synchronise
  * both (the chain of call c waits ON THE DEVICE for the sink's call c - 1, which must already be in a queue); sdrfm_pcm_sink_get_state, _reset and _destroy
- * after sdrfm_synchronize(h) (the launches hold pointers into the sink).  The wait on the device is bounded (0.25 s): should it ever run out — a protocol error —
+ * after sdrfm_synchronize(h) (the launches hold pointers into the sink).  The wait on the device is bounded (2^19 polls: about a second): should it ever run out — a protocol error —
  * the run goes on from state 0 and sdrfm_pcm_sink_synchronize / _get_state answer SDRFM_FAIL from then on (until _reset).
  * kernel name: "... + pcm". */
 int  sdrfm_process_batch_pcm(sdrfm_t* h, sdrfm_pcm_sink_t* sink, const uint8_t* iq, size_t iq_stride, uint32_t nbytes, float* audio, size_t audio_stride,

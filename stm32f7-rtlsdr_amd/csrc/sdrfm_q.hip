@@ -993,7 +993,7 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
       const uint32_t want = run == 0 ? call : call + 1u;
       unsigned long long zero = 0ull;
       asm volatile("" : "+v"(zero));                             // (opaque: "add 0" is a read-modify-write the compiler would turn back into a load, and a load may hit a stale line)
-      // (the predecessor ends when this run does: a few polls at most.  The wait is BOUNDED — a quarter of a second —: a protocol error must not hang the
+      // (the predecessor ends when this run does: a few polls at most.  The wait is BOUNDED — 2^19 polls, about a second —: a protocol error must not hang the
       // machine; it is reported through the sink instead — sdrfm_pcm_sink_synchronize / _get_state answer SDRFM_FAIL — and the run goes on from state 0)
       int it = 0;
       for (;; ++it) {
