@@ -5,11 +5,13 @@
  * the same HIP stream while call k runs — the loop INTEGRATION.md section 3 shows.  What fills the ring here is a file; in the reference's
  * setting it is the bulk-IN FSM (one filled CommItf.buff per RTLSDR_XFER_COMPLETE, usbh_rtlsdr.c:1058-1101) of many dongles.
  *
- *   pipeline_main <iq.u8> <h.f32> <g.f32> <n_streams> <nbytes_per_stream_per_call> <n_calls> <pcm_out.s16> [--serial]
+ *   pipeline_main <iq.u8> <h.f32> <g.f32> <n_streams> <nbytes_per_stream_per_call> <n_calls> <pcm_out.s16> [--serial | --one-call]
  *   (no timing here: with the capture coming from pageable host memory the H2D copies set the pace; bench.py measures the calls)
  *
  * iq.u8 holds n_calls consecutive batches of [n_streams][nbytes] bytes (batch-major).  pcm_out: n_calls blocks of [n_streams][2 n_audio]
- * int16.  --serial makes the same calls without the flag (the output must be the same, bit for bit).  Prints one JSON line.
+ * int16.  --serial makes the same calls without the flag (the output must be the same, bit for bit).  --one-call is the loop with no consumer at all:
+ * sdrfm_process_batch_pcm — the sink runs inside the demodulator's own launch, no audio buffer, nothing to order (PCM within 1 LSB of the other modes').
+ * Prints one JSON line.
  */
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
@@ -46,6 +48,7 @@ int main(int argc, char** argv) {
   const uint32_t ns = (uint32_t)atoi(argv[4]), nbytes = (uint32_t)atoi(argv[5]);
   const int n_calls = atoi(argv[6]);
   const int serial = argc > 8 && !strcmp(argv[8], "--serial");
+  const int one_call = argc > 8 && !strcmp(argv[8], "--one-call");
   const size_t batch = (size_t)ns * nbytes;
   if (niq < batch * (size_t)n_calls) { fprintf(stderr, "iq file too short\n"); return 2; }
 
@@ -81,6 +84,10 @@ int main(int argc, char** argv) {
     /* "the capture": batch k into ring[k % RING] on the stream.  The buffer was last read by call k - RING, which the consumer of call
        k - RING (already enqueued on this stream) waited for. */
     HIPC(hipMemcpyAsync(d_ring[k % RING], iq + (size_t)k * batch, batch, hipMemcpyHostToDevice, st));
+    if (one_call) {                                            /* demodulator and sink in one call: the PCM is all it leaves */
+      SDRC(sdrfm_process_batch_pcm(fm, sink, d_ring[k % RING], nbytes, nbytes, NULL, 0, d_pcm + (size_t)k * ns * 2 * astride, 2 * astride, &na, flags));
+      continue;
+    }
     SDRC(sdrfm_process_batch(fm, d_ring[k % RING], nbytes, nbytes, d_audio[k & 1], astride, &na, flags));
     if (k > 0) {                                               /* the consumer of call k - 1, behind call k - 1 only */
       SDRC(serial ? SDRFM_OK : sdrfm_flush_previous(fm));
@@ -88,8 +95,10 @@ int main(int argc, char** argv) {
     }
   }
   SDRC(sdrfm_flush(fm));
-  SDRC(sdrfm_pcm_sink_process_batch(sink, d_audio[(n_calls - 1) & 1], astride, na, d_pcm + (size_t)(n_calls - 1) * ns * 2 * astride, 2 * astride, SDRFM_F_DEVICE_PTRS));
+  if (!one_call)
+    SDRC(sdrfm_pcm_sink_process_batch(sink, d_audio[(n_calls - 1) & 1], astride, na, d_pcm + (size_t)(n_calls - 1) * ns * 2 * astride, 2 * astride, SDRFM_F_DEVICE_PTRS));
   HIPC(hipStreamSynchronize(st));
+  SDRC(sdrfm_pcm_sink_synchronize(sink));                      /* (also reports a chain error of the one-call mode) */
 
   short* pcm = (short*)malloc((size_t)n_calls * ns * 2 * astride * sizeof(short));
   HIPC(hipMemcpy(pcm, d_pcm, (size_t)n_calls * ns * 2 * astride * sizeof(short), hipMemcpyDeviceToHost));
@@ -99,7 +108,7 @@ int main(int argc, char** argv) {
     for (uint32_t s = 0; s < ns; ++s) fwrite(pcm + ((size_t)k * ns + s) * 2 * astride, sizeof(short), 2 * (size_t)na, fo);
   fclose(fo);
   printf("{\"n_streams\":%u,\"bytes_per_stream_per_call\":%u,\"n_calls\":%d,\"n_audio\":%u,\"mode\":\"%s\",\"kernel\":\"%s\"}\n", ns, nbytes, n_calls,
-         na, serial ? "serial" : "overlapped", sdrfm_kernel_name(fm));
+         na, serial ? "serial" : (one_call ? "one-call" : "overlapped"), sdrfm_kernel_name(fm));
 
   sdrfm_pcm_sink_destroy(sink);
   sdrfm_destroy(fm);

@@ -115,7 +115,8 @@ def test_c_multi_gpu_host_on_the_devices_present(pkg, oracle_mod, tmp_path, tran
 def test_c_pipeline_host_overlapped_equals_serial_and_the_host_sink(pkg, tmp_path):
     """examples/pipeline_main.c: a capture ring of three device buffers filled on the stream, SDRFM_F_OVERLAP calls, the device PCM sink
     as the consumer of call k-1 behind sdrfm_flush_previous while call k runs.  The PCM must equal the same program's --serial output
-    bit for bit, and — within the 1 LSB the device sink's blocked scan is held to — the host sink run over the Python wrapper's serial audio."""
+    bit for bit, and — within the 1 LSB the device sink's blocked scan is held to — the host sink run over the Python wrapper's serial audio; so must the PCM
+    of --one-call (sdrfm_process_batch_pcm: no consumer, no audio buffer — the sink inside the demodulator's own launch)."""
     import json
     exe = os.path.join(ROOT, "examples", "pipeline_main")
     if not os.path.exists(exe):
@@ -130,16 +131,17 @@ def test_c_pipeline_host_overlapped_equals_serial_and_the_host_sink(pkg, tmp_pat
     (tmp_path / "h.f32").write_bytes(h.tobytes())
     (tmp_path / "g.f32").write_bytes(g_.tobytes())
     outs = {}
-    for mode in ("overlapped", "serial"):
+    for mode in ("overlapped", "serial", "one-call"):
         out = tmp_path / ("pcm_%s.s16" % mode)
         cmd = [exe, str(tmp_path / "iq.u8"), str(tmp_path / "h.f32"), str(tmp_path / "g.f32"), str(ns), str(2 * nsamp), str(n_calls), str(out)]
-        if mode == "serial":
-            cmd.append("--serial")
+        if mode != "overlapped":
+            cmd.append("--" + mode)
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr
         info = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
         assert info["mode"] == mode and info["n_audio"] == 480 and info["kernel"].startswith("fast-q")
-        assert ("overlapped" in info["kernel"]) == (mode == "overlapped")
+        assert ("overlapped" in info["kernel"]) == (mode != "serial")
+        assert ("+ pcm" in info["kernel"]) == (mode == "one-call")                           # (sdrfm_process_batch_pcm: the sink inside the demodulator's launch)
         outs[mode] = np.fromfile(out, dtype=np.int16).reshape(n_calls, ns, 960)
     assert np.array_equal(outs["overlapped"], outs["serial"])
     lib = pkg.load_library()
@@ -152,9 +154,10 @@ def test_c_pipeline_host_overlapped_equals_serial_and_the_host_sink(pkg, tmp_pat
             want, st = pkg.pcm_deemph_s16_host(audio[k][s_], alpha, gain, st)
             # (the program uses the device sink's default form, the blocked scan: within 1 LSB of the host routine's exact chain)
             assert np.abs(outs["overlapped"][k, s_].astype(np.int32) - want.astype(np.int32)).max() <= 1, (s_, k)
+            assert np.abs(outs["one-call"][k, s_].astype(np.int32) - want.astype(np.int32)).max() <= 1, (s_, k)
 
 
-def test_c_consumer_loop_host_runs_all_three_forms(pkg):
+def test_c_consumer_loop_host_runs_all_its_forms(pkg):
     """examples/consumer_loop_main.c: the consumer loop of INTEGRATION.md section 3 from a plain-C host — overlapped calls alone, the device PCM sink on the handle's
     stream behind sdrfm_flush_previous, and the sink on its own stream behind sdrfm_wait_previous with the audio buffers guarded on the host.  A short run of each
     form completes and reports sane figures (the timings themselves are profiles/r06_sink.txt's business)."""
@@ -168,7 +171,7 @@ def test_c_consumer_loop_host_runs_all_three_forms(pkg):
     r = subprocess.run([exe, "256", "2", "40", "4"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
     info = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert info["kernel"].startswith("fast-q") and "overlapped" in info["kernel"], info
-    for form in ("calls", "simple", "fast"):
+    assert info["kernel"].startswith("fast-q") and "overlapped" in info["kernel"] and info["kernel"].endswith("+ pcm"), info
+    for form in ("calls", "simple", "fast", "fused", "fused_pcm_only"):
         us = info[form]["us_per_call_regions"]
         assert len(us) == 2 and all(5.0 < x < 5000.0 for x in us), (form, us)

@@ -1,2 +1,1 @@
-mkdir -p gpurun_out/soak
-(timeout 1500 python3 tools/fuzz_parity.py 200 7 2>&1 | tail -2) > gpurun_out/soak/fuzz_parity.txt; tail -n 2 gpurun_out/soak/fuzz_parity.txt
+timeout 900 python3 -m pytest tests/test_c_frontend_gpu.py -x -q -m gpu 2>&1 | tail -6
