@@ -264,8 +264,8 @@ def test_pcm_chain_inside_the_demodulators_launch(pkg, overlap):
 
 
 def test_pcm_chain_rows_that_are_not_16_byte_aligned_and_odd_lengths(pkg):
-    """The tail's two data paths: rows 16-byte aligned (four samples per instruction) or not (audio stride 961 floats), a call whose audio length is no multiple
-    of the tail's 76-sample chunks (968 outputs: the last lane's chunk is short), and a call longer than one segment of 4864 (0.12 s: 5760 outputs)."""
+    """Row layouts and lengths: PCM and audio rows 8-byte aligned or not (audio stride 961 floats: odd rows start on an odd word — the chain stores 8-byte pairs
+    aligned in memory), a call of 968 outputs, and a long one (0.12 s: 5760 outputs, runs of 4.7 steps); nothing may be written past a row's samples."""
     import torch
     alpha, gain = _params(pkg)
     ns = 64
