@@ -75,6 +75,10 @@ def parse():
                     "knobs, e.g. SDRFM_NO_STREAM=1 for design B); the reported line then says so and is not a product figure")
     ap.add_argument("--bit-exact", action="store_true", help="fm workload: SDRFM_CFG_BIT_EXACT handle — the fmaf-chain kernels only (design S "
                     "instead of the matrix-pipe design Q); a comparison figure, labelled as such")
+    ap.add_argument("--pcm-call", choices=["none", "pcm", "both"], default="none",
+                    help="fm workload: make EVERY call of the run through sdrfm_process_batch_pcm (the board's sink format out of the demodulator's own launch: "
+                         "'pcm' without an audio buffer, 'both' with one) — for profiling that kernel; the default line measures the plain calls and reports the "
+                         "PCM calls in its consumer_loop block")
     ap.add_argument("--no-overlap", action="store_true", help="fm workload: make the timed calls one after the other (without SDRFM_F_OVERLAP); "
                     "by default consecutive calls may overlap on the device (two audio buffers in turn) and `value` is that throughput, "
                     "while `roofline` is always taken from calls made one after the other — the duration rocprofv3 reports per kernel")
@@ -441,7 +445,25 @@ def main():
 
     last = {"n": 0}
 
+    pcm_sink = pcm_bufs = None
+    if args.pcm_call != "none":                                   # (profiling aid: every call leaves the PCM — three buffers in turn — instead of / beside the audio)
+        alpha_p, gain_p = float(pkg.load_library().sdrfm_pcm_alpha(48000.0, 75e-6)), float(32767.0 / (2 * np.pi * 75e3 / (fs / D)))
+        pcm_sink = pkg.PcmSink(ns, alpha_p, gain_p, device=local_rank)
+        with torch.cuda.stream(stream):
+            pcm_bufs = [torch.zeros((ns, 2 * n_audio_max + 2), dtype=torch.int16, device="cuda") for _ in range(3)]
+            audio3 = [audio, torch.zeros_like(audio), torch.zeros_like(audio)]
+        stream.synchronize()
+    pcm_calls = {"n": 0}
+
+    def call_pcm(batch, ovl):
+        k = pcm_calls["n"] % 3
+        pcm_calls["n"] += 1
+        return dm.process_batch_pcm_device(pcm_sink, batch, audio3[k] if args.pcm_call == "both" else None, pcm_bufs[k], overlap=ovl)
+
     def step_rot(i):
+        if pcm_sink is not None:
+            last["n"] = call_pcm(batches[i % nb], False)
+            return
         if e2e is None:
             last["n"] = dm.process_batch_device(batches[i % nb], audio)
             return
@@ -469,6 +491,9 @@ def main():
         # previous region's last call wrote (i & 1 restarting at 0) had its first call made serially by the library (two consecutive calls
         # must not write the same audio buffer), and the next few waited on the handle's stream for it — 2 us per call of a 20-call region
         # (profiles/r05_driver_command_trace_before.json)
+        if pcm_sink is not None:
+            last["n"] = call_pcm(batches[i % nb], True)
+            return
         last["n"] = dm.process_batch_device(batches[i % nb], audio_pair[ovl_calls["n"] & 1], overlap=True)
         ovl_calls["n"] += 1
 
@@ -535,7 +560,7 @@ def main():
     # what a consumer of the audio gets: the same overlapped calls made through sdrfm_process_batch_pcm — the board's sink format
     # (de-emphasis, int16 L = R) out of the demodulator's own launch —, steady state, with and without the float audio stored beside the PCM
     consumer = None
-    if steady_ovl and overlap and not args.dev_library and not args.no_consumer_leg:
+    if steady_ovl and overlap and not args.dev_library and not args.no_consumer_leg and pcm_sink is None:
         alpha, gain = float(pkg.load_library().sdrfm_pcm_alpha(48000.0, 75e-6)), float(32767.0 / (2 * np.pi * 75e3 / (fs / D)))
         with torch.cuda.stream(stream):
             pcm_ring = [torch.zeros((ns, 2 * n_audio_max + 2), dtype=torch.int16, device="cuda") for _ in range(3)]
@@ -620,6 +645,8 @@ def main():
         value = sf["value"]
         samples_per_launch = ns * nsamp
         alg_bytes = samples_per_launch * 2.0 + ns * n_audio * 4.0        # 2 B in + 4/(D*Da) B out per IQ sample
+        if args.pcm_call == "both":
+            alg_bytes += ns * n_audio * 4.0                             # (--pcm-call both: the int16 pair beside the float; 'pcm': instead of it — the same 4 B)
         achieved = alg_bytes / (kernel_ms_avg * 1e-3) / 1e9
         traffic = latest_traffic(dm.kernel_name, alg_bytes)
         res = {

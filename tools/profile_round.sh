@@ -46,6 +46,7 @@ for wl in $WLS; do case $wl in
   fm256_D8)  run_wl fm256_D8 k_mfir --fir-decim 8 --no-overlap ;;      # 2.048 MS/s / 8 / 8
   fm256_D16) run_wl fm256_D16 k_mfir --fir-decim 16 --no-overlap ;;    # 3.2 MS/s / 16 / 5
   fm256_bitexact) run_wl fm256_bitexact k_stream --bit-exact --no-overlap ;;
+  fm256_pcm) run_wl fm256_pcm k_mfir_pcm --pcm-call pcm --no-overlap ;;   # every call through sdrfm_process_batch_pcm (no audio buffer): the kernel with the sink's chain in it
   mixed10)   run_wl mixed10 k_mix --iq-class mixed:10 --no-overlap ;;   # 10 % noise-only streams: the one-launch kernel (design-B workgroups inside design Q's grid)
   mixed25)   run_wl mixed25 k_mix --iq-class mixed:25 --no-overlap ;;
   wbfm)      run_wl wbfm k_wbfm_ --workload wbfm ;;

@@ -1,4 +1,9 @@
-timeout 900 python3 -m pytest tests/test_pcm_sink_gpu.py tests/test_c_frontend_gpu.py -x -q -m gpu 2>&1 | tail -5
-for i in 1 2 3; do timeout 60 ./examples/consumer_loop_main 256 10 300 6 | python3 -c "
-import sys,json
-d=json.loads(sys.stdin.read()); print({k:(v['steady_us_per_call'] if isinstance(v,dict) else v) for k,v in d.items() if k!='kernel'})"; done
+WLS="fm256_pcm" bash tools/profile_round.sh r06 $1 > gpurun_out/prof_pcm.log 2>&1; tail -3 gpurun_out/prof_pcm.log
+head -3 gpurun_out/profiles_r06/r06_fm256_pcm_kernel_stats.csv | cut -c1-200
+python3 - <<'PY'
+import json
+d=json.load(open('gpurun_out/profiles_r06/r06_fm256_pcm_pmc.json'))
+print({k:d[k] for k in list(d)[:40]})
+b=json.load(open('gpurun_out/profiles_r06/r06_fm256_pcm_bench.json'))
+print(b['value'], b['config'].get('kernel'), b['roofline'].get('traffic'), b['roofline']['read_basis'])
+PY
