@@ -51,9 +51,9 @@ for wl in $WLS; do case $wl in
   mixed25)   run_wl mixed25 k_mix --iq-class mixed:25 --no-overlap ;;
   wbfm)      run_wl wbfm k_wbfm_ --workload wbfm ;;
   spectrum)  run_wl spectrum k_spectrum --workload spectrum ;;
-  fm256_overlap|fm512_overlap)   # SDRFM_F_OVERLAP calls: the kernel trace itself (start / end of every dispatch, queue ids) and what it says
+  fm256_overlap|fm512_overlap|fm256_pcm_overlap)   # SDRFM_F_OVERLAP calls: the kernel trace itself (start / end of every dispatch, queue ids) and what it says
     W=$OUT/work_$wl; mkdir -p "$W"
-    EXTRA=""; [ $wl = fm512_overlap ] && EXTRA="--streams-per-gpu 512"
+    EXTRA=""; [ $wl = fm512_overlap ] && EXTRA="--streams-per-gpu 512"; [ $wl = fm256_pcm_overlap ] && EXTRA="--pcm-call pcm"
     rocprofv3 --output-format csv --kernel-trace -d "$W/trace" -o trace -- python3 bench.py $PROF_ARGS $EXTRA > "$W/bench_trace.log" 2>&1
     grep "^{\"metric\"" "$W/bench_trace.log" | tail -1 > "$OUT/${TAG}_${wl}_bench_under_rocprof.json"
     python3 tools/overlap_trace_summarize.py "$(find "$W/trace" -name "*kernel_trace.csv" | head -1)" "$OUT/${TAG}_${wl}_trace.json" "$COMMIT" ;;
