@@ -334,7 +334,9 @@ int  sdrfm_pcm_sink_synchronize(sdrfm_pcm_sink_t* k);
 int  sdrfm_pcm_sink_get_state(sdrfm_pcm_sink_t* k, float* state_out /* n_streams floats */);
 
 /* ONE call of the demodulator and of the sink (round 6): sdrfm_process_batch(h, iq, ..., audio, ..., flags) and then the sink's default form over that
- * audio into pcm — device buffers only (flags must hold SDRFM_F_DEVICE_PTRS; SDRFM_F_OVERLAP as for sdrfm_process_batch, with pcm rotated like audio).
+ * audio into pcm.  With SDRFM_F_DEVICE_PTRS the buffers are device memory and the call only enqueues (SDRFM_F_OVERLAP as for sdrfm_process_batch, with pcm
+ * rotated like audio); without it they are host memory and the call stages, runs and copies back, synchronous like sdrfm_process_batch with host buffers — the
+ * reference superloop's two steps on one filled CommItf.buff: demodulate it, hand int16 stereo to BSP_AUDIO_OUT_Play.
  * Where the matrix-pipe kernel serves the whole call, the sink's chain runs INSIDE its launch (csrc/sdrfm_sink_chain.h): the de-emphasis forgets — (1 - alpha)^64
  * is below rounding —, so every wave sinks the ~400 outputs it has just computed where they lie, publishes its end state in one word, and finishes its first 64
  * outputs with its neighbour's.  No second launch, no stream to order, nothing between two overlapped calls: the consumer loop of INTEGRATION.md section 3 runs

@@ -1025,6 +1025,7 @@ struct sdrfm {
   sdrfm_pcm_sink* pcm_sink; int16_t* pcm_out; size_t pcm_out_stride; bool pcm_fused;
   bool pcm_no_audio; float* d_pcm_audio; size_t pcm_audio_stride; uint32_t pcm_audio_cap, pcm_audio_flip;   // a call without an audio buffer: the library's own, for the calls that need one
   const int16_t* prev_ovl_pcm; size_t prev_ovl_pcm_stride;       // the PCM rows the previous overlapped call may still be writing
+  int16_t* d_pcm_stage;                                          // sdrfm_process_batch_pcm with host buffers: the PCM rows before they are copied back
   unsigned long long* d_runstate; uint32_t runstate_cap;        // the runs' hand-off words (sdrfm_sink_chain.h), allocated at the first such call
   bool ovl_pending[2], ovl_bound[2], ovl_join_style;   // (bound: the latest kernel of stream k carries ovl_done[k] as its stop event; join_style: the caller joins after every call)
   uint32_t ovl_next;
@@ -1139,7 +1140,8 @@ static uint32_t max_audio_for(const sdrfm_config& c, uint32_t nbytes) {
 static void q_free(sdrfm* h) {
   if (h->d_runstate) (void)hipFree(h->d_runstate);
   if (h->d_pcm_audio) (void)hipFree(h->d_pcm_audio);
-  h->d_runstate = nullptr; h->d_pcm_audio = nullptr;
+  if (h->d_pcm_stage) (void)hipFree(h->d_pcm_stage);
+  h->d_runstate = nullptr; h->d_pcm_audio = nullptr; h->d_pcm_stage = nullptr;
   if (h->d_qA) (void)hipFree(h->d_qA);
   if (h->d_hpad) (void)hipFree(h->d_hpad);
   h->d_qA = nullptr; h->d_hpad = nullptr;
@@ -2074,9 +2076,41 @@ int sdrfm_process_batch(sdrfm_t* h, const uint8_t* iq, size_t iq_stride, uint32_
 int sdrfm_process_batch_pcm(sdrfm_t* h, sdrfm_pcm_sink_t* sink, const uint8_t* iq, size_t iq_stride, uint32_t nbytes, float* audio, size_t audio_stride,
                             int16_t* pcm, size_t pcm_stride, uint32_t* n_audio, uint32_t flags) {
   if (!h || !sink || !n_audio) return SDRFM_EINVAL;
-  if (!(flags & SDRFM_F_DEVICE_PTRS) || (flags & ~(SDRFM_F_DEVICE_PTRS | SDRFM_F_OVERLAP))) return SDRFM_EINVAL;
+  if (flags & ~(SDRFM_F_DEVICE_PTRS | SDRFM_F_OVERLAP)) return SDRFM_EINVAL;
+  if ((flags & SDRFM_F_OVERLAP) && !(flags & SDRFM_F_DEVICE_PTRS)) return SDRFM_EINVAL;
   if (nbytes & 1u) return SDRFM_EODD;
   if (nbytes == 0) { *n_audio = 0; return SDRFM_OK; }
+  if (!(flags & SDRFM_F_DEVICE_PTRS)) {
+    // Host buffers: stage -> the call below on the staging buffers -> copy back; synchronous, as sdrfm_process_batch with host buffers (the caller may re-arm `iq`
+    // as soon as this returns, like the reference FSM does with CommItf.buff, and hand `pcm` to BSP_AUDIO_OUT_Play).
+    if (!iq) return SDRFM_EINVAL;
+    const uint32_t ns = h->cfg.n_streams;
+    if (nbytes > h->max_bytes) return SDRFM_ECAPACITY;
+    if (ns > 1 && iq_stride < nbytes) return SDRFM_ECAPACITY;
+    uint32_t A = 0;
+    (void)sdrfm_audio_count(h, nbytes, &A);
+    if (A && (!pcm || (pcm_stride & 1u))) return SDRFM_EINVAL;
+    if (ns > 1 && (pcm_stride < 2 * (size_t)A || (audio && audio_stride < A))) return SDRFM_ECAPACITY;
+    HIP_TRY(hipSetDevice(h->device), SDRFM_FAIL);
+    int rc = ensure_staging(h);
+    if (rc != SDRFM_OK) return rc;
+    const size_t pstride = 2 * h->d_audio_stride;
+    if (!h->d_pcm_stage) HIP_TRY(hipMalloc(&h->d_pcm_stage, sizeof(int16_t) * pstride * ns), SDRFM_ENOMEM);
+    HIP_TRY(hipMemcpy2DAsync(h->d_iq, h->d_iq_stride, iq, ns > 1 ? iq_stride : nbytes, nbytes, ns, hipMemcpyHostToDevice, h->stream), SDRFM_FAIL);
+    rc = sdrfm_process_batch_pcm(h, sink, h->d_iq, h->d_iq_stride, nbytes, audio ? h->d_audio : nullptr, h->d_audio_stride, h->d_pcm_stage, pstride, n_audio,
+                                 SDRFM_F_DEVICE_PTRS);
+    if (rc != SDRFM_OK) return rc;
+    { const int jrc = join_overlap(h); if (jrc != SDRFM_OK) return jrc; }
+    if (*n_audio) {
+      HIP_TRY(hipMemcpy2DAsync(pcm, (ns > 1 ? pcm_stride : 2 * (size_t)*n_audio) * sizeof(int16_t), h->d_pcm_stage, pstride * sizeof(int16_t),
+                               2 * (size_t)*n_audio * sizeof(int16_t), ns, hipMemcpyDeviceToHost, h->stream), SDRFM_FAIL);
+      if (audio)
+        HIP_TRY(hipMemcpy2DAsync(audio, (ns > 1 ? audio_stride : *n_audio) * sizeof(float), h->d_audio, h->d_audio_stride * sizeof(float),
+                                 *n_audio * sizeof(float), ns, hipMemcpyDeviceToHost, h->stream), SDRFM_FAIL);
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream), SDRFM_FAIL);
+    return SDRFM_OK;
+  }
   uint32_t A = 0;
   (void)sdrfm_audio_count(h, nbytes, &A);
   if (A && (!pcm || ((uintptr_t)pcm & 3u) || (pcm_stride & 1u))) return SDRFM_EINVAL;

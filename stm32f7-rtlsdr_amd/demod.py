@@ -168,6 +168,24 @@ class FmDemod:
                                                _l.F_DEVICE_PTRS | (_l.F_OVERLAP if overlap else 0)), "sdrfm_process_batch(device)")
         return n.value
 
+    def process_batch_pcm(self, sink, iq, want_audio=False):
+        """sdrfm_process_batch_pcm on HOST buffers (synchronous): iq uint8 [n_streams, nbytes] -> int16 PCM [n_streams, 2 * n_audio] (L = R, de-emphasised by the
+        device sink `sink`), and the float audio too when want_audio.  The reference superloop's two steps on one filled buffer."""
+        import numpy as np
+        iq = np.ascontiguousarray(iq, dtype=np.uint8)
+        if iq.ndim == 1:
+            iq = iq[None, :]
+        ns, nbytes = iq.shape
+        assert ns == self.cfg.n_streams
+        cap = self.audio_count(nbytes)
+        pcm = np.zeros((ns, 2 * cap), np.int16)
+        audio = np.zeros((ns, cap), np.float32) if want_audio else None
+        n = C.c_uint32()
+        self._ck(self._lib.sdrfm_process_batch_pcm(self._h, sink._h, iq.ctypes.data_as(C.c_void_p), iq.strides[0], nbytes,
+                                                   audio.ctypes.data_as(C.c_void_p) if want_audio else None, cap, pcm.ctypes.data_as(C.c_void_p), 2 * cap,
+                                                   C.byref(n), 0), "sdrfm_process_batch_pcm(host)")
+        return (pcm[:, :2 * n.value], audio[:, :n.value]) if want_audio else pcm[:, :2 * n.value]
+
     def process_batch_pcm_device(self, sink, iq, audio, pcm, nbytes=None, overlap=False):
         """sdrfm_process_batch_pcm: one call of the demodulator and of the device PCM sink `sink` (a PcmSink of this device and this many streams) —
         where design Q serves the call the sink's chain runs inside its launch (kernel_name ends in "+ pcm"), any other call is followed by the sink's

@@ -349,7 +349,7 @@ def test_pcm_call_argument_errors(pkg):
         args = lambda k, pp, ps, fl: (dm._h, k._h, C.c_void_p(iq.data_ptr()), iq.stride(0), 96000, C.c_void_p(audio.data_ptr()), audio.stride(0),
                                       C.c_void_p(pp), ps, C.byref(n), fl)
         assert lib.sdrfm_process_batch_pcm(*args(other, pcm.data_ptr(), 1920, 1)) == pkg.lib.EINVAL     # a sink of another stream count
-        assert lib.sdrfm_process_batch_pcm(*args(sink, pcm.data_ptr(), 1920, 0)) == pkg.lib.EINVAL      # host buffers: not this call
+        assert lib.sdrfm_process_batch_pcm(*args(sink, pcm.data_ptr(), 1920, 2)) == pkg.lib.EINVAL      # SDRFM_F_OVERLAP asks for device buffers
         assert lib.sdrfm_process_batch_pcm(*args(sink, pcm.data_ptr() + 2, 1920, 1)) == pkg.lib.EINVAL  # rows are written as (L, R) words
         assert lib.sdrfm_process_batch_pcm(*args(sink, pcm.data_ptr(), 1919, 1)) == pkg.lib.EINVAL
         assert lib.sdrfm_process_batch_pcm(*args(sink, pcm.data_ptr(), 1918, 1)) == pkg.lib.ECAPACITY
@@ -473,3 +473,42 @@ def test_pcm_chain_for_one_dongle(pkg, taps):
         d = np.abs(pcm[k][0].cpu().numpy().astype(np.int32) - want[k].astype(np.int32))
         assert d.max() <= 1, (k, int(d.max()), int(np.argmax(d)))
     assert abs(state[0] - st) <= 1e-6 * max(abs(st), 0.25)
+
+
+@pytest.mark.parametrize("ns,nsamp", [(1, 131072), (4, 48000), (64, 240000)])
+def test_pcm_call_on_host_buffers(pkg, ns, nsamp):
+    """Without SDRFM_F_DEVICE_PTRS the call takes host buffers, synchronous like sdrfm_process_batch with host buffers — the reference superloop's two steps on one
+    filled CommItf.buff (here: one dongle's DEFAULT_BUF_LENGTH, four dongles, a batch design Q serves): PCM within 1 LSB of the host routine over the audio of the
+    same call, with and without an audio buffer, the state carried across calls."""
+    import ctypes as C
+    alpha, gain = _params(pkg)
+    h, g = pkg.default_config(64)
+    lib = pkg.load_library()
+    nb = 3
+    iq = pkg.make_iq(ns, nb * nsamp, mode="fm", first_id=4500)
+    na_cap = nsamp // 50 + 1
+    with pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=ns, max_bytes_per_call=2 * nsamp)) as dm, pkg.PcmSink(ns, alpha, gain) as sink, \
+            pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=ns, max_bytes_per_call=2 * nsamp)) as dref:
+        state = {s: 0.0 for s in range(ns)}
+        for k in range(nb):
+            chunk = np.ascontiguousarray(iq[:, 2 * k * nsamp:2 * (k + 1) * nsamp])
+            audio = np.zeros((ns, na_cap), np.float32)
+            pcm = np.full((ns, 2 * na_cap), 12345, np.int16)
+            n = C.c_uint32()
+            with_audio = k != 1
+            rc = lib.sdrfm_process_batch_pcm(dm._h, sink._h, chunk.ctypes.data_as(C.c_void_p), chunk.strides[0], 2 * nsamp,
+                                             audio.ctypes.data_as(C.c_void_p) if with_audio else None, na_cap, pcm.ctypes.data_as(C.c_void_p), 2 * na_cap,
+                                             C.byref(n), 0)
+            assert rc == 0, rc
+            ref = dref.process_batch(chunk) if ns > 1 else dref.process(chunk[0])[None, :]
+            assert n.value == ref.shape[1]
+            if with_audio:
+                assert np.array_equal(audio[:, :n.value], ref)      # (the audio the call leaves is sdrfm_process_batch's)
+            for s in range(0, ns, max(1, ns // 4)):
+                want, state[s] = pkg.pcm_deemph_s16_host(ref[s], alpha, gain, state[s])
+                assert np.abs(pcm[s, :2 * n.value].astype(np.int32) - want.astype(np.int32)).max() <= 1, (k, s)
+                assert (pcm[s, 2 * n.value:] == 12345).all()
+        got_state = sink.state()
+        for s in state:
+            if s % max(1, ns // 4) == 0:
+                assert abs(got_state[s] - state[s]) <= 1e-6 * max(abs(state[s]), 0.25), (s, got_state[s], state[s])
