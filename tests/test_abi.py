@@ -123,6 +123,7 @@ def test_ordering_calls_reject_a_null_handle_without_touching_the_gpu(pkg):
     assert lib.sdrfm_wait_previous(None, None) == 16                       # (round 6: a consumer's own stream behind call k - 1)
     n = __import__("ctypes").c_uint32()
     assert lib.sdrfm_process_batch(None, None, 0, 0, None, 0, __import__("ctypes").byref(n), 3) == 16
+    assert lib.sdrfm_process_batch_pcm(None, None, None, 0, 0, None, 0, None, 0, __import__("ctypes").byref(n), 0) == 16   # (round 6: demodulator and PCM sink in one call)
 
 
 def test_discriminator_conventions(pkg):
