@@ -521,7 +521,10 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
     asm volatile("" : "+s"(pp));
     return (KChainPtr)(pp + offsetof(QPcmArgs, t));
   };
-  auto flush_audio = [&]() {
+  // (PCM) the first poll of the predecessor's word, issued inside the run's last flush — as soon as the scan has the run's end state — and consumed behind it
+  [[maybe_unused]] unsigned long long pv_early = 0ull;
+  [[maybe_unused]] bool published = false;
+  auto flush_audio = [&](const bool fin = false) {
     __builtin_amdgcn_wave_barrier();
     // Row elements [max(jfl, jlo), min(jfl + 128 npend, j1)) come from ab[e - jfl] (the outputs before jlo — a warm-up's — are the previous
     // run's; those from j1 on the next one's), stored as 8-byte pairs aligned in MEMORY whatever the parity of jfl (4-byte stores cost
@@ -581,6 +584,26 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
           const float sn = __builtin_fmaf(pw, o, sc);
           sc = ln_ >= d ? sn : sc;
           pw *= pw;
+        }
+        if (fin) {
+          // The run's end state is known HERE, before the second walk: the scan's value of the lane that holds the last output is that state decayed over the
+          // zeros behind it in the lane's chunk — undone by the host's (1 - alpha)^-k.  Published at once, and the predecessor's word asked for at once: both
+          // round trips run under the second walk and the stores instead of behind them.  (Re-associated like every carry: 1e-7 relative.)
+          const int Ll = (cntf - 1) / PCH, rl = (cntf - 1) % PCH;
+          const float ypub = __shfl(sc, Ll, 64) * tp->dinv[PCH - 1 - rl];
+          uint32_t bid2 = bid;
+          asm volatile("" : "+s"(bid2));
+          if (ln_ == 0) {
+            const uint32_t call = tp->call, nst = tp->n_streams;
+            const unsigned long long w = ((unsigned long long)(call + 1u) << 32) | __builtin_bit_cast(unsigned, ypub);
+            __hip_atomic_store(last_run ? tp->sg + (size_t)((call + 1u) % SDRFM_CHAIN_SG_SLOTS) * nst + st_ : tp->runstate + bid2, w, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long zero = 0ull;
+            asm volatile("" : "+v"(zero));
+            pv_early = __hip_atomic_fetch_add(run == 0 ? tp->sg + (size_t)(call % SDRFM_CHAIN_SG_SLOTS) * nst + st_ : tp->runstate + (bid2 - 1u), zero,
+                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          published = true;
         }
         float y = __shfl_up(sc, 1u, 64);                        // 3. the exact form's chain from the true carry-in
         if (ln_ == 0) y = yrun;
@@ -974,7 +997,7 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
   const unsigned long long t_loop = __builtin_amdgcn_s_memrealtime();
 #endif
   wait_vmcnt<0>();                                              // nothing may still be in flight towards this wave's LDS when it ends
-  flush_audio();
+  flush_audio(true);
   if constexpr (PCM) {
     // ---- the run's end state published, its predecessor's taken, the run's first outputs finished (sdrfm_sink_chain.h) ---------------------------------
     const KChainPtr tp = kchain();
@@ -985,10 +1008,12 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
     unsigned long long* const rs = tp->runstate;
     unsigned long long* const sg = tp->sg;
     const float dp = ln_ < (int)SDRFM_CHAIN_FIX ? tp->dpow[ln_] : 0.0f;
-    unsigned long long pv = 0;
+    unsigned long long pv = pv_early;
     if (ln_ == 0) {
-      const unsigned long long w = ((unsigned long long)(call + 1u) << 32) | __builtin_bit_cast(unsigned, yrun);
-      __hip_atomic_store(last_run ? sg + (size_t)((call + 1u) % SDRFM_CHAIN_SG_SLOTS) * nst + st_ : rs + bid_, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!published) {                                          // (a last flush with nothing in it: the state as the earlier flushes left it)
+        const unsigned long long w = ((unsigned long long)(call + 1u) << 32) | __builtin_bit_cast(unsigned, yrun);
+        __hip_atomic_store(last_run ? sg + (size_t)((call + 1u) % SDRFM_CHAIN_SG_SLOTS) * nst + st_ : rs + bid_, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       unsigned long long* const src = run == 0 ? sg + (size_t)(call % SDRFM_CHAIN_SG_SLOTS) * nst + st_ : rs + (bid_ - 1u);
       const uint32_t want = run == 0 ? call : call + 1u;
       unsigned long long zero = 0ull;
@@ -997,7 +1022,7 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
       // machine; it is reported through the sink instead — sdrfm_pcm_sink_synchronize / _get_state answer SDRFM_FAIL — and the run goes on from state 0)
       int it = 0;
       for (;; ++it) {
-        pv = __hip_atomic_fetch_add(src, zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (it > 0 || !published) pv = __hip_atomic_fetch_add(src, zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the first answer is the early poll's)
         if ((uint32_t)(pv >> 32) == want || it == (1 << 19)) break;
         __builtin_amdgcn_s_sleep(16);
       }

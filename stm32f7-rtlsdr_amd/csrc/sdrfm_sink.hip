@@ -243,6 +243,7 @@ int sdrfm_sink_chain_params(sdrfm_pcm_sink* k, int device, uint32_t n_streams, S
   out->alpha = k->alpha; out->gain = k->gain;
   out->pc = (float)pow(1.0 - (double)k->alpha, (double)SDRFM_CHAIN_CH);
   for (uint32_t q = 0; q < SDRFM_CHAIN_CH; ++q) out->w[q] = (float)((double)k->alpha * pow(1.0 - (double)k->alpha, (double)(SDRFM_CHAIN_CH - 1u - q)));
+  for (uint32_t q = 0; q < SDRFM_CHAIN_CH; ++q) out->dinv[q] = (float)pow(1.0 - (double)k->alpha, -(double)q);
   return k->alpha >= SDRFM_CHAIN_MIN_ALPHA ? 2 : 1;
 }
 

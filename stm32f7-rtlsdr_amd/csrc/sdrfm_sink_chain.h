@@ -16,7 +16,9 @@
  * What a run cannot know is the state its predecessor — the stream's previous run, or the previous CALL's last run — ends with; that state only reaches the run's
  * first 64 outputs (beyond them it is below rounding), and linearly: y[k] = y_local[k] + d^(k+1) * carry.  So a run keeps y_local[0..64) aside, PUBLISHES its own
  * end state (which, 64 outputs in, no longer depends on the carry either) as one 64-bit word {call tag, state}, reads its predecessor's word (a read-modify-write
- * atomic: performed at the device's coherence point whatever the L2s hold), and finishes its first 64 outputs with one fused multiply-add each.  No wave waits for
+ * atomic: performed at the device's coherence point whatever the L2s hold), and finishes its first 64 outputs with one fused multiply-add each.  (The end state
+ * is taken from the scan of the run's last flush, before the second walk, and the predecessor's word is asked for in the same breath: both round trips run under
+ * the walk and the stores — 0.25 us per call less than publishing behind them.)  No wave waits for
  * more than its neighbour's last step; nothing is counted, nothing is read back from memory, no cache is written back or invalidated.
  * (First version, kept in the history: the stream's LAST wave re-read the whole row and ran the chain as a tail — 30 us per call against the demodulator's 22:
  * four dependent round trips through a saturated memory system at the very end of the launch, which the next launch on that queue waits for.)
@@ -53,6 +55,7 @@ struct SdrfmSinkChain {
   uint32_t call;                  // this call's number (mod 2^32)
   float alpha, gain, pc;          // pc = (1 - alpha)^SDRFM_CHAIN_CH
   float w[SDRFM_CHAIN_CH];         // w[q] = alpha (1 - alpha)^(SDRFM_CHAIN_CH - 1 - q): what sample q of a chunk adds to the chunk's last output
+  float dinv[SDRFM_CHAIN_CH];      // dinv[k] = (1 - alpha)^-k: undoes the decay over the k zeros behind a flush's last output in its lane's chunk
 };
 
 // ---- host side (sdrfm_sink.hip) ---------------------------------------------------------------------------------------------------------------------------
