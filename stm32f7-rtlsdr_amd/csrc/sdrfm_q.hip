@@ -524,6 +524,7 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
   // (PCM) the first poll of the predecessor's word, issued inside the run's last flush — as soon as the scan has the run's end state — and consumed behind it
   [[maybe_unused]] unsigned long long pv_early = 0ull;
   [[maybe_unused]] bool published = false;
+  [[maybe_unused]] float dp_early = 0.0f;                        // (1 - alpha)^(lane + 1), fetched with them
   auto flush_audio = [&](const bool fin = false) {
     __builtin_amdgcn_wave_barrier();
     // Row elements [max(jfl, jlo), min(jfl + 128 npend, j1)) come from ab[e - jfl] (the outputs before jlo — a warm-up's — are the previous
@@ -603,6 +604,7 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
             pv_early = __hip_atomic_fetch_add(run == 0 ? tp->sg + (size_t)(call % SDRFM_CHAIN_SG_SLOTS) * nst + st_ : tp->runstate + (bid2 - 1u), zero,
                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
+          dp_early = ln_ < (int)SDRFM_CHAIN_FIX ? tp->dpow[ln_] : 0.0f;
           published = true;
         }
         float y = __shfl_up(sc, 1u, 64);                        // 3. the exact form's chain from the true carry-in
@@ -1007,7 +1009,7 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
     const uint32_t call = tp->call, nst = tp->n_streams;
     unsigned long long* const rs = tp->runstate;
     unsigned long long* const sg = tp->sg;
-    const float dp = ln_ < (int)SDRFM_CHAIN_FIX ? tp->dpow[ln_] : 0.0f;
+    const float dp = published ? dp_early : (ln_ < (int)SDRFM_CHAIN_FIX ? tp->dpow[ln_] : 0.0f);
     unsigned long long pv = pv_early;
     if (ln_ == 0) {
       if (!published) {                                          // (a last flush with nothing in it: the state as the earlier flushes left it)
