@@ -343,6 +343,7 @@ def test_pcm_call_argument_errors(pkg):
     iq = torch.zeros((4, 96000), dtype=torch.uint8, device="cuda")
     audio = torch.zeros((4, 960), dtype=torch.float32, device="cuda")
     pcm = torch.zeros((4, 1920), dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
     import ctypes as C
     with pkg.FmDemod(pkg.FmConfig(fir_coeffs=h, audio_coeffs=g, n_streams=4)) as dm, pkg.PcmSink(3, alpha, gain) as other, pkg.PcmSink(4, alpha, gain) as sink:
         n = C.c_uint32()
