@@ -962,6 +962,7 @@ struct sdrfm {
   const FastVariant* fast;
   const FastVariant* fast_s;  // design S variant of this geometry, if one is instantiated (serves the calls it is eligible for)
   const FastVariant* fast_mix; size_t fast_mix_lds;   // design B with the smallest tile (R = 4): the noisy streams' workgroups beside design Q's
+  bool mix_split_off; double mix_rho;                            // (development library: SDRFM_MIX_SPLIT_OFF keeps the share-only split of the wave slots; SDRFM_MIX_RHO: the weight)
   uint32_t mix_lds, mix_waves_per_cu, mix_R; double mix_cost;                 // ... or INSIDE design Q's launch (sdrfm_q.hip: k_mix) where an instance exists: LDS bytes of a workgroup (0 = none), workgroups a CU holds
   uint32_t n_cu;              // compute units of the device
   char fast_s_name[64];
@@ -1463,9 +1464,11 @@ int sdrfm_create(const sdrfm_config* cfg, sdrfm_t** out) {
       h->fast_mix_lds = (size_t)v.xbytes + (size_t)(DOFF + (uint32_t)fastb_ab((int)v.R) * NYT + v.T + cfg->audio_taps) * 4;
       // a stream costs the design-B workgroups about mix_cost times what it costs design Q's: the shares of the wave slots (measured: 2.0 / 2.7 / 3.2 ->
       // 41.2 / 38.9 / 40.3 us serial, 31.5 / 30.8 / 33.0 us overlapped with a quarter of the streams noisy: profiles/r05_mixed_batches.txt)
-      h->mix_R = v.R; h->mix_cost = 2.7;
+      h->mix_R = v.R; h->mix_cost = 2.7; h->mix_rho = 12.7;
 #ifdef SDRFM_DEV
       if (const char* e = getenv("SDRFM_MIX_COST")) h->mix_cost = atof(e);
+      if (getenv("SDRFM_MIX_SPLIT_OFF")) h->mix_split_off = true;
+      if (const char* e = getenv("SDRFM_MIX_RHO")) h->mix_rho = atof(e);
 #endif
       h->mix_lds = (cfg->audio_taps == SDRFM_Q_TA) ? sdrfm_q_mix_lds(h->q_c0, h->q_nslot, cfg->fir_decim, cfg->audio_decim, v.T, h->mix_R) : 0u;
       if (h->mix_lds) {
@@ -1805,6 +1808,29 @@ static int enqueue(sdrfm* h, const uint8_t* d_iq, size_t iq_stride, uint32_t nby
       const uint32_t total = h->mix_waves_per_cu * h->n_cu;
       bx_waves = (uint32_t)((double)total * share + 0.5);
       if (bx_waves < n_noisy) bx_waves = n_noisy;
+      // The whole grid is resident at once, so the launch lasts as long as its LONGEST wave, and both kinds of wave come in whole units: a design-B segment walks
+      // ceil(NA Da / 256) sub-tiles (a partly filled one costs a whole one), a design-Q run ceil((quads + runs) / runs) quads.  Around the share above, the number of
+      // segments per routed stream is therefore chosen for the smaller of the two maxima — a sub-tile of design B weighs 12.7 quads of design Q in a wave's time at
+      // this shape (64 taps, / 10: calibrated at 25 % routed streams, where 16 segments of six sub-tiles beside runs of 76 quads balance) —, ties for the fuller
+      // sub-tiles: 28.4 -> 27.1 us per call with a quarter of the streams routed (profiles/r06_mixed_split.txt).  Other shapes keep the share as it is.
+      if (c.fir_taps == 64 && c.fir_decim == 10 && h->mix_R == 4 && A >= 64 && !h->mix_split_off) {
+        const uint32_t nyt = 64u * h->mix_R, qt = ((M + 7u) / 8u + 3u) / 4u, s0 = bx_waves / n_noisy;
+        double best_cost = 1e30, best_eff = 0.0;
+        uint32_t best_s = 0;
+        for (uint32_t sg = s0 > 6u ? s0 - 6u : 1u; sg <= s0 + 4u; ++sg) {
+          const uint32_t na = (A + sg - 1u) / sg, tiles = (A + na - 1u) / na;
+          if ((uint64_t)tiles * n_noisy + n_clean > total) break;
+          const uint32_t sub = (na * c.audio_decim + nyt - 1u) / nyt;
+          uint32_t rr = (total - tiles * n_noisy) / n_clean;
+          if (rr > q_steps / 2u) rr = q_steps / 2u;
+          if (rr < 1u) continue;
+          const uint32_t quads = (qt + rr + rr - 1u) / rr;
+          const double cost = (double)sub * h->mix_rho > (double)quads ? (double)sub * h->mix_rho : (double)quads;
+          const double eff = (double)(na * c.audio_decim) / (double)(sub * nyt);
+          if (cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && eff > best_eff)) { best_cost = cost; best_eff = eff; best_s = tiles; }
+        }
+        if (best_s) bx_waves = best_s * n_noisy;
+      }
       q_total = total > bx_waves + n_clean ? total - bx_waves : n_clean;
     } else {
       uint32_t q_slots = (uint32_t)((double)h->q_waves_per_cu * (1.0 - share) + 0.5);
