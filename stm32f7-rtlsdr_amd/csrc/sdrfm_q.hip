@@ -91,6 +91,9 @@ struct QGeo {
   static_assert(QTP + 2 * D <= 96, "the tap table of the repair path sits below the d history");
   static_assert(D % 2 == 0 && D <= 16 && (ALIGNED || D == 10), "geometries the ring logic is written for");
 };
+#ifndef SDRFM_Q_HO_RING
+#define SDRFM_Q_HO_RING 1   // 1 (round 6): the input-only part of the state hand-over copied from the ring when the run's last step begins (D = 10), not fetched and stored behind it
+#endif
 #ifndef SDRFM_Q_K3
 #define SDRFM_Q_K3 1    // 1 (round 6): K3 as a difference of angles, the guard's norms taken from the arctangent (q_angle); 0: the conjugate-product form of rounds 3 - 5
 #endif
@@ -775,6 +778,27 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
     t_last = __builtin_readcyclecounter();
 #endif
     read_step(B, kk == 0);
+#if SDRFM_Q_HO_RING
+    // (round 6) The part of the state hand-over that is a copy of INPUT bytes — the call's last T - 1 samples in two formats, the last 64 raw ones for the next
+    // call's repair path — is taken from the RING when the run's last step begins (the row's last bytes lie in that step's window, which has just landed; no
+    // fetch is issued after this point) and stored at once: behind the last step it was a fetch from memory and three stores at the very end of the stream's
+    // last wave, and a wave cannot end before its stores are acknowledged (profiles/r06_q_experiments.txt item 8).  Linear rings only (D = 10): ring byte of grid
+    // byte G is PRE + G mod RINGB; the swizzled rings keep the copy behind the loop.
+    if constexpr (!ALIGNED) {
+      if (LAST && last_run) {
+        const KargPtr pp = kargs();
+        const int HTe = (int)pp->T - 1, Ge = 2 * (int)pp->N - gb;     // grid byte offset of the row's end
+        for (int k = lane; k < HTe; k += 64) {
+          const unsigned raw = *reinterpret_cast<const unsigned short*>(smem + PRE + ((Ge - 2 * HTe + 2 * k) % RINGB));
+          reinterpret_cast<unsigned short*>(pp->hist_b_out)[(size_t)stream * HTe + k] = (unsigned short)raw;
+          pp->hist_x_out[(size_t)stream * HTe + k] = make_float2((float)(raw & 0xffu) - 127.5f, (float)(raw >> 8) - 127.5f);
+        }
+        if (lane < 2 * QTP / 16)
+          *reinterpret_cast<qi4_t*>(pp->hist_q_out + (size_t)(2 * QTP) * stream + 16 * lane) =
+              *reinterpret_cast<const qi4_t*>(smem + PRE + ((Ge - 2 * QTP + 16 * lane) % RINGB));
+      }
+    }
+#endif
     Q_PHASE(1);                                                 // wait for the step's bytes, window reads issued
     if (!(SDRFM_Q_PEEL && LAST)) refill_step(kk);
 #ifdef SDRFM_Q_EARLYSTORE   // experiment (round 5): the stages parked so far are stored BEFORE the run's last step computes (their acknowledgements then come
@@ -1056,7 +1080,7 @@ __device__ __forceinline__ void mfir_body(const SdrfmQParams& p, const uint32_t 
   }
 
   // ---- state hand-over by the wave that holds the end of the stream's chunk --------------------------------------------------
-  if (last_run) {
+  if (last_run && !(SDRFM_Q_HO_RING && !ALIGNED)) {               // (linear rings: copied from the ring when the last step began)
     const unsigned char* row = pe->iq + (size_t)stream * pe->iq_stride;
     const int HTe = (int)pe->T - 1;
     const size_t Ne = pe->N;
