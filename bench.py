@@ -126,6 +126,8 @@ def latest_traffic(kernel_name, alg_bytes=None):
                 t = json.load(f)
             if t.get("kernel_name") != kernel_name or "hbm_bytes_per_launch" not in t:
                 continue
+            if str(t.get("workload", "")).endswith("_pcm") != PCM_CALL["on"]:   # (the counters of --pcm-call runs belong to those runs only)
+                continue
             ab = t.get("algorithmic_bytes_per_launch")
             if alg_bytes is not None and ab and abs(ab - alg_bytes) > 1e-3 * alg_bytes:
                 continue
@@ -285,6 +287,7 @@ def pick_batches(args, bytes_per_batch):
     return max(3, -(-int(1.5 * L3_BYTES) // int(bytes_per_batch)) + 1)   # (nb - 1) batches between two uses of one > 1.5 x L3
 
 
+PCM_CALL = {"on": False}                                         # --pcm-call pcm | both: every call through sdrfm_process_batch_pcm
 DIST_DEVICE = {"d": "cuda"}         # where the ranks' bookkeeping tensors live (the CPU test of that bookkeeping, under gloo, sets "cpu")
 TIMED_WITH_BARRIER = {"s": None}   # (N > 1: the last timed region's wall clock with the closing barrier inside the bracket, MAX over ranks)
 
@@ -446,6 +449,7 @@ def main():
     last = {"n": 0}
 
     pcm_sink = pcm_bufs = None
+    PCM_CALL["on"] = args.pcm_call != "none"
     if args.pcm_call != "none":                                   # (profiling aid: every call leaves the PCM — three buffers in turn — instead of / beside the audio)
         alpha_p, gain_p = float(pkg.load_library().sdrfm_pcm_alpha(48000.0, 75e-6)), float(32767.0 / (2 * np.pi * 75e3 / (fs / D)))
         pcm_sink = pkg.PcmSink(ns, alpha_p, gain_p, device=local_rank)
